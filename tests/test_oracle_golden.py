@@ -1,0 +1,174 @@
+"""Pin the numpy oracle (oracle/oracle_np.py) against the golden vectors that
+oracle/gen_golden.py produced from the real reference (CPU only)."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_np as O
+from prego_amd import weights as W
+from prego_amd.config import assembly101_cfg, epic_tent_cfg
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ld(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.mark.parametrize("tag,gain", [("plain", 1.0), ("peaky", 8.0)])
+def test_g1_miniroad_eval_cfg1(tag, gain):
+    """BASELINE config 1: 1 clip x 256 frames x 2048-d, zero flow, CPU."""
+    g = _ld(f"g1_miniroad_eval_{tag}.npz")
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=gain)
+    rgb = W.tsn_features((1, 256, 2048), 20, "g1.rgb")
+    out = O.miniroad_forward(sd, rgb, None, keep=True)            # zero flow == skipped columns
+    assert np.abs(out["logits"][0] - g["probs"]).max() < 2e-6   # fp64 oracle vs torch fp32
+    assert np.abs(out["h_last"][0] - g["h_last"]).max() < 2e-6
+    srt = np.sort(g["probs"], 1)
+    safe = (srt[:, -1] - srt[:, -2]) > 1e-5
+    assert np.array_equal(out["logits"][0].argmax(1)[safe], g["argmax"][safe])
+    # the same with an explicit all-zero flow tensor (the reference's actual call)
+    out2 = O.miniroad_forward(sd, rgb, np.zeros_like(rgb))
+    assert np.abs(out2["logits"] - out["logits"]).max() < 1e-12
+
+
+def test_g2_long_T_4096_nonzero_flow():
+    g = _ld("g2_miniroad_longT_4096.npz")
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    T = 4096
+    rgb = W.tsn_features((1, T, 2048), 20, f"g2.rgb.{T}")
+    flow = W.tsn_features((1, T, 2048), 20, f"g2.flow.{T}")
+    out = O.miniroad_forward(sd, rgb, flow, dt=np.float32)["logits"][0]
+    assert np.abs(out[g["sample_idx"]] - g["sample_probs"]).max() < 5e-5
+    safe = g["margin"] > 2e-4
+    assert np.array_equal(out.argmax(1)[safe], g["argmax"][safe].astype(np.int64))
+
+
+def test_g3_intermediates():
+    g = _ld("g3_miniroad_intermediates.npz")
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20)
+    rgb = W.tsn_features((1, 8, 2048), 20, "g3.rgb")
+    flow = W.tsn_features((1, 8, 2048), 20, "g3.flow")
+    out = O.miniroad_forward(sd, rgb, flow, keep=True)
+    for k, tol in (("y", 5e-6), ("e", 2e-5), ("h", 2e-6), ("raw_logits", 2e-6)):
+        assert np.abs(out[k][0] - g[k]).max() < tol, k
+    assert np.abs(out["logits"][0] - g["probs"]).max() < 1e-6
+
+
+def _small_cfg():
+    return assembly101_cfg(rgb_type="rgb_kinetics_bninception", no_flow=True, embedding_dim=128,
+                           hidden_dim=64, num_classes=12, dropout=0.0, window_size=16, batch_size=4)
+
+
+def _targets(B, T, C, seed, name):
+    cls = (W.uniform01((B, T), seed, name) * C).astype(np.int64)
+    tgt = np.zeros((B, T, C), dtype=np.float32)
+    bi, ti = np.meshgrid(np.arange(B), np.arange(T), indexing="ij")
+    tgt[bi, ti, cls] = 1.0
+    return tgt
+
+
+def test_g4_loss_grads_adamw_small():
+    g = _ld("g4_miniroad_train_small.npz")
+    cfg = _small_cfg()
+    sd = {k: v.astype(np.float64) for k, v in W.miniroad_state_dict(cfg, 20).items()}
+    rgb = W.tsn_features((4, 16, 1024), 20, "g4.rgb")
+    tgt = _targets(4, 16, 12, 20, "g4.tgt")
+    tgt[3, -1] = 0.0
+    tgt[2, -1, 5] = 1.0
+    m = {k: np.zeros_like(v) for k, v in sd.items()}
+    v = {k: np.zeros_like(vv) for k, vv in sd.items()}
+    for step in range(3):
+        loss, grads = O.miniroad_loss_and_grads(sd, rgb, None, tgt)
+        assert abs(loss - g["losses"][step]) < 2e-6
+        if step == 0:
+            for k in sd:
+                ref = g["grad." + k]
+                assert np.abs(grads[k] - ref).max() < 1e-6 + 1e-4 * np.abs(ref).max(), k
+        for k in sd:
+            sd[k], m[k], v[k] = O.adamw_step(sd[k], grads[k], m[k], v[k], step + 1)
+        if step in (0, 2):
+            for k in sd:
+                assert np.abs(sd[k] - g[f"param{step + 1}." + k]).max() < 2e-6, k
+
+
+def test_g4b_loss_grads_full_dims():
+    g = _ld("g4b_miniroad_train_full.npz")
+    cfg = assembly101_cfg(dropout=0.0)
+    sd = W.miniroad_state_dict(cfg, 20)
+    rgb = W.tsn_features((2, 8, 2048), 20, "g4b.rgb")
+    flow = W.tsn_features((2, 8, 2048), 20, "g4b.flow")
+    tgt = _targets(2, 8, 86, 20, "g4b.tgt")
+    loss, grads = O.miniroad_loss_and_grads(sd, rgb, flow, tgt)
+    assert abs(loss - float(g["loss"])) < 2e-6
+    for k in sd:
+        gg = grads[k].reshape(-1)
+        assert abs(np.linalg.norm(gg) - float(g["norm." + k])) < 1e-4 * float(g["norm." + k]) + 1e-9, k
+        ref = g["val." + k]
+        assert np.abs(gg[g["idx." + k]] - ref).max() < 1e-7 + 1e-3 * np.abs(ref).max(), k
+
+
+def _vit_cfg():
+    return assembly101_cfg(model="Transformer", window_size=128, patch_dim=1, num_heads=8,
+                           attn_dropout_rate=0.0, dropout=0.0)
+
+
+def test_g5_vit_forward():
+    g = _ld("g5_vit_forward.npz")
+    cfg = _vit_cfg()
+    sd = W.vit_state_dict(cfg, 20)
+    rgb = W.tsn_features((2, 128, 2048), 20, "g5.rgb")
+    flow = W.tsn_features((2, 128, 2048), 20, "g5.flow")
+    out = O.vit_forward(sd, rgb, flow, heads=8, keep=True)
+    assert out["logits"].shape == (2, 1, 86)
+    assert np.abs(out["logits"] - g["logits"]).max() < 2e-5
+    for k in ("ln1", "attn", "ln2", "ffn"):
+        assert np.abs(out[k][:, g["rows"]] - g[k]).max() < 5e-5, k
+
+
+@pytest.mark.parametrize("L", [128, 1024])
+def test_g6_causal_attention(L):
+    g = _ld(f"g6_causal_attention_L{L}.npz")
+    sd = W.attention_layer_state_dict(2048, 20)
+    x = W.normal((1, L, 2048), 20, f"g6.x.{L}")
+    args = [sd[n + s].astype(np.float64) for n in ("query_projection", "key_projection", "value_projection", "out_projection")
+            for s in (".weight", ".bias")]
+    o = O.causal_attention_layer(x.astype(np.float64), *args, heads=8)
+    assert np.abs(o[0][g["rows"]] - g["out"]).max() < 2e-5
+    # causality property
+    x2 = x.copy()
+    x2[0, -1] += 1.0
+    o2 = O.causal_attention_layer(x2.astype(np.float64), *args, heads=8)
+    assert np.array_equal(o[0, :-1], o2[0, :-1])
+
+
+def test_g7_evaluate_json_and_argmax():
+    g = json.load(open(os.path.join(G, "g7_evaluate.json")))
+    cfg = epic_tent_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    for i, T in enumerate(g["lens"]):
+        rgb = W.tsn_features((T, 2048), 20, f"g7.rgb.{i}")
+        probs = O.miniroad_forward(sd, rgb[None], None)["logits"][0]
+        seg = (np.arange(T) // 37) % 12
+        tgt = np.zeros((T, 12), np.float32)
+        tgt[np.arange(T), seg] = 1.0
+        pred, gt = O.eval_argmax(probs, tgt)
+        ref = g["output"][f"synth_video_{i}"]
+        srt = np.sort(probs, 1)
+        safe = (srt[:, -1] - srt[:, -2]) > 1e-5
+        assert np.array_equal(pred[safe], np.array(ref["pred"])[safe])
+        assert gt.tolist() == ref["gt"]
+
+
+def test_g8_aggregate_known_answer():
+    with gzip.open(os.path.join(G, "g8_output_miniROAD.json.gz"), "rt") as f:
+        data = json.load(f)
+    want = json.load(open(os.path.join(G, "g8_aggregated_data.json")))
+    assert json.load(open(os.path.join(G, "g8_meta.json")))["shipped_equals_rerun"]
+    assert O.aggregate(data) == want
