@@ -1,0 +1,108 @@
+/* prego_amd.h - C ABI of the MI355X-native PREGO step_recognition hot path.
+ *
+ * The reference (aleflabo/PREGO) is pure Python and has no FFI; its plug-in API for this path is the
+ * string registry (step_recognition/utils/registry.py:6-20, model/model_builder.py:5-9).  The entry points
+ * below are what a binding of that plug-in boundary needs; each one cites the reference interface it
+ * replaces.  INTEGRATION.md shows the ctypes stub a PREGO maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no torch / HIP types in signatures
+ *    (`prego_stream_t` is a `hipStream_t` passed as void*; NULL = the default stream).
+ *  - every pointer called "device" is HBM memory of the current HIP device, fp32, row-major contiguous.
+ *  - functions return 0 on success, a negative PREGO_E* code otherwise; prego_last_error() gives the text.
+ *  - calls only enqueue work on the caller's stream; nothing synchronises except prego_miniroad_check().
+ *  - the caller owns inputs, outputs and the workspace; they must stay valid until the stream reaches the
+ *    end of the call.  The handle owns converted weight copies and small plan tables.
+ *  - one handle per (device, stream); different handles are independent and re-entrant.
+ */
+#ifndef PREGO_AMD_H
+#define PREGO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PREGO_ABI_VERSION 1
+
+enum {
+  PREGO_OK = 0,
+  PREGO_EINVAL = -1,       /* bad argument / unsupported dimension */
+  PREGO_EHIP = -2,         /* a HIP runtime call failed */
+  PREGO_EWORKSPACE = -3,   /* workspace too small */
+  PREGO_ETIMEOUT = -4      /* the persistent recurrence kernel gave up waiting (reported by _check) */
+};
+
+/* arithmetic type of the MFMA operands; accumulation, GRU state, LayerNorm and softmax are always fp32 */
+enum { PREGO_F32 = 0, PREGO_BF16 = 1 };
+
+/* forward() flags */
+enum {
+  PREGO_FWD_SOFTMAX = 1,   /* eval branch of MROAD.forward: out = softmax(logits) (rnn.py:66-70); else raw logits */
+  PREGO_FWD_KEEP = 2       /* keep activations for backward() in the training workspace */
+};
+
+typedef void* prego_stream_t;
+typedef struct prego_miniroad prego_miniroad;
+
+int prego_abi_version(void);
+const char* prego_last_error(void);
+
+/* ---- MiniROAD (MROAD, registry name "MiniROAD"): step_recognition/model/rnn/rnn.py:18-71 ---------------- */
+
+/* MROAD.__init__ (rnn.py:21-49): d_rgb/d_flow = FEATURE_SIZES of cfg['rgb_type'/'flow_type'] (0 when
+ * --no_rgb/--no_flow), emb = cfg['embedding_dim'], hid = cfg['hidden_dim'], n_classes = cfg['num_classes'].
+ * Supported on gfx950: hid == 1024, emb % 256 == 0 (<= 4096), (d_rgb + d_flow) % 64 == 0, n_classes <= 128. */
+int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
+                          int compute_dtype);
+void prego_miniroad_destroy(prego_miniroad* h);
+
+/* load_state_dict (main.py:48): device fp32 tensors with the reference's state_dict shapes
+ *   layer1.0.weight [emb, d_rgb+d_flow]  layer1.0.bias [emb]   layer1.1.weight/bias [emb]   (rnn.py:39-44)
+ *   gru.weight_ih_l0 [3*hid, emb]  gru.weight_hh_l0 [3*hid, hid]  gru.bias_ih_l0/bias_hh_l0 [3*hid] (rnn.py:38)
+ *   f_classification.0.weight [n_classes, hid]  f_classification.0.bias [n_classes]          (rnn.py:45-47)
+ * The handle keeps its own (converted) copies: call again after every optimizer step. */
+int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1_w, const float* layer1_b, const float* ln_w,
+                               const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih,
+                               const float* b_hh, const float* fc_w, const float* fc_b, prego_stream_t stream);
+
+/* Largest number of clips one forward() call can advance together (clips beyond it: call again). */
+int prego_miniroad_max_clips(const prego_miniroad* h);
+
+/* Workspace size (bytes) that lets forward() process `rows_per_chunk` packed rows (frames) per pipeline
+ * pass; any size >= the value for rows_per_chunk = n_clips works, larger chunks run faster.
+ * flags: PREGO_FWD_KEEP adds the activations backward() needs (whole batch resident). */
+size_t prego_miniroad_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens,
+                                      int64_t rows_per_chunk, int flags);
+
+/* MROAD.forward (rnn.py:51-71) for a ragged batch, and the device half of Evaluate.eval (trainer/eval.py:36-56).
+ *   lens[i]            frames of clip i (host array)
+ *   rgb[i], flow[i]    device fp32 [lens[i], d_rgb] / [lens[i], d_flow]; flow == NULL or flow[i] == NULL means an
+ *                      all-zero flow half (datasets/dataset.py:69) and skips its half of layer1's K dimension
+ *   out[i]             device fp32 [lens[i], n_classes]: probabilities (PREGO_FWD_SOFTMAX) or logits; nullable
+ *   argmax[i]          device int32 [lens[i]]: np.argmax(prob, axis=1) of eval.py:53, first max wins; nullable
+ *   h0 / h_last        device fp32 [n_clips, hid] GRU state before frame 0 / after the last frame of each clip;
+ *                      NULL h0 = zeros (rnn.py:49,60).  Chaining h_last -> h0 gives streaming inference.
+ * The pointer arrays themselves are host arrays (copied during the call). */
+int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* rgb,
+                           const float* const* flow, float* const* out, int32_t* const* argmax, const float* h0,
+                           float* h_last, int flags, void* workspace, size_t workspace_bytes,
+                           prego_stream_t stream);
+
+/* Synchronises `stream` and reports a recurrence timeout (PREGO_ETIMEOUT) or HIP error since the last check. */
+int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream);
+
+/* Kernel-level timing hooks for bench.py's roofline leg: when enabled, forward() brackets its GEMM launches and
+ * its recurrence launches with HIP events on the caller's stream; read() synchronises and returns the summed
+ * milliseconds and launch counts since enable. */
+int prego_miniroad_timing_enable(prego_miniroad* h, int enable);
+int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flop,
+                               double* gru_ms, int64_t* gru_launches, double* pack_ms, int64_t* pack_launches,
+                               double* pack_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PREGO_AMD_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of libprego_amd.so (include/prego_amd.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded the
+import of the product path fails loudly.  (`python -m prego_amd.build` or
+`__graft_entry__.build()` produces the library in-tree.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprego_amd.so")
+
+PREGO_F32, PREGO_BF16 = 0, 1
+FWD_SOFTMAX, FWD_KEEP = 1, 2
+E_TIMEOUT = -4
+
+# every symbol include/prego_amd.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "prego_abi_version", "prego_last_error",
+    "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_set_weights",
+    "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
+    "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
+]
+
+
+class PregoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PregoError(
+            f"{LIB_PATH} not found: the HIP library has not been built. Run `python -m prego_amd.build` "
+            "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+    lib.prego_abi_version.restype = i32
+    lib.prego_last_error.restype = C.c_char_p
+    lib.prego_miniroad_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
+    lib.prego_miniroad_destroy.argtypes = [vp]
+    lib.prego_miniroad_destroy.restype = None
+    lib.prego_miniroad_set_weights.argtypes = [vp] + [vp] * 10 + [vp]
+    lib.prego_miniroad_max_clips.argtypes = [vp]
+    lib.prego_miniroad_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32), i64, i32]
+    lib.prego_miniroad_workspace_bytes.restype = sz
+    lib.prego_miniroad_forward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp),
+                                           C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp, sz, vp]
+    lib.prego_miniroad_check.argtypes = [vp, vp]
+    lib.prego_miniroad_timing_enable.argtypes = [vp, i32]
+    lib.prego_miniroad_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
+                                               C.POINTER(i64), C.POINTER(C.c_double)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):
+            pass
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise PregoError(f"prego_amd error {rc}: {load().prego_last_error().decode()}")
+
+
+def ptr_array(ptrs):
+    """host array of device pointers (None -> NULL)"""
+    arr = (C.c_void_p * len(ptrs))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p
+    return arr

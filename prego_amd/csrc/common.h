@@ -1,0 +1,75 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// Wave = 64 lanes, 4 SIMDs per CU, MFMA 16x16x32 bf16 / 16x16x4 f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef unsigned short bf16_t;                               // raw bf16 bits in memory
+
+#define PREGO_WAVE 64
+#define AUX_SC1 16          // buffer/global aux bit: system-coherent level 1 = bypass the per-CU L1
+
+// fp32 -> bf16, round to nearest even.  A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+// (NaN-safe, MI355X_MICROARCH.md "Correctness boundaries").
+__device__ __forceinline__ bf16_t f2bf(float x) {
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) {
+  return __builtin_bit_cast(float, (unsigned)b << 16);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// streaming (read-once) 16-byte load
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+  const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp: accurate to ~1e-7 abs, saturates cleanly
+__device__ __forceinline__ float tanhf_(float x) {
+  float e = __expf(-2.0f * fabsf(x));
+  float t = (1.0f - e) / (1.0f + e);
+  return copysignf(t, x);
+}
+
+// Packed time-major row layout (the cuDNN/PackedSequence idea, rebuilt for this path):
+// clips are sorted by length, descending; at time t the first nact[t] sorted clips are alive;
+// row(t, i) = rowoff[t] + i.  Everything between the pack kernel and the head kernel is
+// indexed by packed row, so a chunk of time steps is a contiguous row range.
+struct PackedPlan {
+  const int* rowoff;      // [T_max + 1] prefix sum of nact (absolute, over the whole pass)
+  const int* nact;        // [T_max]
+  const int* sorted_clip; // [n_clips] sorted position -> caller's clip index
+  int t_max;
+  int n_clips;
+};
+
+// largest t with rowoff[t] <= row  (row < rowoff[t_max])
+__device__ __forceinline__ int plan_time_of_row(const int* __restrict__ rowoff, int t_max, int row) {
+  int lo = 0, hi = t_max;            // invariant: rowoff[lo] <= row < rowoff[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (rowoff[mid] <= row) lo = mid; else hi = mid;
+  }
+  return lo;
+}

@@ -1,0 +1,222 @@
+// Dense "NT" GEMMs of the MiniROAD path:  C[M,N] = A[M,K] . B[N,K]^T + bias[N]
+// (nn.Linear semantics: both operands K-contiguous).  Call sites replaced:
+//   layer1[0]  Linear(4096,2048)      model/rnn/rnn.py:40     M = packed rows, N = 2048, K = 4096
+//   GRU input projection W_ih          model/rnn/rnn.py:38,61  M = packed rows, N = 3072, K = 2048
+//
+// bf16 kernel (the product path): 128x128x64 tiles, 4 waves (2x2, 64x64 each), 16x16x32 bf16 MFMA,
+// fp32 accumulate.  Operands go HBM -> LDS with 16-byte LDS-DMA (global_load_lds_dwordx4); the LDS image
+// is lane-linear per wave-instruction (8 rows x 128 B), the 16-byte chunk XOR-swizzle sits on the SOURCE
+// address and on the ds_read address (cdna_hip_programming.md rule 21) so the ds_read_b128 fragments are
+// bank-conflict free.  Two LDS buffers, one barrier per K tile.  Block ids are remapped so that one XCD's
+// L2 sees consecutive N tiles of the same M tile (A rows are re-used from L2).
+//
+// fp32 kernel (parity mode): exact-fp32 MFMA 16x16x4 (bit-for-bit an fmaf chain), register staged.
+#include "common.h"
+#include "kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // bijective XCD-aware remap (cdna_hip_programming.md, T1): blocks b and b+8 share an XCD
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename OutT, bool RELU_IN /*unused*/>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+    OutT* __restrict__ C, int M, int N, int K, int lda, int ldb) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int ntm = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  // per-lane staging source (row within the 8-row group of a wave-instruction, swizzled chunk)
+  const int sr = lane >> 3;          // 0..7
+  const int scp = lane & 7;          // chunk position in LDS
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + sr;                 // tile row 0..127
+    const int c = scp ^ ((r >> 1) & 7);                    // source chunk that lands at position scp
+    int ar = m0 + r; if (ar > M - 1) ar = M - 1;           // clamp: rows past M are never stored
+    a_src[i] = A + (size_t)ar * lda + c * 8;
+    b_src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * 32768;
+    char* lb = la + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = (wave * 4 + i) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(la + off), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(lb + off), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = w*64 + i*16 + (lane&15); chunk = ks*4 + (lane>>4), swizzled
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * 32768;
+    const char* lb = la + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr;
+        af[i] = *(const bf16x8*)(la + ra * 128 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 4));
+        const int rb = wn * 64 + i * 16 + fr;
+        bfr[i] = *(const bf16x8*)(lb + rb * 128 + (((ks * 4 + fq) ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = K / BK;
+  stage(0, 0);
+  __syncthreads();                      // emits vmcnt(0): tile 0 landed
+  int cur = 0;
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    stage(cur ^ 1, kt + 1);
+    compute(cur);
+    __syncthreads();                    // vmcnt(0) + barrier: next tile landed, everyone done reading cur
+    cur ^= 1;
+  }
+  compute(cur);
+
+  // epilogue: D layout col = lane&15, row = (lane>>4)*4 + j
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+        if (m < M) {
+          float v = acc[i][j][e] + bv;
+          if constexpr (sizeof(OutT) == 2) C[(size_t)m * N + n] = f2bf(v);
+          else C[(size_t)m * N + n] = v;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// exact fp32 GEMM: 128x128x16 tiles, v_mfma_f32_16x16x4_f32.  Each lane reads 4 consecutive k
+// (one ds_read_b128) and feeds element j to the j-th MFMA; A and B use the same k permutation,
+// so the sum is over the same 16 k values.
+// ------------------------------------------------------------------------------------------
+#define FK 16
+#define FLD 20
+template <int DUMMY>
+__global__ __launch_bounds__(256) void gemm_f32_nt_kernel(
+    const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb) {
+  __shared__ __attribute__((aligned(16))) float sa[BM * FLD];
+  __shared__ __attribute__((aligned(16))) float sb[BN * FLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (N + BN - 1) / BN;
+  const int ntm = (M + BM - 1) / BM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int k0 = 0; k0 < K; k0 += FK) {
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;          // 512 float4 per operand tile
+      const int r = idx >> 2, c4 = idx & 3;
+      int ar = m0 + r; if (ar > M - 1) ar = M - 1;
+      int br = n0 + r; if (br > N - 1) br = N - 1;
+      ra[i] = *(const float4*)(A + (size_t)ar * lda + k0 + c4 * 4);
+      rb[i] = *(const float4*)(B + (size_t)br * ldb + k0 + c4 * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + i * 256;
+      const int r = idx >> 2, c4 = idx & 3;
+      *(float4*)(sa + r * FLD + c4 * 4) = ra[i];
+      *(float4*)(sb + r * FLD + c4 * 4) = rb[i];
+    }
+    __syncthreads();
+    float4 af[4], bfv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[i] = *(const float4*)(sa + (wm * 64 + i * 16 + fr) * FLD + fq * 4);
+      bfv[i] = *(const float4*)(sb + (wn * 64 + i * 16 + fr) * FLD + fq * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bfv[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bfv[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bfv[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bfv[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+          if (m < M) C[(size_t)m * N + n] = acc[i][j][e] + bv;
+        }
+      }
+    }
+}
+
+// bf16: requires N % 128 == 0, K % 64 == 0 (checked by the caller); M arbitrary (>0)
+void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int M, int N,
+                         int K, hipStream_t s) {
+  if (M <= 0) return;
+  const int ntm = (M + BM - 1) / BM, ntn = N / BN;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr_set = true;
+  }
+  gemm_bf16_nt_kernel<float, false><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb);
+}
+
+// fp32: K % 16 == 0; M, N arbitrary
+void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int M, int N,
+                        int K, hipStream_t s) {
+  if (M <= 0) return;
+  const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+  gemm_f32_nt_kernel<0><<<ntm * ntn, 256, 0, s>>>(A, B, bias, C, M, N, K, lda, ldb);
+}

@@ -1,0 +1,135 @@
+// Classification head + eval epilogue of MiniROAD, fused:
+//   logits = relu(h) W_c^T + b_c            f_classification, model/rnn/rnn.py:62-64
+//   probs  = softmax(logits, -1)            eval branch,      model/rnn/rnn.py:66-70
+//   pred   = argmax(probs, axis=1)          trainer/eval.py:53
+// and the scatter from packed time-major rows back to the caller's per-clip [T, C] arrays.
+// C <= 128.  One wave owns 16 packed rows and all C (padded to 16*NTC) columns: the row softmax is a
+// 16-lane shuffle reduce over the MFMA accumulator layout (col = lane&15, row = (lane>>4)*4 + reg).
+// HBM-bound on reading relu(h) (2 KB/row in bf16); W_c (<= 256 KB) stays in L2.
+#include "common.h"
+#include "kernels.h"
+
+template <typename WT, int NTC>
+__global__ __launch_bounds__(256) void head_softmax_kernel(
+    const WT* __restrict__ Hrelu,      // [nrows][HID] chunk-relative packed rows
+    const WT* __restrict__ Wc,         // [16*NTC][HID] zero padded rows
+    const float* __restrict__ bc,      // [16*NTC] zero padded
+    const int* __restrict__ rowoff, const int* __restrict__ sorted_clip, int t_max,
+    int row0, int nrows, int HID, int C, int apply_softmax,
+    float* const* __restrict__ out_ptrs,     // per clip [T][C] fp32 (probs or logits), entries nullable
+    int* const* __restrict__ argmax_ptrs) {  // per clip [T] int32, nullable array / entries
+  constexpr bool BF = (sizeof(WT) == 2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int rbase = (blockIdx.x * 4 + wave) * 16;
+  if (rbase >= nrows) return;
+  int arow = rbase + l15; if (arow > nrows - 1) arow = nrows - 1;
+
+  f32x4 acc[NTC];
+#pragma unroll
+  for (int j = 0; j < NTC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if constexpr (BF) {
+    const bf16_t* ap = (const bf16_t*)Hrelu + (size_t)arow * HID + 8 * l4;
+    const bf16_t* bp = (const bf16_t*)Wc + (size_t)l15 * HID + 8 * l4;
+    for (int k = 0; k < HID; k += 32) {
+      const bf16x8 af = *(const bf16x8*)(ap + k);
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        const bf16x8 bfr = *(const bf16x8*)(bp + (size_t)j * 16 * HID + k);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[j], 0, 0, 0);
+      }
+    }
+  } else {
+    const float* ap = (const float*)Hrelu + (size_t)arow * HID + 4 * l4;
+    const float* bp = (const float*)Wc + (size_t)l15 * HID + 4 * l4;
+    for (int k = 0; k < HID; k += 16) {
+      const float4 af = *(const float4*)(ap + k);
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        const float4 bv = *(const float4*)(bp + (size_t)j * 16 * HID + k);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bv.x, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bv.y, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bv.z, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bv.w, acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // lane holds, for rows r = l4*4 + e (e = 0..3), columns c = j*16 + l15
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v[NTC];
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) {
+      const int c = j * 16 + l15;
+      v[j] = acc[j][e] + bc[c];
+      if (c < C && v[j] > mx) { mx = v[j]; mi = c; }    // ascending c: first max wins inside the lane
+    }
+    // reduce (max, lowest index) over the 16 lanes that share this row
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const float omx = __shfl_xor(mx, o, 64);
+      const int omi = __shfl_xor(mi, o, 64);
+      if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+    }
+    float s = 0.f;
+    if (apply_softmax) {
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        const int c = j * 16 + l15;
+        v[j] = (c < C) ? __expf(v[j] - mx) : 0.f;
+        s += v[j];
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+      const float inv = 1.0f / s;
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) v[j] *= inv;
+    }
+    const int r = rbase + l4 * 4 + e;
+    if (r < nrows) {
+      const int row = row0 + r;
+      const int t = plan_time_of_row(rowoff, t_max, row);
+      const int clip = sorted_clip[row - rowoff[t]];
+      float* op = out_ptrs ? out_ptrs[clip] : nullptr;
+      if (op) {
+        op += (size_t)t * C;
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+          const int c = j * 16 + l15;
+          if (c < C) op[c] = v[j];
+        }
+      }
+      if (argmax_ptrs && l15 == 0) {
+        int* aptr = argmax_ptrs[clip];
+        if (aptr) aptr[t] = mi;
+      }
+    }
+  }
+}
+
+int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
+                        const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s) {
+  if (nrows <= 0) return 0;
+  const int ntc = (C + 15) / 16;
+  const int grid = (nrows + 63) / 64;
+#define HL(WT, N)                                                                                             \
+  head_softmax_kernel<WT, N><<<grid, 256, 0, s>>>((const WT*)Hrelu, (const WT*)Wc, bc, rowoff, sorted_clip,   \
+                                                  t_max, row0, nrows, hid, C, apply_softmax, out_ptrs, argmax_ptrs)
+#define HD(N)                          \
+  case N:                              \
+    if (bf16) HL(bf16_t, N);           \
+    else HL(float, N);                 \
+    break
+  switch (ntc) {
+    HD(1); HD(2); HD(3); HD(4); HD(5); HD(6); HD(7); HD(8);
+    default: return -1;
+  }
+#undef HD
+#undef HL
+  return 0;
+}

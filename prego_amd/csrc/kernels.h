@@ -1,0 +1,43 @@
+// Host-visible declarations of the kernel launchers (implemented in the .hip files).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+struct GruArgs {
+  const void* whh;       // [3H][H] bf16 or f32, reference layout of gru.weight_hh_l0 (rows r|z|n)
+  const float* b_hn;     // [H]  = gru.bias_hh_l0[2H:3H]
+  const float* gi;       // [rows][3H] fp32, chunk-relative packed rows
+  void* h_relu_out;      // [rows][H] WT  relu(h_t)  (operand of the classification GEMM), nullable
+  float* h_raw_out;      // [rows][H] fp32 h_t (kept for BPTT), nullable
+  float* h_state;        // [n_clips][H] fp32, indexed by SORTED clip position; in: h_{t0-1}, out: h_{t1-1}
+  void* hx;              // exchange buffers [G][2][16*NCT][H] WT
+  unsigned* flags;       // [G*P] one word per producer workgroup, zeroed before every launch
+  unsigned* abort_word;  // set to 1 on spin timeout
+  const int* rowoff;     // absolute packed row offsets, [t_max+1]
+  const int* nact;       // [t_max]
+  int t0, t1;            // time steps [t0, t1) handled by this launch
+  int row_base;          // rowoff[t0]: chunk-relative row = rowoff[t] - row_base + sorted_index
+  int n_clips;
+  int G;
+};
+
+void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,
+                      const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
+                      hipStream_t s);
+void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
+                    void* out, float* stats, hipStream_t s);
+void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
+void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
+                        int cols_dst, hipStream_t s);
+void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int M, int N,
+                         int K, hipStream_t s);
+void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int M, int N,
+                        int K, hipStream_t s);
+int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);
+int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
+                        const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s);
+void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
+                         hipStream_t s);
+void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s);

@@ -1,0 +1,185 @@
+// Row-wise, HBM-bound kernels of the MiniROAD path:
+//   pack_rows      feature streaming: per-clip fp32 [T,D] rgb/flow  ->  packed time-major X[row, Din]
+//                  (replaces torch.cat at model/rnn/rnn.py:53 and the batch_first layout; never
+//                  materialises the concat in fp32)
+//   ln_relu_rows   LayerNorm(E) + ReLU (model/rnn/rnn.py:41-42) on the layer1 GEMM output
+// Both are pure streaming: 16 B per lane, one pass, no LDS.
+#include "common.h"
+#include "kernels.h"
+
+// One 256-thread block per packed row.  D_rgb, D_flow multiples of 8.
+// OutT = bf16_t (MFMA operand) or float (fp32 parity mode).
+template <typename OutT>
+__global__ __launch_bounds__(256) void pack_rows_kernel(
+    const float* const* __restrict__ rgb_ptrs, const float* const* __restrict__ flow_ptrs,
+    const int* __restrict__ rowoff, const int* __restrict__ sorted_clip, int t_max,
+    int row0, int nrows, int d_rgb, int d_flow, OutT* __restrict__ X) {
+  const int din = d_rgb + d_flow;
+  for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+    const int row = row0 + r;
+    const int t = plan_time_of_row(rowoff, t_max, row);
+    const int clip = sorted_clip[row - rowoff[t]];
+    const float* rgb = rgb_ptrs ? rgb_ptrs[clip] : nullptr;
+    const float* flow = flow_ptrs ? flow_ptrs[clip] : nullptr;   // nullptr = all-zero flow half
+    OutT* dst = X + (size_t)r * din;
+    for (int c = threadIdx.x * 8; c < din; c += 256 * 8) {
+      float4 a, b;
+      const float* src = (c < d_rgb) ? (rgb ? rgb + (size_t)t * d_rgb + c : nullptr)
+                                     : (flow ? flow + (size_t)t * d_flow + (c - d_rgb) : nullptr);
+      if (src) {
+        a = nt_load4(src);
+        b = nt_load4(src + 4);
+      } else {
+        a = make_float4(0, 0, 0, 0);
+        b = a;
+      }
+      if constexpr (sizeof(OutT) == 2) {
+        uint4 o;
+        o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
+        o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+        *(uint4*)(dst + c) = o;
+      } else {
+        *(float4*)(dst + c) = a;
+        *((float4*)(dst + c) + 1) = b;
+      }
+    }
+  }
+}
+
+// One wave per row, 4 rows per block.  E multiple of 256 and <= 4096 (16 float4 per lane max).
+// Two-pass statistics in registers (mean, then centred sum of squares) = what torch's CPU
+// LayerNorm computes up to summation order; biased variance, eps inside the sqrt.
+template <typename OutT, int MAXV>
+__global__ __launch_bounds__(256) void ln_relu_rows_kernel(
+    const float* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    int nrows, int E, float eps, OutT* __restrict__ out, float* __restrict__ stats /*nullable [nrows][2]*/) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nv = E / 256;                      // float4 per lane
+  for (int r = blockIdx.x * 4 + wave; r < nrows; r += gridDim.x * 4) {
+    const float4* y = (const float4*)(Y + (size_t)r * E);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        v[i] = y[i * 64 + lane];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    const float mu = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+        q += (a * a + b * b) + (c * c + d * d);
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
+    if (stats && lane == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 g = *(const float4*)(gamma + c);
+        const float4 b = *(const float4*)(beta + c);
+        float o0 = fmaxf((v[i].x - mu) * rstd * g.x + b.x, 0.f);
+        float o1 = fmaxf((v[i].y - mu) * rstd * g.y + b.y, 0.f);
+        float o2 = fmaxf((v[i].z - mu) * rstd * g.z + b.z, 0.f);
+        float o3 = fmaxf((v[i].w - mu) * rstd * g.w + b.w, 0.f);
+        if constexpr (sizeof(OutT) == 2) {
+          uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
+          *(uint2*)(out + (size_t)r * E + c) = o;
+        } else {
+          *(float4*)(out + (size_t)r * E + c) = make_float4(o0, o1, o2, o3);
+        }
+      }
+  }
+}
+
+// fp32 -> bf16 weight conversion (set_weights)
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = f2bf(src[i]);
+}
+
+// dst[r][0:cols_dst] = bf16/f32(src[r][0:cols_src]) zero-padded to rows_dst x cols_dst
+template <typename OutT>
+__global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, int cols_src, int ld_src,
+                                   OutT* __restrict__ dst, int rows_dst, int cols_dst) {
+  size_t n = (size_t)rows_dst * cols_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / cols_dst), c = (int)(i % cols_dst);
+    float v = (r < rows_src && c < cols_src) ? src[(size_t)r * ld_src + c] : 0.f;
+    if constexpr (sizeof(OutT) == 2) dst[i] = f2bf(v); else dst[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host launchers (called from miniroad.cpp)
+// ------------------------------------------------------------------------------------------
+void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,
+                      const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
+                      hipStream_t s) {
+  if (nrows <= 0) return;
+  int grid = nrows < 65536 ? nrows : 65536;
+  if (bf16)
+    pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, rowoff, sorted_clip, t_max, row0, nrows, d_rgb,
+                                                  d_flow, (bf16_t*)X);
+  else
+    pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, rowoff, sorted_clip, t_max, row0, nrows, d_rgb,
+                                                 d_flow, (float*)X);
+}
+
+void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
+                    void* out, float* stats, hipStream_t s) {
+  if (nrows <= 0) return;
+  int grid = (nrows + 3) / 4;
+  if (grid > 16384) grid = 16384;
+  if (E <= 2048) {
+    if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats);
+    else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats);
+  } else {
+    if (bf16) ln_relu_rows_kernel<bf16_t, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats);
+    else ln_relu_rows_kernel<float, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats);
+  }
+}
+
+void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
+  int grid = (int)((n + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  f32_to_bf16_kernel<<<grid, 256, 0, s>>>(src, (bf16_t*)dst, n);
+}
+
+void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
+                        int cols_dst, hipStream_t s) {
+  size_t n = (size_t)rows_dst * cols_dst;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  if (bf16) pad_convert_kernel<bf16_t><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (bf16_t*)dst, rows_dst, cols_dst);
+  else pad_convert_kernel<float><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (float*)dst, rows_dst, cols_dst);
+}
+
+// h-state rows between the caller's clip order and the sorted (by length) order used internally
+__global__ void permute_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                    const int* __restrict__ sorted_clip, int n, int width, int to_sorted) {
+  const int i = blockIdx.x;              // sorted position
+  if (i >= n) return;
+  const int c = sorted_clip[i];
+  const float* s = to_sorted ? src + (size_t)c * width : src + (size_t)i * width;
+  float* d = to_sorted ? dst + (size_t)i * width : dst + (size_t)c * width;
+  for (int k = threadIdx.x; k < width; k += blockDim.x) d[k] = s[k];
+}
+void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
+                         hipStream_t s) {
+  if (n > 0) permute_rows_kernel<<<n, 256, 0, s>>>(src, dst, sorted_clip, n, width, to_sorted);
+}
+
+// out[i] = a[i] + (i < n_add ? b[i] : 0)   (folds b_hh's r,z rows into the W_ih GEMM bias)
+__global__ void add_vec_kernel(const float* a, const float* b, float* out, int n, int n_add) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + (i < n_add ? b[i] : 0.f);
+}
+void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s) {
+  add_vec_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n, n_add);
+}

@@ -1,0 +1,89 @@
+"""`MiniROAD` behind the reference's plug-in API (step_recognition/model/rnn/rnn.py:18-71).
+
+Same constructor (`MROAD(cfg)`), same `forward(rgb_input, flow_input) -> {'logits': ...}`
+(probabilities in eval mode, raw logits in training mode, rnn.py:66-70), same
+state_dict keys/shapes/dtypes (`gru.*`, `layer1.*`, `f_classification.*`), so reference
+checkpoints load here and ours load there.  The torch sub-modules are parameter
+containers only (constructed in the reference's order, so a given torch seed gives
+the reference's initial weights); every FLOP runs in libprego_amd.so.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .config import FEATURE_SIZES
+from .engine import MiniRoadEngine
+from ._lib import PregoError
+from .registry import META_ARCHITECTURES
+
+
+@META_ARCHITECTURES.register("MiniROAD")
+class MROAD(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.use_flow = not cfg["no_flow"]
+        self.use_rgb = not cfg["no_rgb"]
+        self.d_rgb = FEATURE_SIZES[cfg["rgb_type"]] if self.use_rgb else 0
+        self.d_flow = FEATURE_SIZES[cfg["flow_type"]] if self.use_flow else 0
+        self.input_dim = self.d_rgb + self.d_flow
+        self.hidden_dim = cfg["hidden_dim"]
+        self.num_layers = cfg["num_layers"]
+        self.out_dim = cfg["num_classes"]
+        self.window_size = cfg["window_size"]
+        self.embedding_dim = cfg["embedding_dim"]
+        if self.num_layers != 1:
+            raise PregoError("prego_amd MiniROAD supports num_layers == 1 (both shipped configs)")
+        # parameter containers, reference construction order (rnn.py:38-47)
+        self.gru = nn.GRU(self.embedding_dim, self.hidden_dim, self.num_layers, batch_first=True)
+        self.layer1 = nn.Sequential(
+            nn.Linear(self.input_dim, self.embedding_dim),
+            nn.LayerNorm(self.embedding_dim),
+            nn.ReLU(),
+            nn.Dropout(p=cfg["dropout"]),
+        )
+        self.f_classification = nn.Sequential(nn.Linear(self.hidden_dim, self.out_dim))
+        # build-specific knobs (not reference keys)
+        self.compute_dtype = cfg.get("compute_dtype", "bf16")          # 'bf16' | 'fp32'
+        self.assume_zero_flow = bool(cfg.get("assume_zero_flow", False))  # dataset.py:69 zeroes the flow half
+        self._engine = None
+        self._engine_key = None
+        self._w_versions = None
+
+    # -- engine plumbing -------------------------------------------------------------------
+    def engine(self) -> MiniRoadEngine:
+        dev = self.layer1[0].weight.device
+        key = (dev, self.compute_dtype)
+        if self._engine is None or self._engine_key != key:
+            self._engine = MiniRoadEngine(self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim, self.out_dim,
+                                          dev, self.compute_dtype)
+            self._engine_key = key
+            self._w_versions = None
+        vers = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if vers != self._w_versions:
+            self._engine.set_weights(dict(self.named_parameters()))
+            self._w_versions = vers
+        return self._engine
+
+    def forward(self, rgb_input, flow_input):
+        if self.training:
+            from .autograd import miniroad_train_forward
+            return {"logits": miniroad_train_forward(self, rgb_input, flow_input)}
+        eng = self.engine()
+        src = rgb_input if self.use_rgb else flow_input
+        B, T = src.shape[0], src.shape[1]
+        rgb = [rgb_input[b].contiguous() for b in range(B)] if self.use_rgb else None
+        if self.use_flow and not self.assume_zero_flow:
+            flow = [flow_input[b].contiguous() for b in range(B)]
+        else:
+            flow = None
+        if not self.use_rgb:
+            raise PregoError("--no_rgb (flow-only) models are not supported by the HIP path yet")
+        outs, _, _ = eng.forward_ragged(rgb, flow, softmax=True)
+        return {"logits": torch.stack(outs, 0)}
+
+    @torch.no_grad()
+    def forward_clips(self, rgb_list, flow_list=None, want_probs=True, want_argmax=True):
+        """Ragged batched inference (the data-parallel hot path): many whole videos per call."""
+        eng = self.engine()
+        return eng.forward_ragged(rgb_list, flow_list, softmax=True, want_out=want_probs, want_argmax=want_argmax)
