@@ -102,6 +102,11 @@ int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm
                                double* gru_ms, int64_t* gru_launches, double* pack_ms, int64_t* pack_launches,
                                double* pack_bytes);
 
+/* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
+ * recurrence kernel: out8[0..4] = gather, mfma, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
+ * [6] = time steps.  Synchronises the device. */
+int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
+
 #ifdef __cplusplus
 }
 #endif

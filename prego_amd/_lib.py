@@ -22,6 +22,7 @@ SYMBOLS = [
     "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
+    "prego_miniroad_debug_stamps",
 ]
 
 
@@ -40,6 +41,9 @@ def load() -> C.CDLL:
         raise PregoError(
             f"{LIB_PATH} not found: the HIP library has not been built. Run `python -m prego_amd.build` "
             "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
+    # torch ships its own libamdhip64; import it first so that the one HIP runtime in the process is
+    # torch's (loading ours first makes torch's copy fail with "no ROCm-capable device")
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     lib.prego_abi_version.restype = i32
@@ -58,6 +62,7 @@ def load() -> C.CDLL:
     lib.prego_miniroad_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                                C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                                C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.prego_miniroad_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef unsigned short bf16_t;                               // raw bf16 bits in memory
 
 #define PREGO_WAVE 64
+#define AUX_NT 2            // non-temporal: streams through (bypasses) the per-CU L1, L2-served
 #define AUX_SC1 16          // buffer/global aux bit: system-coherent level 1 = bypass the per-CU L1
 
 // fp32 -> bf16, round to nearest even.  A plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
@@ -44,13 +45,11 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-// tanh via exp: accurate to ~1e-7 abs, saturates cleanly
-__device__ __forceinline__ float tanhf_(float x) {
-  float e = __expf(-2.0f * fabsf(x));
-  float t = (1.0f - e) / (1.0f + e);
-  return copysignf(t, x);
-}
+// v_exp_f32 + v_rcp_f32 (1 ulp each): the recurrence runs one wave per SIMD, every VALU instruction is ~4 cycles of
+// the step's critical path, so no IEEE division sequences here
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// tanh(x) = 2 sigmoid(2x) - 1: abs error ~1e-7, saturates cleanly (exp overflow -> rcp(inf) = 0)
+__device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // Packed time-major row layout (the cuDNN/PackedSequence idea, rebuilt for this path):
 // clips are sorted by length, descending; at time t the first nact[t] sorted clips are alive;

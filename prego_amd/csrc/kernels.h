@@ -20,6 +20,8 @@ struct GruArgs {
   int row_base;          // rowoff[t0]: chunk-relative row = rowoff[t] - row_base + sorted_index
   int n_clips;
   int G;
+  unsigned* sync;              // [16] placement rendezvous words (8 per-XCD tickets + total), zeroed per launch; nullable
+  unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
 };
 
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -55,6 +56,8 @@ struct prego_miniroad {
   unsigned* flags = nullptr;    // [G*P] + abort word
   unsigned* abort_word = nullptr;
   float* h_state = nullptr;     // [max_clips][H]
+  unsigned long long* stamps = nullptr;   // debug phase counters (PREGO_GRU_STAMPS=1)
+  bool use_stamps = false;
   // plan cache
   std::vector<int32_t> plan_lens;
   std::vector<int> h_rowoff, h_nact, h_sorted;
@@ -110,6 +113,9 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   A((void**)&h->h_state, (size_t)max_clips_of(h) * H * 4);
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
+  A((void**)&h->stamps, 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
+  h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
   if (e == hipSuccess) e = hipMemset(h->hx, 0, (size_t)h->G * 2 * 64 * H * es);
   if (e == hipSuccess) e = hipMemset(h->flags, 0, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   if (e != hipSuccess) { prego_miniroad_destroy(h); return fail(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -121,7 +127,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
 extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
-                  h->flags, h->h_state, h->d_rowoff, h->d_nact, h->d_sorted, h->d_ptrs};
+                  h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_ptrs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   delete h;
@@ -329,7 +335,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
     ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
-    ga.n_clips = n_clips; ga.G = h->G;
+    ga.n_clips = n_clips; ga.G = h->G; ga.stamps = h->use_stamps ? h->stamps : nullptr;
+    ga.sync = (getenv("PREGO_GRU_NO_LOCAL") == nullptr) ? h->flags : nullptr;   // flags[0..15] double as the rendezvous words
     ev = ev_begin(h, 1, s);
     if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
     ev_end(ev, s);
@@ -391,5 +398,15 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
   h->ev_used = 0;
   h->gemm_flop = 0;
   h->pack_bytes = 0;
+  return PREGO_OK;
+}
+
+// debug: per-phase shader-cycle sums of workgroup 0 / wave 0 of the recurrence kernel (PREGO_GRU_STAMPS=1):
+// out[0..4] = poll, mfma, reduce+barrier, gates+publish, outputs; out[5] = poll retry rounds; out[6] = time steps
+extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8) {
+  if (!h || !out8) return fail(PREGO_EINVAL, "NULL");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out8, h->stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long)));
   return PREGO_OK;
 }

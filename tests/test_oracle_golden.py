@@ -172,3 +172,17 @@ def test_g8_aggregate_known_answer():
     want = json.load(open(os.path.join(G, "g8_aggregated_data.json")))
     assert json.load(open(os.path.join(G, "g8_meta.json")))["shipped_equals_rerun"]
     assert O.aggregate(data) == want
+
+
+def test_torch_port_matches_golden():
+    """bench.py's cpu_baseline ("port") computes what the reference computes."""
+    import torch
+    from oracle.oracle_torch import TorchPort
+    g = _ld("g1_miniroad_eval_peaky.npz")
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    port = TorchPort(sd, 1024)
+    rgb = torch.from_numpy(W.tsn_features((1, 256, 2048), 20, "g1.rgb"))
+    out = port.forward(rgb, torch.zeros_like(rgb))[0].numpy()
+    assert np.abs(out - g["probs"]).max() < 1e-6
+    assert np.array_equal(out.argmax(1), g["argmax"])
