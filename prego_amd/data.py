@@ -1,0 +1,113 @@
+"""Feature feeder replacing step_recognition/datasets/dataset.py:24-135.
+
+Same on-disk format ({root}/{annotation_type|rgb_type}/{vid}.npy: float [T, 2048] features, [T, C] one-hot
+targets), same items `(rgb[T,2048] f32, flow[T,2048] f32, target[T,C] f32, vid, start, end)`, same training
+windowing (front zero-pad window_size-1, stride 4, random phase re-drawn by `_init_features()` each epoch,
+dataset.py:53-55,96-123) and whole-video test items (dataset.py:120-123).
+
+Differences on purpose: no `ipdb` breakpoints (dataset.py:108,112), a missing video is skipped without
+mutating the list being iterated (dataset.py:87-94 skips the element after each failure), pads are float32
+(the reference's np.zeros pads are float64 and get re-cast per item), and when flow_type is
+'flow_anet_resnet50' the flow half - which the reference overwrites with zeros (dataset.py:63-69) - is a
+stride-0 zero tensor instead of a materialised [T,2048] array."""
+from __future__ import annotations
+
+import json
+import os.path as osp
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from .config import FEATURE_SIZES
+from .registry import DATA_LAYERS
+
+
+class StepRecognitionDataset(data.Dataset):
+    def __init__(self, cfg, mode="train"):
+        self.root_path = cfg["root_path"]
+        self.mode = mode
+        self.training = mode == "train"
+        self.window_size = cfg["window_size"]
+        self.stride = cfg["stride"]
+        self.num_classes = cfg["num_classes"]
+        self.annotation_type = cfg["annotation_type"]
+        self.rgb_type = cfg["rgb_type"]
+        self.flow_type = cfg["flow_type"]
+        self.zero_flow = cfg["flow_type"] == "flow_anet_resnet50"      # dataset.py:63-69
+        vids = json.load(open(cfg["video_list_path"]))[cfg["data_name"]][mode + "_session_set"]
+        self.vids, self.removed = [], 0
+        self.target_all, self.rgb_inputs, self.flow_inputs = {}, {}, {}
+        pad = self.window_size - 1
+        d_flow = FEATURE_SIZES[self.flow_type]
+        for vid in vids:
+            try:
+                target = np.load(osp.join(self.root_path, self.annotation_type, vid + ".npy")).astype(np.float32)
+                rgb = np.load(osp.join(self.root_path, self.rgb_type, vid + ".npy")).astype(np.float32)
+                if self.zero_flow:
+                    flow = None
+                else:
+                    sub = "assembly_optical_flow_BNInception/" + vid + "/assembling.npy"
+                    flow = np.load(osp.join(self.root_path, self.flow_type, sub)).astype(np.float32)
+            except Exception as e:     # same policy as the reference: drop videos without features
+                print("---- Exception in loading video ", e)
+                self.removed += 1
+                continue
+            if self.training:
+                target = np.concatenate((np.zeros((pad, self.num_classes), np.float32), target), 0)
+                rgb = np.concatenate((np.zeros((pad, rgb.shape[1]), np.float32), rgb), 0)
+                if flow is not None:
+                    flow = np.concatenate((np.zeros((pad, d_flow), np.float32), flow), 0)
+            self.vids.append(vid)
+            self.target_all[vid], self.rgb_inputs[vid], self.flow_inputs[vid] = target, rgb, flow
+        self._zero_row = torch.zeros(1, d_flow)
+        self._init_features()
+
+    def _init_features(self):
+        """re-draw the window phase (main.py:100 calls this after every epoch)"""
+        self.inputs = []
+        for vid in self.vids:
+            n = self.target_all[vid].shape[0]
+            if self.training:
+                seed = np.random.randint(self.stride)
+                for start, end in zip(range(seed, n, self.stride), range(seed + self.window_size, n + 1, self.stride)):
+                    self.inputs.append((vid, start, end))
+            else:
+                self.inputs.append((vid, 0, n))
+
+    def __getitem__(self, index):
+        vid, start, end = self.inputs[index]
+        rgb = torch.from_numpy(self.rgb_inputs[vid][start:end])
+        flow = self.flow_inputs[vid]
+        flow = self._zero_row.expand(end - start, -1) if flow is None else torch.from_numpy(flow[start:end])
+        target = torch.from_numpy(self.target_all[vid][start:end])
+        return rgb, flow, target, vid, start, end
+
+    def __len__(self):
+        return len(self.inputs)
+
+
+for _name in ("ASSEMBLY101-O", "EPIC-TENT-O"):
+    DATA_LAYERS.register(_name, StepRecognitionDataset)
+
+
+def build_data_loader(cfg, mode):
+    """datasets/dataset_builder.py:15-24"""
+    ds = DATA_LAYERS[cfg["data_name"]](cfg, mode)
+    return data.DataLoader(dataset=ds, batch_size=cfg["batch_size"] if mode == "train" else cfg["test_batch_size"],
+                           shuffle=mode == "train", num_workers=cfg["num_workers"], pin_memory=True)
+
+
+# ---- clip sharding for data-parallel inference --------------------------------
+def shard_clips(lengths, world_size: int, rank: int):
+    """Length-balanced partition of the clip list: longest first onto the currently lightest rank (T varies
+    8x on Epic-tent-O).  Deterministic; every rank computes the same partition.  Returns the clip indices
+    of `rank`, in the original order."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world_size
+    owner = [0] * len(lengths)
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += int(lengths[i])
+    return [i for i in range(len(lengths)) if owner[i] == rank]

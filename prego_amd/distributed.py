@@ -1,0 +1,65 @@
+"""One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests).
+
+Inference is embarrassingly data parallel: clips are independent (h0 = 0 per clip, rnn.py:49,60), so the clip
+list is partitioned across ranks (length-balanced, data.shard_clips), weights are replicated, and there is NO
+collective on the data path; rank 0 only gathers the per-clip results at the end.
+Training averages gradients with ONE all-reduce per step over a flat fp32 bucket (see autograd/trainer)."""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .data import shard_clips
+
+
+def init_from_env(backend: str | None = None):
+    """torchrun-style env (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return rank, local_rank, world
+
+
+def sharded_predict(run_clips: Callable[[List[int]], List], lengths: Sequence[int], rank: int, world: int):
+    """Each rank runs `run_clips(my_clip_indices) -> list of per-clip results` (any picklable objects, e.g. the
+    per-frame argmax lists of eval.py:51-56); rank 0 gets the results of ALL clips in the original order,
+    other ranks get None.  No data-path collective: a single gather of the (small) results."""
+    mine = shard_clips(lengths, world, rank)
+    res = run_clips(mine)
+    assert len(res) == len(mine)
+    if world == 1:
+        out = [None] * len(lengths)
+        for i, r in zip(mine, res):
+            out[i] = r
+        return out
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object((mine, res), gathered, dst=0)
+    if rank != 0:
+        return None
+    out = [None] * len(lengths)
+    for idxs, rs in gathered:
+        for i, r in zip(idxs, rs):
+            out[i] = r
+    assert all(o is not None for o in out)
+    return out
+
+
+def allreduce_mean_(flat: torch.Tensor, world: int):
+    """gradient averaging for clip-sharded data-parallel training: loss is a mean over the batch
+    (criterions/loss.py:30-31), so grads are summed over ranks and divided by the world size."""
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+    return flat

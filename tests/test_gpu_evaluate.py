@@ -1,0 +1,67 @@
+"""GPU: the EVAL["OAD"] loop end to end against the fixture produced by the reference's own Evaluate
+(trainer/eval.py) on the same synthetic videos: identical JSON schema, identical gt, pred identical wherever the
+reference's top-1/top-2 margin allows it at bf16 tolerance, mAP within tolerance."""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O                         # noqa: E402  (checker only)
+from prego_amd import weights as W                        # noqa: E402
+from prego_amd.config import epic_tent_cfg                # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+class _Loader:
+    """yields what the reference's test DataLoader yields: batch dim 1, vid as a 1-tuple"""
+    def __init__(self, lens, C, seed, zero_flow_tensor=True):
+        self.items = []
+        for i, T in enumerate(lens):
+            rgb = W.tsn_features((T, 2048), seed, f"g7.rgb.{i}")
+            seg = (np.arange(T) // 37) % C
+            tgt = np.zeros((T, C), np.float32)
+            tgt[np.arange(T), seg] = 1.0
+            self.items.append((torch.from_numpy(rgb)[None], torch.zeros(1, T, 2048), torch.from_numpy(tgt)[None],
+                               (f"synth_video_{i}",), torch.tensor([0]), torch.tensor([T])))
+
+    def __iter__(self):
+        return iter(self.items)
+
+
+@pytest.mark.parametrize("dtype,assume_zero", [("bf16", False), ("bf16", True), ("fp32", False)])
+def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
+    from prego_amd.registry import build_model, build_eval
+    import prego_amd.model, prego_amd.evaluate  # noqa: F401
+    g = json.load(open(os.path.join(G, "g7_evaluate.json")))
+    vl = os.path.join(tmp_path, "video_list.json")
+    json.dump({"EPIC-TENT-O": {"class_index": [f"c{i}" for i in range(12)]}}, open(vl, "w"))
+    cfg = epic_tent_cfg(eval="dummy.pth", video_list_path=vl, compute_dtype=dtype, assume_zero_flow=assume_zero,
+                        eval_output_dir=str(tmp_path / "output_miniRoad"))
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    model = build_model(cfg, "cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    ev = build_eval(cfg)
+    mAP = ev(model, _Loader(g["lens"], 12, 20), logging.getLogger("t"), "cuda:0")
+    js = json.load(open(tmp_path / "output_miniRoad" / "output_miniROAD.json"))
+    assert set(js.keys()) == set(g["output"].keys())
+    tol = 1e-2 if dtype == "bf16" else 1e-3
+    total_mism = 0
+    for i, T in enumerate(g["lens"]):
+        vid = f"synth_video_{i}"
+        assert js[vid]["gt"] == g["output"][vid]["gt"]
+        probs = O.miniroad_forward(sd, W.tsn_features((T, 2048), 20, f"g7.rgb.{i}")[None], None)["logits"][0]
+        srt = np.sort(probs, 1)
+        safe = (srt[:, -1] - srt[:, -2]) > 2 * tol
+        mism = np.array(js[vid]["pred"]) != np.array(g["output"][vid]["pred"])
+        assert not np.any(mism & safe)
+        total_mism += int(mism.sum())
+    assert abs(mAP - g["mAP"]) < 5e-3
+    assert ev.last_fps and ev.last_fps > 0
+    print(f"evaluate {dtype}: mAP {mAP:.5f} (ref {g['mAP']:.5f}), argmax mismatches {total_mism} of {sum(g['lens'])}")

@@ -1,0 +1,126 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, host logic (registries,
+config, deterministic generator, feeder windowing, clip sharding, aggregation known answer)."""
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_abi_library_builds_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    ge.build()
+    from prego_amd import _lib
+    lib = _lib.load()
+    assert lib.prego_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "prego_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(prego_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations found"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/prego_amd.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """no CPU fallback: asking for a CPU device is an error, not a silent torch path"""
+    from prego_amd._lib import PregoError
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.registry import build_model
+    import prego_amd.model  # noqa: F401
+    m = build_model(assembly101_cfg(), "cpu").eval()
+    x = torch.zeros(1, 4, 2048)
+    with pytest.raises(PregoError):
+        m(x, x)
+
+
+def test_state_dict_keys_match_reference_checkpoint_layout():
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.registry import build_model
+    from prego_amd import weights as W
+    import prego_amd.model  # noqa: F401
+    cfg = assembly101_cfg()
+    m = build_model(cfg, "cpu")
+    sd = m.state_dict()
+    ref = W.miniroad_state_dict(cfg, 20)
+    assert set(sd.keys()) == set(ref.keys())          # gru.*, layer1.*, f_classification.* 
+    for k in ref:
+        assert tuple(sd[k].shape) == ref[k].shape and sd[k].dtype == torch.float32
+    assert sum(p.numel() for p in m.parameters()) == 17926230
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()})
+
+
+def test_weight_generator_is_deterministic_and_bounded():
+    from prego_amd import weights as W
+    a = W.uniform((1000,), -0.5, 0.5, 20, "x")
+    b = W.uniform((1000,), -0.5, 0.5, 20, "x")
+    c = W.uniform((1000,), -0.5, 0.5, 21, "x")
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert a.min() >= -0.5 and a.max() < 0.5 and abs(a.mean()) < 0.05
+    f = W.tsn_features((64, 2048), 20, "f")
+    assert f.min() == 0.0 and 0.3 < (f > 0).mean() < 0.7
+
+
+def test_shard_clips_is_a_balanced_partition():
+    from prego_amd.data import shard_clips
+    from prego_amd.workloads import assembly101_eval_lengths
+    lens = assembly101_eval_lengths()
+    assert len(lens) == 182 and min(lens) > 3000 and max(lens) < 35000
+    for world in (1, 2, 4, 8):
+        parts = [shard_clips(lens, world, r) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(lens)))
+        loads = [sum(lens[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(lens)
+
+
+def test_feeder_windows_and_zero_flow(tmp_path):
+    from prego_amd.config import epic_tent_cfg
+    from prego_amd.data import StepRecognitionDataset
+    root = tmp_path / "Epic-tent-O"
+    (root / "target_perframe").mkdir(parents=True)
+    (root / "rgb_anet_resnet50").mkdir()
+    vl = {"EPIC-TENT-O": {"train_session_set": ["a", "missing"], "test_session_set": ["a"], "class_index": list("abcdefghijkl")}}
+    (tmp_path / "vl.json").write_text(json.dumps(vl))
+    T = 300
+    np.save(root / "rgb_anet_resnet50" / "a.npy", np.random.rand(T, 2048).astype(np.float32))
+    tgt = np.zeros((T, 12), np.float32); tgt[np.arange(T), np.arange(T) % 12] = 1
+    np.save(root / "target_perframe" / "a.npy", tgt)
+    cfg = epic_tent_cfg(root_path=str(root), video_list_path=str(tmp_path / "vl.json"))
+    tr = StepRecognitionDataset(cfg, "train")
+    assert tr.removed == 1 and tr.vids == ["a"]
+    n = T + 127
+    assert len(tr) in {len(range(s + 128, n + 1, 4)) for s in range(4)}
+    rgb, flow, target, vid, start, end = tr[0]
+    assert rgb.shape == (128, 2048) and flow.shape == (128, 2048) and target.shape == (128, 12) and end - start == 128
+    assert float(flow.abs().sum()) == 0.0 and flow.stride() == (0, 1)
+    if start == 0:
+        assert float(rgb[:127].abs().sum()) == 0.0       # front padding rows (dataset.py:53-55)
+    te = StepRecognitionDataset(cfg, "test")
+    rgb, flow, target, vid, start, end = te[0]
+    assert rgb.shape == (T, 2048) and (start, end) == (0, T)
+
+
+def test_aggregate_reproduces_reference_known_answer():
+    from prego_amd.aggregate import aggregate
+    with gzip.open(os.path.join(G, "g8_output_miniROAD.json.gz"), "rt") as f:
+        data = json.load(f)
+    want = json.load(open(os.path.join(G, "g8_aggregated_data.json")))
+    assert aggregate(data) == want
+
+
+def test_metrics_ignore_class_zero_and_match_sklearn():
+    from prego_amd.metrics import perframe_average_precision
+    from sklearn.metrics import average_precision_score
+    rng = np.random.default_rng(0)
+    gt = np.zeros((500, 5)); gt[np.arange(500), rng.integers(0, 5, 500)] = 1
+    pr = rng.random((500, 5))
+    res = perframe_average_precision(pr, gt, ["bg", "a", "b", "c", "d"])
+    assert "bg" not in res["per_class_AP"]
+    want = np.mean([average_precision_score(gt[:, i], pr[:, i]) for i in range(1, 5)])
+    assert abs(res["mean_AP"] - want) < 1e-12
