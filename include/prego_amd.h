@@ -102,6 +102,29 @@ int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm
                                double* gru_ms, int64_t* gru_launches, double* pack_ms, int64_t* pack_launches,
                                double* pack_bytes);
 
+/* ---- training: trainer/train.py:6-29 (fwd, loss, backward); criterions/loss.py:15-34 -------------------------- */
+
+/* nn.Dropout(p=cfg['dropout']) after layer1's ReLU (rnn.py:43): applied by forward() calls that carry
+ * PREGO_FWD_KEEP (training mode); the mask is a stateless hash of (seed, element index), regenerated in backward. */
+int prego_miniroad_set_dropout(prego_miniroad* h, float p, uint64_t seed);
+
+/* OadLoss ("NONUNIFORM", loss.py:15-34): loss = mean_b sum_k -(y/||y||_2)_k * log_softmax(logits[b,-1,:])_k with
+ * F.normalize's 1e-12 clamp.  logits[i], target[i]: device fp32 [lens[i], n_classes]; loss_out: device fp32 scalar;
+ * dlogits[i] (array nullable): device fp32 [lens[i], n_classes] := grad_scale * dloss/dlogits (zero except last frame). */
+int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
+                   int n_classes, float* loss_out, float* const* dlogits, float grad_scale, prego_stream_t stream);
+
+/* loss.backward() through MROAD (train.py:23).  Must follow a forward() with PREGO_FWD_KEEP of the same clips whose
+ * workspace is passed back as fwd_workspace (untouched in between).  dlogits[i]: device fp32 [lens[i], n_classes]
+ * (any values: all frames are honoured).  The ten gradient tensors have the shapes of set_weights' arguments and are
+ * OVERWRITTEN.  All column sums are fixed-order (deterministic). */
+size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens);
+int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* dlogits,
+                            float* g_layer1_w, float* g_layer1_b, float* g_ln_w, float* g_ln_b, float* g_w_ih,
+                            float* g_w_hh, float* g_b_ih, float* g_b_hh, float* g_fc_w, float* g_fc_b,
+                            void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
+                            size_t bwd_workspace_bytes, prego_stream_t stream);
+
 /* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
  * recurrence kernel: out8[0..4] = gather, mfma, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
  * [6] = time steps.  Synchronises the device. */

@@ -22,7 +22,8 @@ SYMBOLS = [
     "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
-    "prego_miniroad_debug_stamps",
+    "prego_miniroad_debug_stamps", "prego_miniroad_set_dropout", "prego_oad_loss",
+    "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward",
 ]
 
 
@@ -63,6 +64,12 @@ def load() -> C.CDLL:
                                                C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                                C.POINTER(i64), C.POINTER(C.c_double)]
     lib.prego_miniroad_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.prego_miniroad_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
+    lib.prego_oad_loss.argtypes = [i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), i32, vp, C.POINTER(vp),
+                                   C.c_float, vp]
+    lib.prego_miniroad_backward_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32)]
+    lib.prego_miniroad_backward_workspace_bytes.restype = sz
+    lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):

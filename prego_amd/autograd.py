@@ -1,0 +1,50 @@
+"""torch.autograd glue so that the reference's training loop runs unchanged (trainer/train.py:20-24:
+`out = model(rgb, flow); loss = criterion(out, target); optimizer.zero_grad(); loss.backward(); optimizer.step()`):
+the forward/backward arithmetic is the HIP path, autograd only carries the tensors between the two calls."""
+from __future__ import annotations
+
+import torch
+
+from .engine import _PARAM_ORDER, oad_loss
+
+
+class _MiniRoadTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, rgb, flow, *params):
+        eng = model.engine()
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.layer1[3].p > 0 else 0   # torch RNG drives the mask seed
+        eng.set_dropout(model.layer1[3].p, seed)
+        out = eng.forward_train(rgb, flow)
+        ctx.eng = eng
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.eng.backward(dout)
+        return (None, None, None) + tuple(grads[k] for k in _PARAM_ORDER)
+
+
+def miniroad_train_forward(model, rgb_input, flow_input):
+    if not model.use_rgb:
+        raise NotImplementedError("--no_rgb training")
+    named = dict(model.named_parameters())
+    params = [named[k] for k in _PARAM_ORDER]
+    flow = flow_input if (model.use_flow and not model.assume_zero_flow) else None
+    return _MiniRoadTrainFn.apply(model, rgb_input, flow, *params)
+
+
+class _OadLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        loss, dl = oad_loss(logits, target, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def oad_loss_autograd(logits, target):
+    return _OadLossFn.apply(logits, target)

@@ -51,6 +51,15 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 // tanh(x) = 2 sigmoid(2x) - 1: abs error ~1e-7, saturates cleanly (exp overflow -> rcp(inf) = 0)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// stateless dropout mask: keep iff hash(seed, element index) >= p * 2^32 (same mask in forward and backward)
+__device__ __forceinline__ unsigned mix32_(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x;
+}
+__device__ __forceinline__ bool dropout_keep_(unsigned long long seed, size_t idx, unsigned thresh) {
+  return mix32_(seed * 0x9E3779B97F4A7C15ULL + idx) >= thresh;
+}
+
 // Packed time-major row layout (the cuDNN/PackedSequence idea, rebuilt for this path):
 // clips are sorted by length, descending; at time t the first nact[t] sorted clips are alive;
 // row(t, i) = rowoff[t] + i.  Everything between the pack kernel and the head kernel is

@@ -27,7 +27,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 template <typename OutT, bool RELU_IN /*unused*/>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    OutT* __restrict__ C, int M, int N, int K, int lda, int ldb) {
+    OutT* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
         const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
         if (m < M) {
           float v = acc[i][j][e] + bv;
-          if constexpr (sizeof(OutT) == 2) C[(size_t)m * N + n] = f2bf(v);
-          else C[(size_t)m * N + n] = v;
+          if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = f2bf(v);
+          else C[(size_t)m * ldc + n] = v;
         }
       }
     }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
 template <int DUMMY>
 __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(
     const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ bias,
-    float* __restrict__ C, int M, int N, int K, int lda, int ldb) {
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
   __shared__ __attribute__((aligned(16))) float sa[BM * FLD];
   __shared__ __attribute__((aligned(16))) float sb[BN * FLD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -193,15 +193,15 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
-          if (m < M) C[(size_t)m * N + n] = acc[i][j][e] + bv;
+          if (m < M) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
         }
       }
     }
 }
 
 // bf16: requires N % 128 == 0, K % 64 == 0 (checked by the caller); M arbitrary (>0)
-void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int M, int N,
-                         int K, hipStream_t s) {
+void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
+                         int N, int K, hipStream_t s) {
   if (M <= 0) return;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   static bool attr_set = false;
@@ -210,13 +210,13 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     attr_set = true;
   }
-  gemm_bf16_nt_kernel<float, false><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb);
+  gemm_bf16_nt_kernel<float, false><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
 }
 
 // fp32: K % 16 == 0; M, N arbitrary
-void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int M, int N,
-                        int K, hipStream_t s) {
+void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
+                        int N, int K, hipStream_t s) {
   if (M <= 0) return;
   const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-  gemm_f32_nt_kernel<0><<<ntm * ntn, 256, 0, s>>>(A, B, bias, C, M, N, K, lda, ldb);
+  gemm_f32_nt_kernel<0><<<ntm * ntn, 256, 0, s>>>(A, B, bias, C, M, N, K, lda, ldb, ldc);
 }

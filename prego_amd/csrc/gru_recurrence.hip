@@ -391,6 +391,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             const float z = sigmoidf_(gir[i][1][e] + ghz);
             const float n = tanhf_(gir[i][2][e] + r * (ghn + bhn[i][e]));
             hreg[i][e] = (1.0f - z) * n + z * hreg[i][e];
+            if (a.keep_r) {                                      // training: gate activations for BPTT
+              const size_t ko = (size_t)(rbase + sidx[i]) * HID + ucol[i] + e;
+              a.keep_r[ko] = r; a.keep_z[ko] = z; a.keep_n[ko] = n; a.keep_ghn[ko] = ghn + bhn[i][e];
+            }
           }
         }
       }

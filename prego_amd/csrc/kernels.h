@@ -20,6 +20,7 @@ struct GruArgs {
   int row_base;          // rowoff[t0]: chunk-relative row = rowoff[t] - row_base + sorted_index
   int n_clips;
   int G;
+  float* keep_r; float* keep_z; float* keep_n; float* keep_ghn;   // [rows][H] gate activations for BPTT, nullable
   unsigned* sync;              // [16] placement rendezvous words (8 per-XCD tickets + total), zeroed per launch; nullable
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
 };
@@ -28,14 +29,14 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
                       const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
                       hipStream_t s);
 void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
-                    void* out, float* stats, hipStream_t s);
+                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
                         int cols_dst, hipStream_t s);
-void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int M, int N,
-                         int K, hipStream_t s);
-void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int M, int N,
-                        int K, hipStream_t s);
+void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
+                         int N, int K, hipStream_t s);
+void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
+                        int N, int K, hipStream_t s);
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
                         const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
@@ -43,3 +44,22 @@ int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const floa
 void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
                          hipStream_t s);
 void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s);
+
+// training path (train.hip)
+void launch_oad_loss(const float* const* logit_ptrs, const float* const* target_ptrs, const int* lens, int n_clips, int C,
+                     float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s);
+void launch_gather_dlogits(bool bf16, const float* const* dl_ptrs, const int* rowoff, const int* sorted_clip, int t_max,
+                           int nrows, int C, int Cpad, void* out, hipStream_t s);
+void launch_transpose_convert(bool in_bf16, bool out_bf16, const void* src, int M, int N, int ld_src, void* dst, int Mpad,
+                              hipStream_t s);
+void launch_colsum(const float* src, int M, int N, float* part, float* out, hipStream_t s);
+void launch_colsum_stage2(const float* part, int nb, int N, float* out, hipStream_t s);
+void launch_gru_bwd_step(bool bf16, int t, int na, int na_next, int row_t, int row_tm1, int H, const float* dHout,
+                         const float* carry_in, const float* dhpart, const float* R, const float* Z, const float* Nn,
+                         const float* GHN, const float* Hraw, float* carry_out, float* dGI, float* dGH, void* dGIop,
+                         void* dGHop, hipStream_t s);
+void launch_relu_mask(const float* dHrelu, const float* Hraw, size_t n, float* out, hipStream_t s);
+void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_max, int nrows, int H, void* out,
+                        hipStream_t s);
+int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
+                       int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s);

@@ -58,6 +58,11 @@ struct prego_miniroad {
   float* h_state = nullptr;     // [max_clips][H]
   unsigned long long* stamps = nullptr;   // debug phase counters (PREGO_GRU_STAMPS=1)
   bool use_stamps = false;
+  // training
+  float drop_p = 0.f;
+  unsigned long long drop_seed = 0;
+  int kept_kx = 0;              // K of layer1 actually multiplied by the last PREGO_FWD_KEEP forward
+  int kept_rows = 0;
   // plan cache
   std::vector<int32_t> plan_lens;
   std::vector<int> h_rowoff, h_nact, h_sorted;
@@ -202,7 +207,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, hipStream_t
   return PREGO_OK;
 }
 
-struct RowBytes { size_t x, y, e, gi, hr, hraw, total; };
+struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, total; };
 static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
   const size_t es = h->bf16 ? 2 : 4;
   RowBytes r;
@@ -211,8 +216,11 @@ static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
   r.e = (size_t)h->emb * es;
   r.gi = (size_t)3 * h->hid * 4;
   r.hr = (size_t)h->hid * es;
-  r.hraw = (flags & PREGO_FWD_KEEP) ? (size_t)h->hid * 4 : 0;
-  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw;
+  const bool keep = (flags & PREGO_FWD_KEEP) != 0;
+  r.hraw = keep ? (size_t)h->hid * 4 : 0;
+  r.gates = keep ? (size_t)h->hid * 4 * 4 : 0;      // r, z, n, W_hn h + b_hn
+  r.stats = keep ? 8 : 0;                           // LayerNorm mean, rstd
+  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw + r.gates + r.stats;
   return r;
 }
 
@@ -226,7 +234,7 @@ extern "C" size_t prego_miniroad_workspace_bytes(const prego_miniroad* h, int n_
   if (flags & PREGO_FWD_KEEP) rows = std::max<long long>(rows, total);
   rows = (long long)align_up((size_t)rows, 128);
   const RowBytes rb = row_bytes(h, true, flags);
-  return (size_t)rows * rb.total + 6 * 256;
+  return (size_t)rows * rb.total + 12 * 256;
 }
 
 static EventPair* ev_begin(prego_miniroad* h, int kind, hipStream_t s) {
@@ -282,8 +290,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const int din = h->d_rgb + h->d_flow;
   const RowBytes rb = row_bytes(h, with_flow, flags);
   const int total_rows = h->h_rowoff[h->t_max];
-  if (workspace_bytes < 6 * 256 + 128 * rb.total) return fail(PREGO_EWORKSPACE, "workspace %zu B is too small", workspace_bytes);
-  long long cap_rows = (long long)((workspace_bytes - 6 * 256) / rb.total) / 128 * 128;
+  if (workspace_bytes < 12 * 256 + 128 * rb.total) return fail(PREGO_EWORKSPACE, "workspace %zu B is too small", workspace_bytes);
+  long long cap_rows = (long long)((workspace_bytes - 12 * 256) / rb.total) / 128 * 128;
   if (cap_rows < n_clips) return fail(PREGO_EWORKSPACE, "workspace holds %lld rows, need >= %d (one time step)", cap_rows, n_clips);
   if ((flags & PREGO_FWD_KEEP) && cap_rows < total_rows)
     return fail(PREGO_EWORKSPACE, "PREGO_FWD_KEEP needs the whole batch resident: %d rows, workspace holds %lld", total_rows, cap_rows);
@@ -295,6 +303,15 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   float* GI = (float*)carve((size_t)cap_rows * rb.gi);
   void* HR = carve((size_t)cap_rows * rb.hr);
   float* HRAW = rb.hraw ? (float*)carve((size_t)cap_rows * rb.hraw) : nullptr;
+  float* KR = nullptr; float* KZ = nullptr; float* KN = nullptr; float* KG = nullptr; float* STATS = nullptr;
+  const bool keep = (flags & PREGO_FWD_KEEP) != 0;
+  if (keep) {
+    if (h0) return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) runs from h0 = 0 (rnn.py:49,60): h0 must be NULL");
+    KR = (float*)carve((size_t)cap_rows * h->hid * 4); KZ = (float*)carve((size_t)cap_rows * h->hid * 4);
+    KN = (float*)carve((size_t)cap_rows * h->hid * 4); KG = (float*)carve((size_t)cap_rows * h->hid * 4);
+    STATS = (float*)carve((size_t)cap_rows * 8);
+    h->kept_kx = kx; h->kept_rows = total_rows;
+  }
 
   // initial state (sorted order)
   const int H = h->hid, E = h->emb;
@@ -321,13 +338,13 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     if (h->timing) h->pack_bytes += (double)rows * (kx * 4.0 + rb.x);
 
     ev = ev_begin(h, 0, s);
-    if (h->bf16) launch_gemm_bf16_nt(X, kx, h->w1, din, h->b1, Y, rows, E, kx, s);
-    else launch_gemm_f32_nt((const float*)X, kx, (const float*)h->w1, din, h->b1, Y, rows, E, kx, s);
+    if (h->bf16) launch_gemm_bf16_nt(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx, s);
+    else launch_gemm_f32_nt((const float*)X, kx, (const float*)h->w1, din, h->b1, Y, E, rows, E, kx, s);
     ev_end(ev, s);
-    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, nullptr, s);
+    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s);
     ev = ev_begin(h, 0, s);
-    if (h->bf16) launch_gemm_bf16_nt(Eb, E, h->w_ih, E, h->bias2, GI, rows, 3 * H, E, s);
-    else launch_gemm_f32_nt((const float*)Eb, E, (const float*)h->w_ih, E, h->bias2, GI, rows, 3 * H, E, s);
+    if (h->bf16) launch_gemm_bf16_nt(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E, s);
+    else launch_gemm_f32_nt((const float*)Eb, E, (const float*)h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E, s);
     ev_end(ev, s);
     if (h->timing) h->gemm_flop += 2.0 * rows * ((double)E * kx + 3.0 * H * E);
 
@@ -335,6 +352,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
     ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
+    ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;
     ga.n_clips = n_clips; ga.G = h->G; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = (getenv("PREGO_GRU_NO_LOCAL") == nullptr) ? h->flags : nullptr;   // flags[0..15] double as the rendezvous words
     ev = ev_begin(h, 1, s);
@@ -408,5 +426,192 @@ extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out8, h->stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long)));
+  return PREGO_OK;
+}
+
+// ================================================================================================
+// training: dropout control, loss, backward
+// ================================================================================================
+extern "C" int prego_miniroad_set_dropout(prego_miniroad* h, float p, uint64_t seed) {
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (!(p >= 0.f && p < 1.f)) return fail(PREGO_EINVAL, "dropout p = %f", (double)p);
+  h->drop_p = p;
+  h->drop_seed = seed;
+  return PREGO_OK;
+}
+
+// handle-free: OadLoss is a criterion object of its own in the reference (criterions/loss_builder.py:9-11).
+// Scratch for the pointer tables is one small per-device allocation made on first use.
+#define LOSS_MAX_CLIPS 4096
+extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
+                              int n_classes, float* loss_out, float* const* dlogits, float grad_scale,
+                              prego_stream_t stream) {
+  if (!lens || !logits || !target || !loss_out) return fail(PREGO_EINVAL, "loss: NULL argument");
+  if (n_clips <= 0 || n_clips > LOSS_MAX_CLIPS) return fail(PREGO_EINVAL, "loss: %d clips (max %d)", n_clips, LOSS_MAX_CLIPS);
+  if (n_classes <= 0 || n_classes > 128) return fail(PREGO_EINVAL, "loss: num_classes %d must be in 1..128", n_classes);
+  static void* scratch[64] = {nullptr};
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return fail(PREGO_EINVAL, "device %d", dev);
+  const size_t MC = LOSS_MAX_CLIPS;
+  if (!scratch[dev]) HIPCHK(hipMalloc(&scratch[dev], 4 * MC * sizeof(void*)));
+  void** d = (void**)scratch[dev];
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<const void*> tab(4 * MC, nullptr);
+  for (int i = 0; i < n_clips; ++i) {
+    if (lens[i] <= 0 || !logits[i] || !target[i]) return fail(PREGO_EINVAL, "loss: clip %d", i);
+    tab[0 * MC + i] = logits[i]; tab[1 * MC + i] = target[i]; tab[2 * MC + i] = dlogits ? dlogits[i] : nullptr;
+  }
+  std::memcpy(&tab[3 * MC], lens, (size_t)n_clips * 4);        // 4th table doubles as the lens array
+  HIPCHK(hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  launch_oad_loss((const float* const*)d, (const float* const*)(d + MC), (const int*)(d + 3 * MC), n_clips, n_classes,
+                  loss_out, dlogits ? (float* const*)(d + 2 * MC) : nullptr, grad_scale, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+struct BwdLayout {
+  size_t total;
+  size_t dLp, dLf, dLt, HRt, WcT, dWc, dHR, carry, dhpart, WhhT, dGI, dGH, dGIop, dGHop, part, T1, T2, WihT, dE, dY, Hprev, vec;
+};
+static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
+  const size_t es = h->bf16 ? 2 : 4;
+  const size_t Rp = align_up((size_t)R, 64), H = h->hid, E = h->emb, Din = h->d_rgb + h->d_flow, Cp = 128;
+  const size_t Bp = align_up((size_t)n_clips, 16);
+  BwdLayout L{};
+  size_t off = 0;
+  auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  L.dLp = put((size_t)R * Cp * es); L.dLf = put((size_t)R * Cp * 4); L.dLt = put(Cp * Rp * es);
+  L.HRt = put(H * Rp * es); L.WcT = put(H * Cp * es); L.dWc = put(Cp * H * 4);
+  L.dHR = put((size_t)R * H * 4);
+  L.carry = put(2 * Bp * H * 4); L.dhpart = put(Bp * H * 4);
+  L.WhhT = put(H * 3 * H * es);
+  L.dGI = put((size_t)R * 3 * H * 4); L.dGH = put((size_t)R * 3 * H * 4);
+  L.dGIop = put((size_t)R * 3 * H * es); L.dGHop = put((size_t)R * 3 * H * es);
+  L.part = put(std::max<size_t>(((size_t)R / 64 + 1) * 3 * H, ((size_t)R / 4 + 1) * 2 * E) * 4);
+  L.T1 = put(std::max<size_t>(3 * H, E) * Rp * es);           // transposed "A" operand of a wgrad (dGIt / dGHt / dYt)
+  L.T2 = put(std::max<size_t>(std::max<size_t>(E, H), Din) * Rp * es);   // transposed "B" operand (Et / Hprev_t / Xt)
+  L.WihT = put(E * 3 * H * es);
+  L.dE = put((size_t)R * E * 4); L.dY = put((size_t)R * E * 4);
+  L.Hprev = put((size_t)R * H * es);
+  L.vec = put(4 * E * 4);
+  L.total = off;
+  return L;
+}
+
+extern "C" size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens) {
+  if (!h || n_clips <= 0 || !lens) return 0;
+  long long total = 0;
+  for (int i = 0; i < n_clips; ++i) total += lens[i];
+  return bwd_layout(h, (int)total, n_clips).total;
+}
+
+static void gemm_nt(const prego_miniroad* h, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
+                    int ldc, int M, int N, int K, hipStream_t s) {
+  if (h->bf16) launch_gemm_bf16_nt(A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+  else launch_gemm_f32_nt((const float*)A, lda, (const float*)B, ldb, bias, C, ldc, M, N, K, s);
+}
+
+extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* dlogits,
+                                       float* g_layer1_w, float* g_layer1_b, float* g_ln_w, float* g_ln_b, float* g_w_ih,
+                                       float* g_w_hh, float* g_b_ih, float* g_b_hh, float* g_fc_w, float* g_fc_b,
+                                       void* fwd_workspace, size_t fwd_bytes, void* bwd_workspace, size_t bwd_bytes,
+                                       prego_stream_t stream) {
+  if (!h || !lens || !dlogits || !fwd_workspace || !bwd_workspace) return fail(PREGO_EINVAL, "backward: NULL argument");
+  if (!g_layer1_w || !g_layer1_b || !g_ln_w || !g_ln_b || !g_w_ih || !g_w_hh || !g_b_ih || !g_b_hh || !g_fc_w || !g_fc_b)
+    return fail(PREGO_EINVAL, "backward: NULL gradient tensor");
+  if ((int)h->plan_lens.size() != n_clips || !std::equal(lens, lens + n_clips, h->plan_lens.begin()) || h->kept_rows == 0)
+    return fail(PREGO_EINVAL, "backward must follow a forward(PREGO_FWD_KEEP) of the same clips");
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf = h->bf16;
+  const size_t es = bf ? 2 : 4;
+  const int H = h->hid, E = h->emb, C = h->ncls, Cp = 128, din = h->d_rgb + h->d_flow, kx = h->kept_kx;
+  const int R = h->h_rowoff[h->t_max];
+  const int Rp = (int)align_up((size_t)R, 64);
+  // forward workspace carve (must mirror prego_miniroad_forward with PREGO_FWD_KEEP)
+  const RowBytes rb = row_bytes(h, kx > h->d_rgb, PREGO_FWD_KEEP);
+  const long long cap_rows = (long long)((fwd_bytes - 12 * 256) / rb.total) / 128 * 128;
+  if (cap_rows < R) return fail(PREGO_EWORKSPACE, "forward workspace does not hold the kept activations");
+  char* wp = (char*)fwd_workspace;
+  auto carve = [&](size_t bytes) { char* p = wp; wp += align_up(bytes, 256); return (void*)p; };
+  void* X = carve((size_t)cap_rows * rb.x);
+  float* Y = (float*)carve((size_t)cap_rows * rb.y);
+  void* Eb = carve((size_t)cap_rows * rb.e);
+  (void)carve((size_t)cap_rows * rb.gi);
+  void* HR = carve((size_t)cap_rows * rb.hr);
+  float* HRAW = (float*)carve((size_t)cap_rows * rb.hraw);
+  float* KR = (float*)carve((size_t)cap_rows * H * 4); float* KZ = (float*)carve((size_t)cap_rows * H * 4);
+  float* KN = (float*)carve((size_t)cap_rows * H * 4); float* KG = (float*)carve((size_t)cap_rows * H * 4);
+  float* STATS = (float*)carve((size_t)cap_rows * 8);
+  const BwdLayout L = bwd_layout(h, R, n_clips);
+  if (bwd_bytes < L.total) return fail(PREGO_EWORKSPACE, "backward workspace %zu < %zu", bwd_bytes, L.total);
+  char* bw = (char*)bwd_workspace;
+  float* part = (float*)(bw + L.part);
+
+  // dlogits pointer table
+  const int MC = max_clips_of(h);
+  std::vector<const void*> tab((size_t)MC, nullptr);
+  for (int i = 0; i < n_clips; ++i) { if (!dlogits[i]) return fail(PREGO_EINVAL, "dlogits[%d] is NULL", i); tab[i] = dlogits[i]; }
+  HIPCHK(hipMemcpyAsync(h->d_ptrs, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  const float* const* d_dl = (const float* const*)h->d_ptrs;
+
+  // ---- head: logits = relu(h) Wc^T + bc  (rnn.py:62-64)
+  launch_gather_dlogits(bf, d_dl, h->d_rowoff, h->d_sorted, h->t_max, R, C, Cp, bw + L.dLp, s);
+  launch_gather_dlogits(false, d_dl, h->d_rowoff, h->d_sorted, h->t_max, R, C, Cp, bw + L.dLf, s);
+  launch_colsum((const float*)(bw + L.dLf), R, Cp, part, (float*)(bw + L.vec), s);
+  HIPCHK(hipMemcpyAsync(g_fc_b, bw + L.vec, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+  launch_transpose_convert(bf, bf, bw + L.dLp, R, Cp, Cp, bw + L.dLt, Rp, s);            // [Cp][Rp]
+  launch_transpose_convert(bf, bf, HR, R, H, H, bw + L.HRt, Rp, s);                       // [H][Rp]
+  gemm_nt(h, bw + L.dLt, Rp, bw + L.HRt, Rp, nullptr, (float*)(bw + L.dWc), H, Cp, H, Rp, s);   // dWc[Cp][H]
+  HIPCHK(hipMemcpyAsync(g_fc_w, bw + L.dWc, (size_t)C * H * 4, hipMemcpyDeviceToDevice, s));
+  launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
+  gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
+  launch_relu_mask((const float*)(bw + L.dHR), HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);
+
+  // ---- BPTT through the GRU (rnn.py:61), reverse time
+  launch_transpose_convert(bf, bf, h->w_hh, 3 * H, H, H, bw + L.WhhT, 3 * H, s);          // [H][3H]
+  const size_t Bp = align_up((size_t)n_clips, 16);
+  float* carry[2] = {(float*)(bw + L.carry), (float*)(bw + L.carry) + Bp * H};
+  float* dhpart = (float*)(bw + L.dhpart);
+  for (int t = h->t_max - 1; t >= 0; --t) {
+    const int na = h->h_nact[t];
+    const int na_next = t + 1 < h->t_max ? h->h_nact[t + 1] : 0;
+    const int row_t = h->h_rowoff[t], row_tm1 = t > 0 ? h->h_rowoff[t - 1] : 0;
+    launch_gru_bwd_step(bf, t, na, na_next, row_t, row_tm1, H, (const float*)(bw + L.dHR), carry[(t + 1) & 1], dhpart, KR,
+                        KZ, KN, KG, HRAW, carry[t & 1], (float*)(bw + L.dGI), (float*)(bw + L.dGH), bw + L.dGIop,
+                        bw + L.dGHop, s);
+    if (t > 0)   // dh_{t-1} += dgh_t . W_hh
+      gemm_nt(h, bw + L.dGHop + (size_t)row_t * 3 * H * es, 3 * H, bw + L.WhhT, 3 * H, nullptr, dhpart, H, na, H, 3 * H, s);
+  }
+  // biases of the GRU
+  launch_colsum((const float*)(bw + L.dGI), R, 3 * H, part, g_b_ih, s);
+  launch_colsum((const float*)(bw + L.dGH), R, 3 * H, part, g_b_hh, s);
+  // dW_ih = dGI^T . e
+  launch_transpose_convert(bf, bf, bw + L.dGIop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
+  launch_transpose_convert(bf, bf, Eb, R, E, E, bw + L.T2, Rp, s);
+  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_ih, E, 3 * H, E, Rp, s);
+  // dW_hh = dGH^T . h_{t-1}
+  launch_build_hprev(bf, HRAW, h->d_rowoff, h->t_max, R, H, bw + L.Hprev, s);
+  launch_transpose_convert(bf, bf, bw + L.dGHop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
+  launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
+  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
+  // d e = dGI . W_ih
+  launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
+  gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);
+
+  // ---- Dropout / ReLU / LayerNorm backward (rnn.py:41-43)
+  const int nb = launch_ln_relu_bwd((const float*)(bw + L.dE), Y, STATS, h->ln_g, h->ln_b, R, E, h->drop_p, h->drop_seed, 0,
+                                    (float*)(bw + L.dY), part, s);
+  launch_colsum_stage2(part, nb, 2 * E, (float*)(bw + L.vec), s);
+  HIPCHK(hipMemcpyAsync(g_ln_w, bw + L.vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(g_ln_b, bw + L.vec + (size_t)E * 4, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+
+  // ---- layer1 Linear (rnn.py:40): db = colsum(dY), dW = dY^T . x
+  launch_colsum((const float*)(bw + L.dY), R, E, part, g_layer1_b, s);
+  launch_transpose_convert(false, bf, bw + L.dY, R, E, E, bw + L.T1, Rp, s);
+  launch_transpose_convert(bf, bf, X, R, kx, kx, bw + L.T2, Rp, s);
+  if (kx < din) HIPCHK(hipMemsetAsync(g_layer1_w, 0, (size_t)E * din * 4, s));          // zero-flow columns: zero gradient
+  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_layer1_w, din, E, kx, Rp, s);
+  HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

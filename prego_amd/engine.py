@@ -17,6 +17,51 @@ _PARAM_ORDER = [
 ]
 
 
+# measured recurrence cost per time step (us) by number of live 16-clip tiles per group (scripts/gru_stamps.py)
+_STEP_COST = {0: 0.0, 1: 2.4, 2: 4.4, 3: 6.0, 4: 7.6}
+_LAUNCH_COST_US = 60.0      # per extra pass: plan upload + a few launches
+
+
+def plan_passes(lens, max_clips: int, tile_clips: int = 128):
+    """Partition the clips into forward() passes.  One pass advances all its clips together; the recurrence's
+    per-step cost grows with the number of live 16-clip tiles per group (8 groups x 16 = 128 clips per tile
+    layer), and a tile lives as long as its longest clip.  For ragged eval sets it is therefore cheaper to run
+    the long clips as one 128-clip pass and the short ones afterwards than to drag a second tile through every
+    step of the longest clip.  Exact DP over consecutive ranges of the length-sorted list, cut at multiples of
+    128.  Returns lists of clip indices (sorted by length, descending, inside each pass)."""
+    n = len(lens)
+    order = sorted(range(n), key=lambda i: (-lens[i], i))
+    if n <= tile_clips:
+        return [order]
+    L = [lens[i] for i in order]
+    nb = (n + tile_clips - 1) // tile_clips                       # tile layers
+    maxb = max(1, max_clips // tile_clips)
+
+    def cost(b0, b1):                                             # pass = layers [b0, b1)
+        heads = [L[b * tile_clips] for b in range(b0, b1)]        # lifetime of each layer (longest clip in it)
+        t, prev = 0.0, 0
+        for k in range(len(heads) - 1, -1, -1):                   # layers die shortest first
+            t += (heads[k] - prev) * _STEP_COST[k + 1]
+            prev = heads[k]
+        return t + _LAUNCH_COST_US
+
+    best = [0.0] + [float("inf")] * nb
+    cut = [0] * (nb + 1)
+    for e in range(1, nb + 1):
+        for b in range(max(0, e - maxb), e):
+            if e - b == 3:
+                continue                                          # kernels exist for 1, 2 and 4 tiles per group
+            c = best[b] + cost(b, e)
+            if c < best[e]:
+                best[e], cut[e] = c, b
+    passes, e = [], nb
+    while e > 0:
+        b = cut[e]
+        passes.append(order[b * tile_clips: min(n, e * tile_clips)])
+        e = b
+    return passes[::-1]
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -81,11 +126,17 @@ class MiniRoadEngine:
         outs = [None] * n
         args = [None] * n
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
-        for s in range(0, n, self.max_clips):
-            e = min(n, s + self.max_clips)
-            self._forward_pass(rgb[s:e], None if flow is None else flow[s:e], softmax, want_out, want_argmax,
-                               None if h0 is None else h0[s:e], None if h_last is None else h_last[s:e],
-                               outs, args, s)
+        lens = [int(r.shape[0]) for r in rgb]
+        for idx in plan_passes(lens, self.max_clips):
+            sub_h0 = None if h0 is None else h0[idx].contiguous()
+            sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
+            sub_out, sub_arg = [None] * len(idx), [None] * len(idx)
+            self._forward_pass([rgb[i] for i in idx], None if flow is None else [flow[i] for i in idx], softmax,
+                               want_out, want_argmax, sub_h0, sub_hl, sub_out, sub_arg, 0)
+            for k, i in enumerate(idx):
+                outs[i], args[i] = sub_out[k], sub_arg[k]
+            if h_last is not None:
+                h_last[idx] = sub_hl
         return (outs if want_out else None), (args if want_argmax else None), h_last
 
     def _forward_pass(self, rgb, flow, softmax, want_out, want_argmax, h0, h_last, outs, args, base):
@@ -123,6 +174,56 @@ class MiniRoadEngine:
                 C.c_void_p(h_last.data_ptr()) if h_last is not None else None,
                 flags, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(_stream_ptr(self.device))))
 
+    # -- training ------------------------------------------------------------------------
+    def set_dropout(self, p: float, seed: int):
+        check(self.lib.prego_miniroad_set_dropout(self.h, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def forward_train(self, rgb: torch.Tensor, flow: Optional[torch.Tensor]) -> torch.Tensor:
+        """training-mode forward of a uniform batch [B,T,D]: raw logits [B,T,C]; keeps activations for backward()."""
+        d_rgb, d_flow, emb, hid, ncls = self.dims
+        B, T = rgb.shape[0], rgb.shape[1]
+        if B > self.max_clips:
+            raise PregoError(f"training batch {B} > {self.max_clips} clips per call")
+        rgb = rgb.contiguous()
+        flow = None if flow is None else flow.contiguous()
+        lens_arr = (C.c_int32 * B)(*([T] * B))
+        flags = _lib.FWD_KEEP
+        need = self.lib.prego_miniroad_workspace_bytes(self.h, B, lens_arr, B * T, flags)
+        if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need:
+            self._ws_train = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, T, ncls), dtype=torch.float32, device=self.device)
+        esz = 4
+        rgb_p = ptr_array([rgb.data_ptr() + b * T * d_rgb * esz for b in range(B)])
+        flow_p = None if flow is None else ptr_array([flow.data_ptr() + b * T * d_flow * esz for b in range(B)])
+        out_p = ptr_array([out.data_ptr() + b * T * ncls * esz for b in range(B)])
+        with torch.cuda.device(self.device):
+            check(self.lib.prego_miniroad_forward(self.h, B, lens_arr, rgb_p, flow_p, out_p, None, None, None, flags,
+                                                  C.c_void_p(self._ws_train.data_ptr()), self._ws_train.numel(),
+                                                  C.c_void_p(_stream_ptr(self.device))))
+        self._train_ctx = (B, T, lens_arr, rgb, flow)
+        return out
+
+    def backward(self, dlogits: torch.Tensor) -> dict:
+        """gradients of the ten parameters (reference state_dict names) for the last forward_train()."""
+        d_rgb, d_flow, emb, hid, ncls = self.dims
+        B, T, lens_arr, _, _ = self._train_ctx
+        dlogits = dlogits.to(torch.float32).contiguous()
+        need = self.lib.prego_miniroad_backward_workspace_bytes(self.h, B, lens_arr)
+        if getattr(self, "_ws_bwd", None) is None or self._ws_bwd.numel() < need:
+            self._ws_bwd = torch.empty(need, dtype=torch.uint8, device=self.device)
+        shapes = {"layer1.0.weight": (emb, d_rgb + d_flow), "layer1.0.bias": (emb,), "layer1.1.weight": (emb,),
+                  "layer1.1.bias": (emb,), "gru.weight_ih_l0": (3 * hid, emb), "gru.weight_hh_l0": (3 * hid, hid),
+                  "gru.bias_ih_l0": (3 * hid,), "gru.bias_hh_l0": (3 * hid,), "f_classification.0.weight": (ncls, hid),
+                  "f_classification.0.bias": (ncls,)}
+        grads = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _PARAM_ORDER}
+        dl_p = ptr_array([dlogits.data_ptr() + b * T * ncls * 4 for b in range(B)])
+        with torch.cuda.device(self.device):
+            check(self.lib.prego_miniroad_backward(
+                self.h, B, lens_arr, dl_p, *[C.c_void_p(grads[k].data_ptr()) for k in _PARAM_ORDER],
+                C.c_void_p(self._ws_train.data_ptr()), self._ws_train.numel(),
+                C.c_void_p(self._ws_bwd.data_ptr()), self._ws_bwd.numel(), C.c_void_p(_stream_ptr(self.device))))
+        return grads
+
     def check(self):
         """synchronise and surface a recurrence timeout"""
         with torch.cuda.device(self.device):
@@ -139,3 +240,25 @@ class MiniRoadEngine:
                                                   C.byref(n[1]), C.byref(d[3]), C.byref(n[2]), C.byref(d[4])))
         return dict(gemm_ms=d[0].value, gemm_launches=n[0].value, gemm_flop=d[1].value, gru_ms=d[2].value,
                     gru_launches=n[1].value, pack_ms=d[3].value, pack_launches=n[2].value, pack_bytes=d[4].value)
+
+
+def oad_loss(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
+    """OadLoss on the device (criterions/loss.py:15-34) for uniform [B,T,C] tensors.
+    Returns (loss scalar tensor, dlogits [B,T,C] or None)."""
+    lib = _lib.load()
+    B, T, Cn = logits.shape
+    logits = logits.to(torch.float32).contiguous()
+    target = target.to(torch.float32).contiguous()
+    dev = logits.device
+    if dev.type != "cuda":
+        raise PregoError("oad_loss runs on the GPU only")
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dl = torch.empty_like(logits) if want_grad else None
+    lens_arr = (C.c_int32 * B)(*([T] * B))
+    lp = ptr_array([logits.data_ptr() + b * T * Cn * 4 for b in range(B)])
+    tp = ptr_array([target.data_ptr() + b * T * Cn * 4 for b in range(B)])
+    dp = None if dl is None else ptr_array([dl.data_ptr() + b * T * Cn * 4 for b in range(B)])
+    with torch.cuda.device(dev):
+        check(lib.prego_oad_loss(B, lens_arr, lp, tp, Cn, C.c_void_p(loss.data_ptr()), dp, float(grad_scale),
+                                 C.c_void_p(_stream_ptr(dev))))
+    return loss, dl

@@ -1,0 +1,46 @@
+"""`train_one_epoch` ("OAD") behind the reference's TRAINER registry (trainer/train.py:5-29): same signature and
+return value (sum of per-step losses).  `scheduler` is accepted and never stepped, as in the reference.
+Data-parallel training: when torch.distributed is initialised, gradients are averaged with ONE all-reduce over a flat
+fp32 bucket per step (clip-sharded DP); with a single process this is the reference loop."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .distributed import allreduce_mean_
+from .registry import TRAINER
+
+
+def _allreduce_grads(model):
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return
+    ps = [p for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])        # one bucket: 17.9 M fp32 = 71.7 MB
+    allreduce_mean_(flat, world)
+    o = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[o:o + n].view_as(p))
+        o += n
+
+
+@TRAINER.register("OAD")
+def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, device, writer=None, scheduler=None):
+    if scaler is not None:
+        raise NotImplementedError("--amp: the HIP path already computes with bf16 MFMA operands and fp32 accumulation; "
+                                  "fp16 autocast + GradScaler (train.py:10-18) has nothing to scale")
+    epoch_loss = 0
+    for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(trainloader):
+        rgb_input, flow_input, target = rgb_input.to(device), flow_input.to(device), target.to(device)
+        model.train()
+        out_dict = model(rgb_input, flow_input)
+        loss = criterion(out_dict, target)
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        _allreduce_grads(model)
+        optimizer.step()
+        epoch_loss += loss.item()
+        if writer is not None:
+            writer.add_scalar("Train Loss", loss.item(), it + epoch * len(trainloader))
+    return epoch_loss
