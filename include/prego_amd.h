@@ -125,6 +125,40 @@ int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens,
                             void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
                             size_t bwd_workspace_bytes, prego_stream_t stream);
 
+/* ---- "Transformer" (ViTEnc): step_recognition/model/transformer_models/ViT.py:25-143 ------------------------------ */
+typedef struct prego_vit prego_vit;
+
+/* ViTEnc.__init__ (ViT.py:26-90) with patch_dim = 1: emb = cfg['embedding_dim'], mlp = cfg['hidden_dim'] (ViT.py:75),
+ * heads = cfg['num_heads'], layers = cfg['num_layers'], window = cfg['window_size'] (the learned positional table pins
+ * T == window, PositionalEncoding.py:25-41).  Supported: head dim 64/128/256, emb % 256 == 0, mlp % 128 == 0. */
+int prego_vit_create(prego_vit** out, int d_rgb, int d_flow, int emb, int mlp, int heads, int layers, int window,
+                     int n_classes);
+void prego_vit_destroy(prego_vit* h);
+/* number of tensors set_weights expects: 4 + 11 * layers + 4 */
+int prego_vit_num_tensors(const prego_vit* h);
+/* device fp32 tensors in state_dict order:
+ *   linear_encoding.weight [emb, d_in], linear_encoding.bias, cls_token [emb], position_encoding.pe.weight [window+1, emb],
+ *   per layer l (a = 2l, f = 2l+1): encoder.net.a.fn.norm.{weight,bias}, encoder.net.a.fn.fn.qkv.weight [3emb, emb],
+ *     encoder.net.a.fn.fn.proj.{weight [emb,emb], bias}, encoder.net.f.fn.norm.{weight,bias},
+ *     encoder.net.f.fn.fn.net.0.{weight [mlp,emb], bias}, encoder.net.f.fn.fn.net.3.{weight [emb,mlp], bias},
+ *   pre_head_ln.{weight,bias}, mlp_head.{weight [n_classes, emb], bias} */
+int prego_vit_set_weights(prego_vit* h, const float* const* tensors, int n_tensors, prego_stream_t stream);
+size_t prego_vit_workspace_bytes(const prego_vit* h, int batch);
+/* ViTEnc.forward (ViT.py:117-143): rgb/flow device fp32 [batch, window, d_rgb/d_flow] (flow NULL = zeros);
+ * out_logits device fp32 [batch, n_classes] (the reference returns it as [batch, 1, n_classes], raw logits in both
+ * modes).  flags bit 0: causal self-attention (extension; the reference module has no mask, Attention.py:21-41). */
+int prego_vit_forward(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
+                      void* workspace, size_t workspace_bytes, prego_stream_t stream);
+
+/* AttentionLayer(FullAttention(mask_flag=causal)) of attn.py:139-170,35-57,10-18 as a stateless op (BASELINE config 4:
+ * long-window causal attention).  x, out: device fp32 [batch, len, d_model]; projection weights [d_model, d_model] and
+ * biases [d_model] in nn.Linear layout.  scores = softmax(mask(q k^T) / sqrt(d_model/heads)); never materialised. */
+size_t prego_attention_layer_workspace_bytes(int batch, int len, int d_model);
+int prego_attention_layer_forward(int batch, int len, int d_model, int heads, int causal, const float* x, const float* wq,
+                                  const float* bq, const float* wk, const float* bk, const float* wv, const float* bv,
+                                  const float* wo, const float* bo, float* out, void* workspace, size_t workspace_bytes,
+                                  prego_stream_t stream);
+
 /* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
  * recurrence kernel: out8[0..4] = gather, mfma, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
  * [6] = time steps.  Synchronises the device. */

@@ -24,6 +24,9 @@ SYMBOLS = [
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
     "prego_miniroad_debug_stamps", "prego_miniroad_set_dropout", "prego_oad_loss",
     "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward",
+    "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
+    "prego_vit_workspace_bytes", "prego_vit_forward",
+    "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
 ]
 
 
@@ -70,6 +73,17 @@ def load() -> C.CDLL:
     lib.prego_miniroad_backward_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32)]
     lib.prego_miniroad_backward_workspace_bytes.restype = sz
     lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]
+    lib.prego_vit_create.argtypes = [C.POINTER(vp)] + [i32] * 8
+    lib.prego_vit_destroy.argtypes = [vp]
+    lib.prego_vit_destroy.restype = None
+    lib.prego_vit_num_tensors.argtypes = [vp]
+    lib.prego_vit_set_weights.argtypes = [vp, C.POINTER(vp), i32, vp]
+    lib.prego_vit_workspace_bytes.argtypes = [vp, i32]
+    lib.prego_vit_workspace_bytes.restype = sz
+    lib.prego_vit_forward.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]
+    lib.prego_attention_layer_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.prego_attention_layer_workspace_bytes.restype = sz
+    lib.prego_attention_layer_forward.argtypes = [i32] * 5 + [vp] * 10 + [vp, sz, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):

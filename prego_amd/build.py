@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs, jobs = [], []
     for src in sources():
         sp = os.path.join(CSRC, src)
-        op = os.path.join(LIBDIR, src.rsplit(".", 1)[0] + ".o")
+        op = os.path.join(LIBDIR, src.replace(".", "_") + ".o")
         objs.append(op)
         if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
             cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]

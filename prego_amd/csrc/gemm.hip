@@ -24,10 +24,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename OutT, bool RELU_IN /*unused*/>
+// exact (erf) GELU = nn.GELU() default (Transformer.py:40)
+__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <typename OutT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    OutT* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+    OutT* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -115,8 +118,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
         const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
         if (m < M) {
           float v = acc[i][j][e] + bv;
-          if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = f2bf(v);
-          else C[(size_t)m * ldc + n] = v;
+          if constexpr (EPI == EPI_STORE) {
+            if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = f2bf(v);
+            else C[(size_t)m * ldc + n] = v;
+          } else if constexpr (EPI == EPI_RESIDUAL) {                 // x += v  (fp32 residual stream, in place)
+            float* xr = (float*)C + (size_t)m * ldc + n;
+            *xr = *xr + v;
+          } else if constexpr (EPI == EPI_GELU_BF16) {                // FFN-1: bf16(gelu(v))
+            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gelu_erf_(v));
+          } else if constexpr (EPI == EPI_STORE_BF16) {
+            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
+          } else {                                               // EPI_QKV: split into Q, K [B,h,Ntok,dh] and V^T [B,h,dh,Npad]
+            const int b = m / epi.n_tok, t = m - b * epi.n_tok;
+            const int which = n / epi.emb, r = n - which * epi.emb;
+            const int hd = r / epi.dh, d = r - hd * epi.dh;
+            const size_t bh = (size_t)b * epi.heads + hd;
+            if (which == 0) ((bf16_t*)epi.q)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v * epi.q_scale);
+            else if (which == 1) ((bf16_t*)epi.k)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
+            else ((bf16_t*)epi.vt)[(bh * epi.dh + d) * epi.n_pad + t] = f2bf(v);
+          }
         }
       }
     }
@@ -200,17 +220,33 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(
 }
 
 // bf16: requires N % 128 == 0, K % 64 == 0 (checked by the caller); M arbitrary (>0)
-void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
-                         int N, int K, hipStream_t s) {
+void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
+                             int N, int K, GemmEpi epi, hipStream_t s) {
   if (M <= 0) return;
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr_set = true;
+#define GL(E)                                                                                                   \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    gemm_bf16_nt_kernel<float, E><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi); \
+  } while (0)
+  switch (epi.mode) {
+    case EPI_STORE: GL(EPI_STORE); break;
+    case EPI_RESIDUAL: GL(EPI_RESIDUAL); break;
+    case EPI_GELU_BF16: GL(EPI_GELU_BF16); break;
+    case EPI_STORE_BF16: GL(EPI_STORE_BF16); break;
+    default: GL(EPI_QKV); break;
   }
-  gemm_bf16_nt_kernel<float, false><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+#undef GL
+}
+void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
+                         int N, int K, hipStream_t s) {
+  GemmEpi epi{};
+  epi.mode = EPI_STORE;
+  launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
 }
 
 // fp32: K % 16 == 0; M, N arbitrary

@@ -25,11 +25,23 @@ struct GruArgs {
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
 };
 
+// GEMM epilogues (bf16 kernel): what happens to acc + bias
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU_BF16 = 2, EPI_STORE_BF16 = 3, EPI_QKV = 4 };
+struct GemmEpi {
+  int mode;
+  void* out_b;                 // bf16 output (EPI_GELU_BF16 / EPI_STORE_BF16), leading dim = ldc
+  void* q; void* k; void* vt;  // EPI_QKV destinations
+  int n_tok, n_pad, heads, dh, emb;
+  float q_scale;               // softmax scale folded into Q
+};
+void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
+                             int N, int K, GemmEpi epi, hipStream_t s);
+
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,
                       const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
                       hipStream_t s);
 void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
-                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s);
+                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
                         int cols_dst, hipStream_t s);
@@ -63,3 +75,12 @@ void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_m
                         hipStream_t s);
 int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
                        int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s);
+
+// Transformer path (attention.hip, vit.hip)
+int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
+                           int dh, int causal, hipStream_t s);
+void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s);
+void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
+void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
+                     const float* hb, int C, float* out, hipStream_t s);
+void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);

@@ -53,7 +53,7 @@ template <typename OutT, int MAXV>
 __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
     const float* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
     int nrows, int E, float eps, OutT* __restrict__ out, float* __restrict__ stats /*nullable [nrows][2]*/,
-    float drop_p, unsigned long long seed, int row0_abs) {
+    float drop_p, unsigned long long seed, int row0_abs, int relu) {
   // training-mode Dropout(p) after the ReLU (rnn.py:43): stateless mask = hash(seed, absolute element index),
   // kept values scaled by 1/(1-p); the backward kernel regenerates the same mask
   const unsigned thresh = drop_p > 0.f ? (unsigned)(drop_p * 4294967296.0) : 0u;
@@ -87,10 +87,11 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
         const int c = (i * 64 + lane) * 4;
         const float4 g = *(const float4*)(gamma + c);
         const float4 b = *(const float4*)(beta + c);
-        float o0 = fmaxf((v[i].x - mu) * rstd * g.x + b.x, 0.f);
-        float o1 = fmaxf((v[i].y - mu) * rstd * g.y + b.y, 0.f);
-        float o2 = fmaxf((v[i].z - mu) * rstd * g.z + b.z, 0.f);
-        float o3 = fmaxf((v[i].w - mu) * rstd * g.w + b.w, 0.f);
+        float o0 = (v[i].x - mu) * rstd * g.x + b.x;
+        float o1 = (v[i].y - mu) * rstd * g.y + b.y;
+        float o2 = (v[i].z - mu) * rstd * g.z + b.z;
+        float o3 = (v[i].w - mu) * rstd * g.w + b.w;
+        if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
         if (thresh) {
           const size_t e0 = (size_t)(row0_abs + r) * E + c;
           o0 = dropout_keep_(seed, e0 + 0, thresh) ? o0 * keep_scale : 0.f;
@@ -144,16 +145,16 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
 }
 
 void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
-                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s) {
+                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu) {
   if (nrows <= 0) return;
   int grid = (nrows + 3) / 4;
   if (grid > 16384) grid = 16384;
   if (E <= 2048) {
-    if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs);
-    else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs);
+    if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
   } else {
-    if (bf16) ln_relu_rows_kernel<bf16_t, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs);
-    else ln_relu_rows_kernel<float, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs);
+    if (bf16) ln_relu_rows_kernel<bf16_t, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    else ln_relu_rows_kernel<float, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
   }
 }
 

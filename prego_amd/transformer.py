@@ -1,0 +1,161 @@
+"""`Transformer` (ViTEnc) behind the reference's plug-in API (model/transformer_models/ViT.py:25-143) and the causal
+`AttentionLayer(FullAttention)` op of attn.py as a function.  Same constructor keys (`patch_dim`, `num_heads`,
+`attn_dropout_rate` on top of the yaml), same `forward(rgb, flow) -> {'logits': [B,1,C]}` (raw logits in both modes),
+same state_dict keys/shapes, so reference checkpoints load.  Forward only in this round
+(inference); bf16 MFMA operands, fp32 residual stream / LayerNorm / softmax."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import PregoError, check, ptr_array
+from .config import FEATURE_SIZES
+from .engine import _stream_ptr
+from .registry import META_ARCHITECTURES
+
+
+def _tensor_order(num_layers):
+    names = ["linear_encoding.weight", "linear_encoding.bias", "cls_token", "position_encoding.pe.weight"]
+    for l in range(num_layers):
+        a, f = 2 * l, 2 * l + 1
+        names += [f"encoder.net.{a}.fn.norm.weight", f"encoder.net.{a}.fn.norm.bias", f"encoder.net.{a}.fn.fn.qkv.weight",
+                  f"encoder.net.{a}.fn.fn.proj.weight", f"encoder.net.{a}.fn.fn.proj.bias",
+                  f"encoder.net.{f}.fn.norm.weight", f"encoder.net.{f}.fn.norm.bias",
+                  f"encoder.net.{f}.fn.fn.net.0.weight", f"encoder.net.{f}.fn.fn.net.0.bias",
+                  f"encoder.net.{f}.fn.fn.net.3.weight", f"encoder.net.{f}.fn.fn.net.3.bias"]
+    return names + ["pre_head_ln.weight", "pre_head_ln.bias", "mlp_head.weight", "mlp_head.bias"]
+
+
+class _Norm(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = inner
+
+
+class _Wrap(nn.Module):
+    def __init__(self, inner):
+        super().__init__()
+        self.fn = inner
+
+
+class _Attn(nn.Module):                       # Attention.py:7-19 (parameter container)
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _FF(nn.Module):                         # Transformer.py:35-44 (parameter container; net.0 and net.3 are the Linears)
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden), nn.GELU(), nn.Identity(), nn.Linear(hidden, dim), nn.Identity())
+
+
+class _PE(nn.Module):                         # PositionalEncoding.py:25-34
+    def __init__(self, n, dim):
+        super().__init__()
+        self.pe = nn.Embedding(n, dim)
+        self.register_buffer("position_ids", torch.arange(n).expand((1, -1)))
+
+
+@META_ARCHITECTURES.register("Transformer")
+class ViTEnc(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.img_dim = cfg["window_size"]
+        self.out_dim = cfg["num_classes"]
+        self.embedding_dim = cfg["embedding_dim"]
+        self.patch_dim = cfg["patch_dim"]
+        self.num_heads = cfg["num_heads"]
+        self.num_layers = cfg["num_layers"]
+        self.hidden_dim = cfg["hidden_dim"]
+        if self.patch_dim != 1:
+            raise PregoError("patch_dim != 1 is not supported (the conv-patch branch is dead code in the reference, ViT.py:92-112)")
+        self.use_flow = not cfg["no_flow"]
+        self.use_rgb = not cfg["no_rgb"]
+        self.d_rgb = FEATURE_SIZES[cfg["rgb_type"]] if self.use_rgb else 0
+        self.d_flow = FEATURE_SIZES[cfg["flow_type"]] if self.use_flow else 0
+        self.num_channels = self.d_rgb + self.d_flow
+        self.seq_length = self.img_dim // self.patch_dim + 1
+        E = self.embedding_dim
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, E))                                   # ViT.py:55
+        self.linear_encoding = nn.Linear(self.num_channels, E)                                  # ViT.py:58
+        self.position_encoding = _PE(self.seq_length, E)                                        # ViT.py:60-62
+        layers = []
+        for _ in range(self.num_layers):                                                        # Transformer.py:60-77
+            layers += [_Wrap(_Norm(E, _Attn(E))), _Wrap(_Norm(E, _FF(E, self.hidden_dim)))]
+        self.encoder = nn.Module()
+        self.encoder.net = nn.Sequential(*layers)
+        self.pre_head_ln = nn.LayerNorm(E)                                                      # ViT.py:79
+        self.mlp_head = nn.Linear(E, self.out_dim)                                              # ViT.py:90
+        self.causal = bool(cfg.get("causal_attention", False))     # extension, see DESIGN.md
+        self._h = None
+        self._ver = None
+        self._ws = None
+
+    def _handle(self):
+        dev = self.mlp_head.weight.device
+        if dev.type != "cuda":
+            raise PregoError("prego_amd runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        lib = _lib.load()
+        if self._h is None:
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                check(lib.prego_vit_create(C.byref(h), self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim,
+                                           self.num_heads, self.num_layers, self.img_dim, self.out_dim))
+            self._h = h
+        sd = dict(self.named_parameters())
+        ver = tuple((p.data_ptr(), p._version) for p in sd.values())
+        if ver != self._ver:
+            ts = [sd[k].detach().float().contiguous() for k in _tensor_order(self.num_layers)]
+            with torch.cuda.device(dev):
+                check(lib.prego_vit_set_weights(self._h, ptr_array([t.data_ptr() for t in ts]), len(ts),
+                                                C.c_void_p(_stream_ptr(dev))))
+            self._keep, self._ver = ts, ver
+        return lib, dev
+
+    def forward(self, sequence_input_rgb, sequence_input_flow):
+        lib, dev = self._handle()
+        rgb = sequence_input_rgb.float().contiguous() if self.use_rgb else None
+        flow = sequence_input_flow.float().contiguous() if self.use_flow else None
+        B, T = (rgb if rgb is not None else flow).shape[:2]
+        if T != self.img_dim:
+            raise PregoError(f"ViTEnc needs T == window_size ({self.img_dim}), got {T} (learned positional table, PositionalEncoding.py:25-41)")
+        if rgb is None:
+            raise PregoError("--no_rgb is not supported by the HIP path yet")
+        need = lib.prego_vit_workspace_bytes(self._h, B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, self.out_dim), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.prego_vit_forward(self._h, B, C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
+                                        C.c_void_p(out.data_ptr()), 1 if self.causal else 0, C.c_void_p(self._ws.data_ptr()),
+                                        self._ws.numel(), C.c_void_p(_stream_ptr(dev))))
+        return {"logits": out.unsqueeze(1)}
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                _lib.load().prego_vit_destroy(self._h)
+        except Exception:
+            pass
+
+
+def attention_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True):
+    """AttentionLayer(FullAttention(mask_flag)) forward (attn.py:139-170): x [B,L,D] fp32 cuda -> [B,L,D]."""
+    lib = _lib.load()
+    B, L, D = x.shape
+    dev = x.device
+    ts = [t.detach().float().contiguous() for t in (x, wq, bq, wk, bk, wv, bv, wo, bo)]
+    need = lib.prego_attention_layer_workspace_bytes(B, L, D)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    out = torch.empty((B, L, D), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.prego_attention_layer_forward(B, L, D, n_heads, 1 if mask_flag else 0, *[C.c_void_p(t.data_ptr()) for t in ts],
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(ws.data_ptr()), need,
+                                                C.c_void_p(_stream_ptr(dev))))
+    return out

@@ -1,0 +1,89 @@
+"""GPU parity of the transformer path (a11-a14): ViTEnc forward against the reference's output (G5) and the causal
+AttentionLayer(FullAttention) against the reference's dead-code-but-only causal definition (G6) at L=128 and L=1024
+(BASELINE config 4).  bf16 MFMA operands: tolerance 1e-2 relative to the output scale (logits are O(1))."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O            # noqa: E402
+from prego_amd import weights as W           # noqa: E402
+from prego_amd.config import assembly101_cfg  # noqa: E402
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _vit_cfg(**kw):
+    return assembly101_cfg(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, **kw)
+
+
+def test_g5_vit_forward_matches_reference():
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    g = np.load(os.path.join(G, "g5_vit_forward.npz"))
+    cfg = _vit_cfg()
+    sd = W.vit_state_dict(cfg, 20)
+    m = build_model(cfg, "cuda:0")
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})   # strict: same keys as the reference
+    m.eval()
+    rgb = torch.from_numpy(W.tsn_features((2, 128, 2048), 20, "g5.rgb")).cuda()
+    flow = torch.from_numpy(W.tsn_features((2, 128, 2048), 20, "g5.flow")).cuda()
+    with torch.no_grad():
+        out = m(rgb, flow)["logits"]
+    torch.cuda.synchronize()
+    assert out.shape == (2, 1, 86)
+    got = out.cpu().numpy()
+    err = np.abs(got - g["logits"]).max()
+    print("vit logits max abs err", err, "scale", np.abs(g["logits"]).max())
+    assert err < 1e-2 * max(1.0, np.abs(g["logits"]).max())
+    assert np.array_equal(got.argmax(-1), g["logits"].argmax(-1))
+
+
+def test_vit_state_dict_keys_match_reference():
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    cfg = _vit_cfg()
+    m = build_model(cfg, "cpu")
+    ref = W.vit_state_dict(cfg, 20)
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == ref[k].shape, k
+    assert sum(p.numel() for p in m.parameters()) == 29822038
+
+
+@pytest.mark.parametrize("L", [128, 1024])
+def test_g6_causal_attention_layer(L):
+    from prego_amd.transformer import attention_layer
+    g = np.load(os.path.join(G, f"g6_causal_attention_L{L}.npz"))
+    sd = W.attention_layer_state_dict(2048, 20)
+    x = W.normal((1, L, 2048), 20, f"g6.x.{L}")
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    args = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
+    out = attention_layer(torch.from_numpy(x).cuda(), *args, n_heads=8, mask_flag=True)[0].cpu().numpy()
+    ref = g["out"]
+    err = np.abs(out[g["rows"]] - ref).max()
+    print(f"causal attention L={L}: max abs err {err:.3e}, output scale {np.abs(ref).max():.3f}")
+    assert err < 1e-2 * max(1.0, np.abs(ref).max())
+    # causality property at full size: perturbing the last frame leaves rows 0..L-2 bit-identical
+    x2 = x.copy()
+    x2[0, -1] += 1.0
+    out2 = attention_layer(torch.from_numpy(x2).cuda(), *args, n_heads=8, mask_flag=True)[0].cpu().numpy()
+    assert np.array_equal(out[:-1], out2[:-1])
+    assert not np.array_equal(out[-1], out2[-1])
+
+
+def test_noncausal_attention_vs_oracle_ragged_length():
+    """L = 129 (window + cls token; not a multiple of any tile) without mask, against the numpy oracle"""
+    from prego_amd.transformer import attention_layer
+    sd = W.attention_layer_state_dict(2048, 21)
+    x = W.normal((2, 129, 2048), 21, "nc.x")
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    np_args = [sd[n + s].astype(np.float64) for n in names for s in (".weight", ".bias")]
+    ref = O.causal_attention_layer(x.astype(np.float64), *np_args, heads=8, mask_flag=False)
+    args = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
+    out = attention_layer(torch.from_numpy(x).cuda(), *args, n_heads=8, mask_flag=False).cpu().numpy()
+    assert np.abs(out - ref).max() < 1e-2 * max(1.0, np.abs(ref).max())
