@@ -13,6 +13,7 @@
 // fp32 kernel (parity mode): exact-fp32 MFMA 16x16x4 (bit-for-bit an fmaf chain), register staged.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -142,6 +143,118 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Large-M variant for the two eval-path projections: 256x128x64 tiles, 8 waves (4 x 2, 64x64 each = two waves per
+// SIMD), THREE LDS stages (144 KB, one workgroup per CU) with the prefetch two K tiles ahead: the loop waits with a
+// COUNTED vmcnt (the newest tile stays in flight across the barrier) and uses a raw s_barrier, so the LDS-DMA of tile
+// kt+2 and kt+1 overlap the MFMAs of tile kt (cdna_hip_programming.md "Pipelining across barriers", 3-buffer span).
+// One barrier per K tile: passing barrier(kt) proves every wave finished computing tile kt-1, whose buffer is the one
+// stage(kt+2) overwrites.  Same lane-linear LDS image + source/read XOR swizzle as the 128x128 kernel.
+// ------------------------------------------------------------------------------------------------------
+#define GBM 256
+#define GSTAGE 49152          // A 32 KB + B 16 KB
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][A 32 KB | B 16 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                      // 4 x 2
+  const int ntn = N / BN;
+  const int ntm = (M + GBM - 1) / GBM;
+  const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * GBM, n0 = (tile % ntn) * BN;
+
+  const int sr = lane >> 3, scp = lane & 7;
+  // A: 32 wave-instructions per stage (4 per wave), B: 16 (2 per wave)
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + sr;                 // 0..255
+    const int c = scp ^ ((r >> 1) & 7);
+    int ar = m0 + r; if (ar > M - 1) ar = M - 1;
+    a_src[i] = A + (size_t)ar * lda + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + sr;                 // 0..127
+    const int c = scp ^ ((r >> 1) & 7);
+    b_src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * GSTAGE;
+    char* lb = la + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(la + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(lb + (wave * 2 + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * GSTAGE;
+    const char* lb = la + 32768;
+    // all 16 fragments of the K tile are requested up front (64 VGPRs): the MFMAs of k-step 0 run under the LDS
+    // latency of k-step 1's fragments instead of each group of 8 MFMAs waiting for its own reads
+    bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + fr;
+        af[ks][i] = *(const bf16x8*)(la + ra * 128 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 4));
+        const int rb = wn * 64 + i * 16 + fr;
+        bfr[ks][i] = *(const bf16x8*)(lb + rb * 128 + (((ks * 4 + fq) ^ ((rb >> 1) & 7)) << 4));
+      }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  const int nk = K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed (6 LDS-DMA per wave per tile; leave the newer tile in flight), then meet
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // (staggering waves 4-7 - prefetch after their MFMAs - measured 8 % slower here: 828 vs 905 TFLOP/s)
+    if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
+    compute(kt % 3);
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+        if (m < M) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+      }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // exact fp32 GEMM: 128x128x16 tiles, v_mfma_f32_16x16x4_f32.  Each lane reads 4 consecutive k
 // (one ds_read_b128) and feeds element j to the j-th MFMA; A and B use the same k permutation,
@@ -244,6 +357,17 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 }
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                          int N, int K, hipStream_t s) {
+  static const bool no_big = getenv("PREGO_GEMM_NO_BIG") != nullptr;
+  if (M >= 2048 && !no_big) {            // enough 256-row tiles to fill the chip
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GSTAGE);
+      attr_set = true;
+    }
+    const int ntm = (M + GBM - 1) / GBM, ntn = N / BN;
+    gemm_bf16_nt_big_kernel<<<ntm * ntn, 512, 3 * GSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+    return;
+  }
   GemmEpi epi{};
   epi.mode = EPI_STORE;
   launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);

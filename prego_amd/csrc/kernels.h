@@ -50,6 +50,8 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
 void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
                         int N, int K, hipStream_t s);
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);
+size_t gru_hx_bytes(bool bf16, int hid, int G);
+int gru_max_tiles();
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
                         const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
                         float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s);

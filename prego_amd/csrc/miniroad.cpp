@@ -89,7 +89,7 @@ struct prego_miniroad {
   double gemm_flop = 0, pack_bytes = 0;
 };
 
-static int max_clips_of(const prego_miniroad* h) { return h->G * 64; }
+static int max_clips_of(const prego_miniroad* h) { return h->G * 16 * gru_max_tiles(); }
 
 extern "C" int prego_abi_version(void) { return PREGO_ABI_VERSION; }
 extern "C" const char* prego_last_error(void) { return g_err.c_str(); }
@@ -124,14 +124,14 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A(&h->w_ih, (size_t)3 * H * emb * es); A(&h->w_hh, (size_t)3 * H * H * es);
   A((void**)&h->bias2, 3 * H * 4); A((void**)&h->b_hn, H * 4);
   A(&h->w_c, (size_t)h->ncls_pad * H * es); A((void**)&h->b_c, h->ncls_pad * 4);
-  A(&h->hx, (size_t)h->G * 2 * 64 * H * es);
+  A(&h->hx, gru_hx_bytes(h->bf16, H, h->G));
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   A((void**)&h->h_state, (size_t)max_clips_of(h) * H * 4);
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
-  if (e == hipSuccess) e = hipMemset(h->hx, 0, (size_t)h->G * 2 * 64 * H * es);
+  if (e == hipSuccess) e = hipMemset(h->hx, 0, gru_hx_bytes(h->bf16, H, h->G));
   if (e == hipSuccess) e = hipMemset(h->flags, 0, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   if (e != hipSuccess) { prego_miniroad_destroy(h); return fail(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
   h->abort_word = h->flags + (size_t)h->G * h->P;
@@ -329,7 +329,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   else HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)n_clips * H * 4, s));
 
   const int slots = (n_clips + h->G - 1) / h->G;
-  const int nct = slots <= 16 ? 1 : slots <= 32 ? 2 : 4;
+  const int nct = (slots + 15) / 16;          // live 16-clip tiles per group (kernels: 1, 2, 4, 8)
 
   int t0 = 0;
   while (t0 < h->t_max) {

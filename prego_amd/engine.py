@@ -18,7 +18,7 @@ _PARAM_ORDER = [
 
 
 # measured recurrence cost per time step (us) by number of live 16-clip tiles per group (scripts/gru_stamps.py)
-_STEP_COST = {0: 0.0, 1: 2.4, 2: 4.4, 3: 6.0, 4: 7.6}
+_STEP_COST = {0: 0.0, 1: 2.4, 2: 3.2, 3: 4.4, 4: 5.6, 5: 7.0, 6: 8.4, 7: 9.8, 8: 11.2}
 _LAUNCH_COST_US = 60.0      # per extra pass: plan upload + a few launches
 
 
@@ -49,8 +49,6 @@ def plan_passes(lens, max_clips: int, tile_clips: int = 128):
     cut = [0] * (nb + 1)
     for e in range(1, nb + 1):
         for b in range(max(0, e - maxb), e):
-            if e - b == 3:
-                continue                                          # kernels exist for 1, 2 and 4 tiles per group
             c = best[b] + cost(b, e)
             if c < best[e]:
                 best[e], cut[e] = c, b
