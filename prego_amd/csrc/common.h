@@ -64,13 +64,23 @@ __device__ __forceinline__ bool dropout_keep_(unsigned long long seed, size_t id
 // clips are sorted by length, descending; at time t the first nact[t] sorted clips are alive;
 // row(t, i) = rowoff[t] + i.  Everything between the pack kernel and the head kernel is
 // indexed by packed row, so a chunk of time steps is a contiguous row range.
-struct PackedPlan {
-  const int* rowoff;      // [T_max + 1] prefix sum of nact (absolute, over the whole pass)
-  const int* nact;        // [T_max]
-  const int* sorted_clip; // [n_clips] sorted position -> caller's clip index
-  int t_max;
-  int n_clips;
+// Continuous batching: the units that are alive/sorted are SLOTS, not clips.  A slot runs a list of clips back to
+// back (longest-processing-time packing on the host), so the number of sequential steps is max(longest clip,
+// frames / slots) instead of the longest clip with most slots idle.  Slot i's clips are the segments
+// seg_off[i] .. seg_off[i+1]-1: clip seg_clip[k] occupies steps [seg_start[k], seg_start[k+1]) of that slot.
+// With one clip per slot this degenerates to the plain length-sorted packing.
+#ifndef PREGO_HAVE_SLOTPLAN
+#define PREGO_HAVE_SLOTPLAN 1
+struct SlotPlan {
+  const int* rowoff;      // [s_max + 1] prefix sum of nact
+  const int* nact;        // [s_max]  live slots per step
+  const int* seg_off;     // [n_slots + 1]
+  const int* seg_clip;    // [n_clips] caller's clip index
+  const int* seg_start;   // [n_clips] first step of the segment
+  int s_max;
+  int n_slots;
 };
+#endif
 
 // largest t with rowoff[t] <= row  (row < rowoff[t_max])
 __device__ __forceinline__ int plan_time_of_row(const int* __restrict__ rowoff, int t_max, int row) {
@@ -80,4 +90,15 @@ __device__ __forceinline__ int plan_time_of_row(const int* __restrict__ rowoff, 
     if (rowoff[mid] <= row) lo = mid; else hi = mid;
   }
   return lo;
+}
+
+// packed row -> (caller's clip, frame inside the clip)
+__device__ __forceinline__ void plan_clip_of_row(const SlotPlan& p, int row, int& clip, int& frame) {
+  const int s = plan_time_of_row(p.rowoff, p.s_max, row);
+  const int slot = row - p.rowoff[s];
+  int k = p.seg_off[slot];
+  const int kend = p.seg_off[slot + 1];
+  while (k + 1 < kend && p.seg_start[k + 1] <= s) ++k;      // a handful of segments per slot
+  clip = p.seg_clip[k];
+  frame = s - p.seg_start[k];
 }

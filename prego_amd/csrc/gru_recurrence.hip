@@ -132,6 +132,24 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 #pragma unroll
     for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = (sidx[ct] < a.n_clips) ? a.h_state[(size_t)sidx[ct] * HID + ucol + e] : 0.f;
   }
+  // continuous batching: a slot runs several clips back to back; h restarts from 0 where the next clip begins
+  int nstart[NCT], segp[NCT], sege[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    nstart[ct] = 0x7fffffff; segp[ct] = 0; sege[ct] = 0;
+    if (a.seg_start != nullptr && sidx[ct] < a.n_clips) {
+      int k = a.seg_off[sidx[ct]];
+      sege[ct] = a.seg_off[sidx[ct] + 1];
+      while (k < sege[ct] && a.seg_start[k] < a.t0) ++k;
+      if (k < sege[ct] && a.seg_start[k] == a.t0 && a.t0 > 0) {        // a clip starts on this launch's first step
+#pragma unroll
+        for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = 0.f;
+      }
+      while (k < sege[ct] && a.seg_start[k] <= a.t0) ++k;
+      segp[ct] = k;
+      nstart[ct] = k < sege[ct] ? a.seg_start[k] : 0x7fffffff;
+    }
+  }
 
   // exchange buffers: [2][G][GROUP_BYTES]; one descriptor per group, buffer index in the offset
   const int buf_stride = a.G * GROUP_BYTES;
@@ -148,15 +166,15 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     return (__float_as_uint(x) & 0xBFFFFFFFu) | (tag << 30);
   };
   // publish this lane's slice of tile ct; no waiting
-  auto publish = [&](int ct, int buf, unsigned tag) {
+  auto publish = [&](int ct, int buf, unsigned tag, bool zero) {
     const int off = buf * buf_stride + ((ucol / KF) * GRU_MAX_TILES + ct) * 1024 + ((((ucol % KF) / EPL) << 4) + l15) * 16 +
                     (ucol % EPL) * (int)sizeof(WT);
     if constexpr (BF) {
-      const unsigned v = tag_bf(hreg[ct][0], tag) | (tag_bf(hreg[ct][1], tag) << 16);
+      const unsigned v = tag_bf(zero ? 0.f : hreg[ct][0], tag) | (tag_bf(zero ? 0.f : hreg[ct][1], tag) << 16);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
     } else {
-      const unsigned v = tag_f32(hreg[ct][0], tag);
+      const unsigned v = tag_f32(zero ? 0.f : hreg[ct][0], tag);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
     }
@@ -194,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   float giA[NCT][3][OWN_R], giB[NCT][3][OWN_R];                         // ping-pong: no register copies
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
-    if (tfirst[ct] < na_c) { publish(ct, 1, 1u); load_gi(giA[ct], ct, na_c, rb_c); }
+    if (tfirst[ct] < na_c) { publish(ct, 1, 1u, false); load_gi(giA[ct], ct, na_c, rb_c); }
   int parity = 0;
 
   // one time step; gir = gi of this step (loaded a step ago), gin = where the next step's gi lands
@@ -337,7 +355,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           }
         }
         // ---- (4) publish h_t of this tile for step t+1 (fire and forget)
-        if (more && tfirst[ct] < na_n) publish(ct, tl & 1, (unsigned)((tl >> 1) & 1));
+        const bool restart = (t + 1 == nstart[ct]);          // the slot's next clip begins at step t+1: it sees h = 0
+        if (more && tfirst[ct] < na_n) publish(ct, tl & 1, (unsigned)((tl >> 1) & 1), restart);
         STAMP(3);
         // ---- (5) outputs
         if (sidx[ct] < na) {
@@ -357,6 +376,13 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 #pragma unroll
             for (int e = 0; e < OWN_R; ++e) a.h_raw_out[o + e] = hreg[ct][e];
           }
+        }
+        if (restart) {
+#pragma unroll
+          for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = 0.f;
+          ++segp[ct];
+          nstart[ct] = segp[ct] < sege[ct] ? a.seg_start[segp[ct]] : 0x7fffffff;
+          asm volatile("" : "+v"(nstart[ct]));      // take the (rare) load's wait here, not as a vmcnt(0) in every step
         }
         STAMP(4);
       }

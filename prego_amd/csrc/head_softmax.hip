@@ -14,8 +14,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
     const WT* __restrict__ Hrelu,      // [nrows][HID] chunk-relative packed rows
     const WT* __restrict__ Wc,         // [16*NTC][HID] zero padded rows
     const float* __restrict__ bc,      // [16*NTC] zero padded
-    const int* __restrict__ rowoff, const int* __restrict__ sorted_clip, int t_max,
-    int row0, int nrows, int HID, int C, int apply_softmax,
+    SlotPlan plan, int row0, int nrows, int HID, int C, int apply_softmax,
     float* const* __restrict__ out_ptrs,     // per clip [T][C] fp32 (probs or logits), entries nullable
     int* const* __restrict__ argmax_ptrs) {  // per clip [T] int32, nullable array / entries
   constexpr bool BF = (sizeof(WT) == 2);
@@ -92,8 +91,8 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
     const int r = rbase + l4 * 4 + e;
     if (r < nrows) {
       const int row = row0 + r;
-      const int t = plan_time_of_row(rowoff, t_max, row);
-      const int clip = sorted_clip[row - rowoff[t]];
+      int clip, t;
+      plan_clip_of_row(plan, row, clip, t);
       float* op = out_ptrs ? out_ptrs[clip] : nullptr;
       if (op) {
         op += (size_t)t * C;
@@ -111,15 +110,15 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
   }
 }
 
-int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
-                        const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
+int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
+                        int row0, int nrows, int hid, int C, int apply_softmax,
                         float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s) {
   if (nrows <= 0) return 0;
   const int ntc = (C + 15) / 16;
   const int grid = (nrows + 63) / 64;
 #define HL(WT, N)                                                                                             \
-  head_softmax_kernel<WT, N><<<grid, 256, 0, s>>>((const WT*)Hrelu, (const WT*)Wc, bc, rowoff, sorted_clip,   \
-                                                  t_max, row0, nrows, hid, C, apply_softmax, out_ptrs, argmax_ptrs)
+  head_softmax_kernel<WT, N><<<grid, 256, 0, s>>>((const WT*)Hrelu, (const WT*)Wc, bc, plan, row0, nrows,     \
+                                                  hid, C, apply_softmax, out_ptrs, argmax_ptrs)
 #define HD(N)                          \
   case N:                              \
     if (bf16) HL(bf16_t, N);           \

@@ -4,6 +4,15 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// host-visible copy of the slot schedule descriptor (layout identical to common.h's SlotPlan)
+#ifndef PREGO_HAVE_SLOTPLAN
+struct SlotPlan {
+  const int* rowoff; const int* nact; const int* seg_off; const int* seg_clip; const int* seg_start;
+  int s_max; int n_slots;
+};
+#define PREGO_HAVE_SLOTPLAN 1
+#endif
+
 struct GruArgs {
   const void* whh;       // [3H][H] bf16 or f32, reference layout of gru.weight_hh_l0 (rows r|z|n)
   const float* b_hn;     // [H]  = gru.bias_hh_l0[2H:3H]
@@ -18,8 +27,9 @@ struct GruArgs {
   const int* nact;       // [t_max]
   int t0, t1;            // time steps [t0, t1) handled by this launch
   int row_base;          // rowoff[t0]: chunk-relative row = rowoff[t] - row_base + sorted_index
-  int n_clips;
+  int n_clips;                 // number of SLOTS (one or more clips each)
   int G;
+  const int* seg_off; const int* seg_start;   // slot schedule: where each slot's next clip starts (h := 0 there)
   float* keep_r; float* keep_z; float* keep_n; float* keep_ghn;   // [rows][H] gate activations for BPTT, nullable
   unsigned* sync;              // [16] placement rendezvous words (8 per-XCD tickets + total), zeroed per launch; nullable
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
@@ -37,9 +47,8 @@ struct GemmEpi {
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
 
-void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,
-                      const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
-                      hipStream_t s);
+void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s);
 void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
@@ -52,8 +61,8 @@ void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const 
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);
 size_t gru_hx_bytes(bool bf16, int hid, int G);
 int gru_max_tiles();
-int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const int* rowoff,
-                        const int* sorted_clip, int t_max, int row0, int nrows, int hid, int C, int apply_softmax,
+int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
+                        int row0, int nrows, int hid, int C, int apply_softmax,
                         float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s);
 void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
                          hipStream_t s);

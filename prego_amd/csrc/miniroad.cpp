@@ -75,9 +75,14 @@ struct prego_miniroad {
   int kept_rows = 0;
   // plan cache
   std::vector<int32_t> plan_lens;
-  std::vector<int> h_rowoff, h_nact, h_sorted;
+  std::vector<int> h_rowoff, h_nact, h_sorted;      // h_sorted: first clip of each slot (slot order)
+  std::vector<int> h_seg_off, h_seg_clip, h_seg_start;
+  int n_slots = 0;
+  bool plan_single = true;       // one clip per slot (required for h0 / h_last / training)
+  bool plan_want_single = false;
   int t_max = 0;
   int* d_rowoff = nullptr; int* d_nact = nullptr; int* d_sorted = nullptr;
+  int* d_seg_off = nullptr; int* d_seg_clip = nullptr; int* d_seg_start = nullptr;
   size_t cap_t = 0, cap_c = 0;
   // per-call pointer tables (device)
   void** d_ptrs = nullptr;      // [4][max_clips]
@@ -89,7 +94,9 @@ struct prego_miniroad {
   double gemm_flop = 0, pack_bytes = 0;
 };
 
-static int max_clips_of(const prego_miniroad* h) { return h->G * 16 * gru_max_tiles(); }
+static int max_slots_of(const prego_miniroad* h) { return h->G * 16 * gru_max_tiles(); }
+#define PREGO_MAX_CLIPS 8192     // clips per call (continuous batching packs them into <= max_slots slots)
+static int max_clips_of(const prego_miniroad*) { return PREGO_MAX_CLIPS; }
 
 extern "C" int prego_abi_version(void) { return PREGO_ABI_VERSION; }
 extern "C" const char* prego_last_error(void) { return g_err.c_str(); }
@@ -126,7 +133,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A(&h->w_c, (size_t)h->ncls_pad * H * es); A((void**)&h->b_c, h->ncls_pad * 4);
   A(&h->hx, gru_hx_bytes(h->bf16, H, h->G));
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
-  A((void**)&h->h_state, (size_t)max_clips_of(h) * H * 4);
+  A((void**)&h->h_state, (size_t)max_slots_of(h) * H * 4);
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
@@ -142,7 +149,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
 extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
-                  h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_ptrs};
+                  h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
+                  h->d_seg_start, h->d_ptrs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   delete h;
@@ -175,46 +183,123 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
 }
 
 // ---- plan -------------------------------------------------------------------------------------
-static int build_plan(prego_miniroad* h, int n, const int32_t* lens, hipStream_t s) {
-  if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin())) return PREGO_OK;
-  int tmax = 0;
+// recurrence cost per time step (us) by live 16-clip tiles per group, measured (scripts/gru_stamps.py)
+static const double kStepCost[5] = {0.0, 2.4, 4.4, 6.4, 8.4};
+
+// Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
+// backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
+// minimises the estimated recurrence time: sequential steps = max(longest clip, frames / slots).
+static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single, hipStream_t s) {
+  if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin()) && h->plan_want_single == want_single)
+    return PREGO_OK;
   long long total = 0;
+  int lmax = 0;
   for (int i = 0; i < n; ++i) {
     if (lens[i] <= 0) return fail(PREGO_EINVAL, "clip %d has %d frames", i, lens[i]);
-    tmax = std::max(tmax, lens[i]);
+    lmax = std::max(lmax, lens[i]);
     total += lens[i];
   }
   if (total >= (1ll << 31)) return fail(PREGO_EINVAL, "more than 2^31 frames in one call");
-  h->h_sorted.resize(n);
-  std::iota(h->h_sorted.begin(), h->h_sorted.end(), 0);
-  std::stable_sort(h->h_sorted.begin(), h->h_sorted.end(), [&](int a, int b) { return lens[a] > lens[b]; });
-  h->h_nact.assign(tmax, 0);
-  // nact[t] = #clips with len > t: histogram of lengths, suffix sum
-  std::vector<int> cnt(tmax + 1, 0);
-  for (int i = 0; i < n; ++i) cnt[lens[i]]++;
+  const int per_layer = h->G * 16, max_slots = max_slots_of(h);
+  if (want_single && n > max_slots) return fail(PREGO_EINVAL, "%d clips > %d per call when h0/h_last/training is used", n, max_slots);
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+
+  // candidate slot counts; LPT packing; exact cost = sum over steps of cost(live tiles)
+  struct Cand { int S; std::vector<std::vector<int>> bins; std::vector<long long> load; double cost; };
+  auto pack = [&](int S) {
+    Cand c; c.S = S; c.bins.assign(S, {}); c.load.assign(S, 0);
+    // min-heap on (load, slot)
+    std::vector<std::pair<long long, int>> heap;
+    for (int i = 0; i < S; ++i) heap.push_back({0, i});
+    auto cmp = [](const std::pair<long long, int>& a, const std::pair<long long, int>& b) { return a > b; };
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    for (int idx : order) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      auto top = heap.back(); heap.pop_back();
+      c.bins[top.second].push_back(idx);
+      c.load[top.second] += lens[idx];
+      top.first += lens[idx];
+      heap.push_back(top); std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+    std::vector<long long> sorted_load = c.load;
+    std::sort(sorted_load.begin(), sorted_load.end(), std::greater<long long>());
+    double cost = 0; long long prev = 0;
+    const int layers = (S + per_layer - 1) / per_layer;
+    for (int k = layers - 1; k >= 0; --k) {            // layer k lives as long as its most loaded slot = sorted_load[k*per_layer]
+      const long long life = sorted_load[(size_t)k * per_layer];
+      cost += (double)(life - prev) * kStepCost[std::min(4, k + 1)];
+      prev = life;
+    }
+    c.cost = cost;
+    return c;
+  };
+  Cand best;
+  if (want_single || n <= per_layer) best = pack(n);
+  else {
+    best = pack(std::min(n, per_layer));
+    for (int S = 2 * per_layer; S <= max_slots; S *= 2) {
+      Cand c = pack(std::min(n, S));
+      if (c.cost < best.cost) best = std::move(c);
+      if (S >= n) break;
+    }
+  }
+  const int S = best.S;
+  std::vector<int> slot_order(S);
+  std::iota(slot_order.begin(), slot_order.end(), 0);
+  std::stable_sort(slot_order.begin(), slot_order.end(), [&](int a, int b) { return best.load[a] > best.load[b]; });
+  const int smax = (int)best.load[slot_order[0]];
+  h->h_seg_off.assign(S + 1, 0); h->h_seg_clip.clear(); h->h_seg_start.clear(); h->h_sorted.assign(S, 0);
+  std::vector<int> cnt((size_t)smax + 1, 0);
+  bool single = true;
+  for (int i = 0; i < S; ++i) {
+    const auto& bin = best.bins[slot_order[i]];
+    int start = 0;
+    for (int idx : bin) { h->h_seg_clip.push_back(idx); h->h_seg_start.push_back(start); start += lens[idx]; }
+    h->h_seg_off[i + 1] = (int)h->h_seg_clip.size();
+    h->h_sorted[i] = bin.empty() ? 0 : bin[0];
+    single = single && bin.size() == 1;
+    cnt[start]++;
+  }
+  h->h_nact.assign(smax, 0);
   int alive = 0;
-  for (int t = tmax; t >= 1; --t) { alive += cnt[t]; h->h_nact[t - 1] = alive; }
-  h->h_rowoff.assign(tmax + 1, 0);
-  for (int t = 0; t < tmax; ++t) h->h_rowoff[t + 1] = h->h_rowoff[t] + h->h_nact[t];
-  if ((size_t)tmax + 1 > h->cap_t) {
+  for (int t = smax; t >= 1; --t) { alive += cnt[t]; h->h_nact[t - 1] = alive; }
+  h->h_rowoff.assign((size_t)smax + 1, 0);
+  for (int t = 0; t < smax; ++t) h->h_rowoff[t + 1] = h->h_rowoff[t] + h->h_nact[t];
+  if ((size_t)smax + 1 > h->cap_t) {
     if (h->d_rowoff) (void)hipFree(h->d_rowoff);
     if (h->d_nact) (void)hipFree(h->d_nact);
-    h->cap_t = (size_t)tmax + 1 + 1024;
+    h->cap_t = (size_t)smax + 1 + 1024;
     HIPCHK(hipMalloc((void**)&h->d_rowoff, h->cap_t * 4));
     HIPCHK(hipMalloc((void**)&h->d_nact, h->cap_t * 4));
   }
-  if ((size_t)n > h->cap_c) {
-    if (h->d_sorted) (void)hipFree(h->d_sorted);
+  if ((size_t)n + 1 > h->cap_c) {
+    for (int** p : {&h->d_sorted, &h->d_seg_off, &h->d_seg_clip, &h->d_seg_start}) if (*p) { (void)hipFree(*p); *p = nullptr; }
     h->cap_c = (size_t)n + 64;
-    HIPCHK(hipMalloc((void**)&h->d_sorted, h->cap_c * 4));
+    HIPCHK(hipMalloc((void**)&h->d_sorted, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_off, (h->cap_c + 1) * 4));
+    HIPCHK(hipMalloc((void**)&h->d_seg_clip, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_start, h->cap_c * 4));
   }
   // pageable-source async copies: the runtime stages the host data before returning
-  HIPCHK(hipMemcpyAsync(h->d_rowoff, h->h_rowoff.data(), ((size_t)tmax + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_nact, h->h_nact.data(), (size_t)tmax * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_sorted, h->h_sorted.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-  h->t_max = tmax;
+  HIPCHK(hipMemcpyAsync(h->d_rowoff, h->h_rowoff.data(), ((size_t)smax + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->d_nact, h->h_nact.data(), (size_t)smax * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->d_sorted, h->h_sorted.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->d_seg_off, h->h_seg_off.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->d_seg_clip, h->h_seg_clip.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->d_seg_start, h->h_seg_start.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  h->t_max = smax;
+  h->n_slots = S;
+  h->plan_single = single;
+  h->plan_want_single = want_single;
   h->plan_lens.assign(lens, lens + n);
   return PREGO_OK;
+}
+
+static SlotPlan device_plan(const prego_miniroad* h) {
+  SlotPlan p;
+  p.rowoff = h->d_rowoff; p.nact = h->d_nact; p.seg_off = h->d_seg_off; p.seg_clip = h->d_seg_clip; p.seg_start = h->d_seg_start;
+  p.s_max = h->t_max; p.n_slots = h->n_slots;
+  return p;
 }
 
 struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, total; };
@@ -273,8 +358,11 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "rgb pointer array is NULL");
   if (!workspace) return fail(PREGO_EINVAL, "workspace is NULL");
   hipStream_t s = (hipStream_t)stream;
-  int rc = build_plan(h, n_clips, lens, s);
+  const bool want_single = h0 != nullptr || h_last != nullptr || (flags & PREGO_FWD_KEEP) != 0;
+  int rc = build_plan(h, n_clips, lens, want_single, s);
   if (rc) return rc;
+  const SlotPlan plan = device_plan(h);
+  const int n_slots = h->n_slots;
 
   // pointer tables -> device
   const int MC = max_clips_of(h);
@@ -302,7 +390,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const int total_rows = h->h_rowoff[h->t_max];
   if (workspace_bytes < 12 * 256 + 128 * rb.total) return fail(PREGO_EWORKSPACE, "workspace %zu B is too small", workspace_bytes);
   long long cap_rows = (long long)((workspace_bytes - 12 * 256) / rb.total) / 128 * 128;
-  if (cap_rows < n_clips) return fail(PREGO_EWORKSPACE, "workspace holds %lld rows, need >= %d (one time step)", cap_rows, n_clips);
+  if (cap_rows < n_slots) return fail(PREGO_EWORKSPACE, "workspace holds %lld rows, need >= %d (one time step)", cap_rows, n_slots);
   if ((flags & PREGO_FWD_KEEP) && cap_rows < total_rows)
     return fail(PREGO_EWORKSPACE, "PREGO_FWD_KEEP needs the whole batch resident: %d rows, workspace holds %lld", total_rows, cap_rows);
   char* wp = (char*)workspace;
@@ -325,10 +413,10 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
 
   // initial state (sorted order)
   const int H = h->hid, E = h->emb;
-  if (h0) launch_permute_rows(h0, h->h_state, h->d_sorted, n_clips, H, 1, s);
-  else HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)n_clips * H * 4, s));
+  if (h0) launch_permute_rows(h0, h->h_state, h->d_sorted, n_slots, H, 1, s);        // one clip per slot here
+  else HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)n_slots * H * 4, s));
 
-  const int slots = (n_clips + h->G - 1) / h->G;
+  const int slots = (n_slots + h->G - 1) / h->G;
   const int nct = (slots + 15) / 16;          // live 16-clip tiles per group (kernels: 1, 2, 4, 8)
 
   int t0 = 0;
@@ -342,8 +430,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     const int rows = h->h_rowoff[t1] - base;
 
     EventPair* ev = ev_begin(h, 2, s);
-    launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, h->d_rowoff, h->d_sorted, h->t_max, base, rows, h->d_rgb,
-                     with_flow ? h->d_flow : 0, X, s);
+    launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base, rows, h->d_rgb, with_flow ? h->d_flow : 0, X, s);
     ev_end(ev, s);
     if (h->timing) h->pack_bytes += (double)rows * (kx * 4.0 + rb.x);
 
@@ -363,20 +450,21 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
     ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
     ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;
-    ga.n_clips = n_clips; ga.G = h->G; ga.stamps = h->use_stamps ? h->stamps : nullptr;
+    ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
+    ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = (getenv("PREGO_GRU_NO_LOCAL") == nullptr) ? h->flags : nullptr;   // flags[0..15] double as the rendezvous words
     ev = ev_begin(h, 1, s);
     if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
     ev_end(ev, s);
 
     if (out || argmax) {
-      if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, h->d_rowoff, h->d_sorted, h->t_max, base, rows, H, h->ncls,
+      if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, plan, base, rows, H, h->ncls,
                               (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s))
         return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
     }
     t0 = t1;
   }
-  if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_clips, H, 0, s);
+  if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

@@ -11,14 +11,13 @@
 // OutT = bf16_t (MFMA operand) or float (fp32 parity mode).
 template <typename OutT>
 __global__ __launch_bounds__(256) void pack_rows_kernel(
-    const float* const* __restrict__ rgb_ptrs, const float* const* __restrict__ flow_ptrs,
-    const int* __restrict__ rowoff, const int* __restrict__ sorted_clip, int t_max,
+    const float* const* __restrict__ rgb_ptrs, const float* const* __restrict__ flow_ptrs, SlotPlan plan,
     int row0, int nrows, int d_rgb, int d_flow, OutT* __restrict__ X) {
   const int din = d_rgb + d_flow;
   for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
     const int row = row0 + r;
-    const int t = plan_time_of_row(rowoff, t_max, row);
-    const int clip = sorted_clip[row - rowoff[t]];
+    int clip, t;
+    plan_clip_of_row(plan, row, clip, t);
     const float* rgb = rgb_ptrs ? rgb_ptrs[clip] : nullptr;
     const float* flow = flow_ptrs ? flow_ptrs[clip] : nullptr;   // nullptr = all-zero flow half
     OutT* dst = X + (size_t)r * din;
@@ -131,17 +130,14 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
 // ------------------------------------------------------------------------------------------
 // host launchers (called from miniroad.cpp)
 // ------------------------------------------------------------------------------------------
-void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const int* rowoff,
-                      const int* sorted_clip, int t_max, int row0, int nrows, int d_rgb, int d_flow, void* X,
-                      hipStream_t s) {
+void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s) {
   if (nrows <= 0) return;
   int grid = nrows < 65536 ? nrows : 65536;
   if (bf16)
-    pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, rowoff, sorted_clip, t_max, row0, nrows, d_rgb,
-                                                  d_flow, (bf16_t*)X);
+    pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X);
   else
-    pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, rowoff, sorted_clip, t_max, row0, nrows, d_rgb,
-                                                 d_flow, (float*)X);
+    pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X);
 }
 
 void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,

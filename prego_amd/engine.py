@@ -17,47 +17,16 @@ _PARAM_ORDER = [
 ]
 
 
-# measured recurrence cost per time step (us) by number of live 16-clip tiles per group (scripts/gru_stamps.py)
-_STEP_COST = {0: 0.0, 1: 2.4, 2: 3.2, 3: 4.4, 4: 5.6, 5: 7.0, 6: 8.4, 7: 9.8, 8: 11.2}
-_LAUNCH_COST_US = 60.0      # per extra pass: plan upload + a few launches
-
-
-def plan_passes(lens, max_clips: int, tile_clips: int = 128):
-    """Partition the clips into forward() passes.  One pass advances all its clips together; the recurrence's
-    per-step cost grows with the number of live 16-clip tiles per group (8 groups x 16 = 128 clips per tile
-    layer), and a tile lives as long as its longest clip.  For ragged eval sets it is therefore cheaper to run
-    the long clips as one 128-clip pass and the short ones afterwards than to drag a second tile through every
-    step of the longest clip.  Exact DP over consecutive ranges of the length-sorted list, cut at multiples of
-    128.  Returns lists of clip indices (sorted by length, descending, inside each pass)."""
+def plan_passes(lens, max_clips: int, single: bool = False, max_slots: int = 512):
+    """Split a clip list into forward() calls.  The C ABI packs up to `max_clips` clips per call into its recurrence
+    slots itself (continuous batching: longest-first bin packing, see csrc/miniroad.cpp::build_plan); only calls that
+    need one clip per slot (h0 / h_last) are limited to `max_slots` clips.  Returns lists of clip indices."""
     n = len(lens)
+    cap = max_slots if single else max_clips
+    if n <= cap:
+        return [list(range(n))]
     order = sorted(range(n), key=lambda i: (-lens[i], i))
-    if n <= tile_clips:
-        return [order]
-    L = [lens[i] for i in order]
-    nb = (n + tile_clips - 1) // tile_clips                       # tile layers
-    maxb = max(1, max_clips // tile_clips)
-
-    def cost(b0, b1):                                             # pass = layers [b0, b1)
-        heads = [L[b * tile_clips] for b in range(b0, b1)]        # lifetime of each layer (longest clip in it)
-        t, prev = 0.0, 0
-        for k in range(len(heads) - 1, -1, -1):                   # layers die shortest first
-            t += (heads[k] - prev) * _STEP_COST[k + 1]
-            prev = heads[k]
-        return t + _LAUNCH_COST_US
-
-    best = [0.0] + [float("inf")] * nb
-    cut = [0] * (nb + 1)
-    for e in range(1, nb + 1):
-        for b in range(max(0, e - maxb), e):
-            c = best[b] + cost(b, e)
-            if c < best[e]:
-                best[e], cut[e] = c, b
-    passes, e = [], nb
-    while e > 0:
-        b = cut[e]
-        passes.append(order[b * tile_clips: min(n, e * tile_clips)])
-        e = b
-    return passes[::-1]
+    return [order[s:s + cap] for s in range(0, n, cap)]
 
 
 def _stream_ptr(device) -> int:
@@ -125,7 +94,8 @@ class MiniRoadEngine:
         args = [None] * n
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
         lens = [int(r.shape[0]) for r in rgb]
-        for idx in plan_passes(lens, self.max_clips):
+        single = h0 is not None or want_h_last
+        for idx in plan_passes(lens, self.max_clips, single, 512 if self.compute_dtype == "bf16" else 256):
             sub_h0 = None if h0 is None else h0[idx].contiguous()
             sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
             sub_out, sub_arg = [None] * len(idx), [None] * len(idx)

@@ -190,3 +190,31 @@ def test_chunking_and_streaming_are_bit_exact(dtype):
     for i in range(len(lens)):
         assert torch.equal(torch.cat([o1[i], o2[i]]), a[i])
     assert torch.equal(h2, ha)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_continuous_batching_matches_per_clip_results(dtype):
+    """more clips than recurrence slots: several clips share a slot back to back (h restarts at 0 at every clip
+    boundary, chunk boundaries fall anywhere).  Every clip must come out exactly as when it is run alone."""
+    cfg = epic_tent_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    m = _model(cfg, sd, dtype)
+    eng = m.engine()
+    n = 300 if dtype == "bf16" else 150                      # > 128 (bf16) / 64 (fp32) slots of one tile layer
+    lens = [3 + (i * 7) % 40 for i in range(n)]
+    lens[5] = 200                                            # one long clip sets the number of sequential steps
+    rgb = [torch.from_numpy(W.tsn_features((T, 2048), 13, f"cb.{i}")).cuda() for i, T in enumerate(lens)]
+    eng.rows_per_chunk = 1000                                # several chunks: restarts also land on launch boundaries
+    eng._ws = None
+    outs, args, _ = eng.forward_ragged(rgb, None, want_argmax=True)
+    eng.check()
+    for i in (0, 5, 17, 128, 129, n - 1):
+        alone, _, _ = eng.forward_ragged([rgb[i]], None)
+        assert torch.equal(outs[i], alone[0]), i
+    ref = O.miniroad_forward(sd, rgb[n - 1].cpu().numpy()[None], None)["logits"][0]
+    assert np.abs(outs[n - 1].cpu().numpy() - ref).max() < TOL[dtype]
+    for i in range(n):
+        assert outs[i].shape == (lens[i], 12) and bool(torch.isfinite(outs[i]).all())
+        assert np.array_equal(args[i].cpu().numpy(), outs[i].cpu().numpy().argmax(1))
+    eng.rows_per_chunk = 65536
+    eng._ws = None
