@@ -53,9 +53,11 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also exercised with one rank)
         import torch.distributed as dist_
         dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
 
     from prego_amd import weights as W
@@ -143,7 +145,7 @@ def main():
             except Exception:
                 traffic = {}
         step_ms = dt / args.steps * 1e3
-        gemm_name = ("gemm_bf16_nt_big_kernel" if args.dtype == "bf16" else "gemm_f32_nt_kernel") + " (layer1 + W_ih projections)"
+        gemm_name = ("gemm_bf16_nt_256sq_kernel" if args.dtype == "bf16" else "gemm_f32_nt_kernel") + " (layer1 + W_ih projections)"
         rl_gemm = {"bound": "mfma", "kernel": gemm_name, "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",
                    "frac": gemm_tflops / peak, "traffic": traffic.get("gemm_bytes_per_launch"),
                    "avg_launch_ms": kt["gemm_ms"] / n_l, "launches": kt["gemm_launches"], "ms_per_step": kt["gemm_ms"] / args.steps}

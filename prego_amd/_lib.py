@@ -26,7 +26,7 @@ SYMBOLS = [
     "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
-    "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
+    "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward", "prego_debug_gemm_bf16",
 ]
 
 
@@ -84,6 +84,7 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_workspace_bytes.argtypes = [i32, i32, i32]
     lib.prego_attention_layer_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward.argtypes = [i32] * 5 + [vp] * 10 + [vp, sz, vp]
+    lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):

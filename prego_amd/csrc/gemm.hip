@@ -332,6 +332,8 @@ __global__ __launch_bounds__(256) void gemm_f32_nt_kernel(
     }
 }
 
+void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
+                                   int ldc, int M, int N, int K, hipStream_t s);
 // bf16: requires N % 128 == 0, K % 64 == 0 (checked by the caller); M arbitrary (>0)
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s) {
@@ -358,6 +360,10 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                          int N, int K, hipStream_t s) {
   static const bool no_big = getenv("PREGO_GEMM_NO_BIG") != nullptr;
+  if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles, two 64 KB stages (gemm_exp.hip, variant 2): 1.15 PFLOP/s
+    launch_gemm_bf16_experimental(2, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+    return;
+  }
   if (M >= 2048 && !no_big) {            // enough 256-row tiles to fill the chip
     static bool attr_set = false;
     if (!attr_set) {
@@ -371,6 +377,20 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
   GemmEpi epi{};
   epi.mode = EPI_STORE;
   launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+}
+
+void launch_gemm_bf16_variant(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
+                              int M, int N, int K, hipStream_t s) {
+  if (variant == 0) {
+    GemmEpi epi{}; epi.mode = EPI_STORE;
+    launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
+  } else if (variant == 1) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GSTAGE);
+    const int ntm = (M + GBM - 1) / GBM, ntn = N / BN;
+    gemm_bf16_nt_big_kernel<<<ntm * ntn, 512, 3 * GSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else {
+    launch_gemm_bf16_experimental(variant, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+  }
 }
 
 // fp32: K % 16 == 0; M, N arbitrary

@@ -1,0 +1,128 @@
+// Experimental bf16 GEMM variants (selected by scripts/gemm_bench.py through prego_debug_gemm_bf16); the ones that
+// win move into gemm.hip.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// variant 2: 256x256x64 tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64 = 8x4 MFMA tiles (128 accumulator registers),
+// two LDS stages of 64 KB (A 32 KB + B 32 KB), one barrier per K tile.  Per K tile a wave issues 8 LDS-DMA, 24
+// ds_read_b128 and 64 MFMAs (0.375 reads per MFMA, half the LDS and L2 bytes per FLOP of the 256x128 kernel).
+#define XBM 256
+#define XBN 256
+#define XBK 64
+#define XSTAGE 65536
+template <int NSPLIT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KB | B 32 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;                      // 2 x 4
+  const int ntn = N / XBN;
+  const int ntm = (M + XBM - 1) / XBM;
+  const int tile = xcd_remap2(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * XBM, n0 = (tile % ntn) * XBN;
+  const int sr = lane >> 3, scp = lane & 7;
+  const bf16_t* a_src[4];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + sr;                 // 0..255
+    const int c = scp ^ ((r >> 1) & 7);
+    int ar = m0 + r; if (ar > M - 1) ar = M - 1;
+    a_src[i] = A + (size_t)ar * lda + c * 8;
+    b_src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * XSTAGE;
+    char* lb = la + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * XBK),
+                                       (__attribute__((address_space(3))) void*)(la + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * XBK),
+                                       (__attribute__((address_space(3))) void*)(lb + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  auto stage_piece = [&](int buf, int kt, int i) {
+    char* la = smem + buf * XSTAGE;
+    char* lb = la + 32768;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (size_t)kt * XBK),
+                                     (__attribute__((address_space(3))) void*)(la + (wave * 4 + i) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (size_t)kt * XBK),
+                                     (__attribute__((address_space(3))) void*)(lb + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  auto compute = [&](int buf, int nbuf, int nkt, bool pre) {
+    const char* la = smem + buf * XSTAGE;
+    const char* lb = la + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rb = wn * 64 + j * 16 + fr;
+        bfr[j] = *(const bf16x8*)(lb + rb * 128 + (((ks * 4 + fq) ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ra = wm * 128 + h * 64 + i * 16 + fr;
+          af[i] = *(const bf16x8*)(la + ra * 128 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 4));
+        }
+        if constexpr (NSPLIT == 1) { if (pre) stage_piece(nbuf, nkt, ks * 2 + h); }   // 2 of the next tile's 8 DMA pieces per phase
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  };
+  const int nk = K / XBK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (nothing newer is in flight yet)
+    __builtin_amdgcn_s_barrier();
+    if constexpr (NSPLIT == 0) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
+    compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 128 + i * 16 + fq * 4 + e;
+        if (m < M) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+      }
+    }
+}
+
+void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
+                                   int ldc, int M, int N, int K, hipStream_t s) {
+  const int ntm = (M + XBM - 1) / XBM, ntn = N / XBN;
+  if (variant == 2 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<0><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 3 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<1><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  }
+}

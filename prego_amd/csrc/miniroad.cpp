@@ -713,3 +713,15 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
+
+// debug / microbenchmark: C[M,N] (fp32) = A[M,K] . B[N,K]^T + bias with a chosen bf16 kernel variant
+// (0 = 128x128 two-stage, 1 = 256x128 three-stage counted-vmcnt, 2.. = experimental), scripts/gemm_bench.py
+void launch_gemm_bf16_variant(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
+                              int M, int N, int K, hipStream_t s);
+extern "C" int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,
+                                     prego_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N % 128 || K % 64) return fail(PREGO_EINVAL, "debug gemm: bad arguments");
+  launch_gemm_bf16_variant(variant, A, K, B, K, bias, C, N, M, N, K, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
