@@ -233,32 +233,35 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
       if (tfirst[ct] < na) {                                            // else: this and all later clip tiles are finished
         // ---- (1) gather h_{t-1} of tile ct (data-is-the-flag): load every fragment, re-load the ones that still show
         // the old tag until all are valid; then multiply in a FIXED order (bit-reproducible fp32 sums).
-        u32x4 hb[NKS];          // tile-local on purpose: loop-carried load registers make hipcc wait vmcnt(0) at every use
-        unsigned pending = (1u << NKS) - 1u;
+        // Every round (re)loads ALL fragments and validates them with one AND- or OR-reduction over the tag bits: no
+        // per-fragment bookkeeping.  (Tracking stale fragments individually made hipcc carry the fragment registers
+        // through the spin loop in AGPRs - 165 v_accvgpr moves and ~100 scalar branches per step - for a retry that
+        // happens 0.3 times per step and costs one L2-served 8 KB re-read.)
+        u32x4 hb[NKS];
         unsigned spins = 0;
-        auto issue = [&](int tile, int buf, unsigned mask, unsigned spins_) {
-#pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-            if ((mask >> ks) & 1u) {
-              const int off = buf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + tile) * 1024 + lane * 16;
-              hb[ks] = (local && spins_ < 6u) ? __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX_NT)
-                                              : __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX_SC1);
-            }
-        };
-        issue(ct, rbuf, pending, 0u);
         for (;;) {
-          unsigned bad = 0;
+          if (local && spins < 6u) {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-            if ((pending >> ks) & 1u) bad |= (hb[ks][0] ^ eword) | (hb[ks][1] ^ eword) | (hb[ks][2] ^ eword) | (hb[ks][3] ^ eword);
-          if (__all((bad & TAGM) == 0u)) break;
+            for (int ks = 0; ks < NKS; ++ks)
+              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+          } else {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-            if ((pending >> ks) & 1u) {
-              const unsigned b = ((hb[ks][0] ^ eword) | (hb[ks][1] ^ eword) | (hb[ks][2] ^ eword) | (hb[ks][3] ^ eword)) & TAGM;
-              if (__all(b == 0u)) pending &= ~(1u << ks);
-            }
-          if (pending == 0u) break;
+            for (int ks = 0; ks < NKS; ++ks)
+              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+          }
+          unsigned bad;
+          if (etag) {                                   // every element must have the tag bit SET
+            unsigned all1 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) all1 &= hb[ks][0] & hb[ks][1] & hb[ks][2] & hb[ks][3];
+            bad = ~all1 & TAGM;
+          } else {                                      // every element must have it CLEAR
+            unsigned any1 = 0u;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) any1 |= hb[ks][0] | hb[ks][1] | hb[ks][2] | hb[ks][3];
+            bad = any1 & TAGM;
+          }
+          if (__all(bad == 0u)) break;
           if (++spins > SPIN_LIMIT) {
             if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
@@ -266,7 +269,6 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           if ((spins & 255u) == 0u) {
             if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
           }
-          issue(ct, rbuf, pending, spins);
         }
         if (stamp) st_acc[5] += spins;
         STAMP(0);
