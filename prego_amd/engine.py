@@ -90,6 +90,8 @@ class MiniRoadEngine:
         Returns (outs list of [T_i, C] or None, argmax list of int32 [T_i] or None, h_last or None)."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
         n = len(rgb)
+        if n == 0:                      # empty clip list: nothing to do (the reference's loader simply yields nothing)
+            return ([] if want_out else None), ([] if want_argmax else None), (torch.empty((0, hid), device=self.device) if want_h_last else None)
         outs = [None] * n
         args = [None] * n
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None

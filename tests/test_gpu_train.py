@@ -140,3 +140,39 @@ def test_dropout_mask_is_consistent_between_forward_and_backward():
     eng.set_dropout(0.0, 0)
     out0 = eng.forward_train(rgb, torch.zeros_like(rgb))
     assert float((out0 - out).abs().max()) > 1e-4
+
+
+def test_train_one_epoch_registry_loop_reduces_loss():
+    """TRAINER["OAD"] end to end (train.py:5-29 contract): two epochs over a tiny synthetic loader with the reference's
+    optimizer construction (main.py:62-67) lower the loss; return value = sum of per-step losses."""
+    from prego_amd.registry import build_trainer
+    import prego_amd.trainer  # noqa: F401
+    cfg = assembly101_cfg(dropout=0.2, compute_dtype="bf16", assume_zero_flow=True)
+    sd = W.miniroad_state_dict(cfg, 20)
+    model, crit = _build(cfg, sd)
+    train_one_epoch = build_trainer(cfg)
+    B, T = 4, 16
+    batches = []
+    for i in range(3):
+        rgb = torch.from_numpy(W.tsn_features((B, T, 2048), 30 + i, "ep.rgb"))
+        tgt = torch.from_numpy(_targets(B, T, 86, 30 + i, "ep.tgt"))
+        batches.append((rgb, torch.zeros_like(rgb), tgt, ["v"] * B, torch.zeros(B), torch.full((B,), T)))
+    opt = torch.optim.AdamW([{"params": model.parameters(), "initial_lr": 1e-3}], lr=1e-3, weight_decay=cfg["weight_decay"])
+    l1 = train_one_epoch(batches, model, crit, opt, None, 1, "cuda:0", None, scheduler=None)
+    l2 = train_one_epoch(batches, model, crit, opt, None, 2, "cuda:0", None, scheduler=None)
+    l3 = train_one_epoch(batches, model, crit, opt, None, 3, "cuda:0", None, scheduler=None)
+    model.engine().check()
+    assert np.isfinite([l1, l2, l3]).all() and l3 < l1, (l1, l2, l3)
+    # eval mode still works after training steps (weights re-ingested), probabilities normalised
+    model.eval()
+    with torch.no_grad():
+        p = model(batches[0][0].cuda(), batches[0][1].cuda())["logits"]
+    assert torch.allclose(p.sum(-1), torch.ones_like(p[..., 0]), atol=1e-4)
+
+
+def test_empty_clip_list_is_a_noop():
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20)
+    model, _ = _build(cfg, sd)
+    outs, args, hl = model.engine().forward_ragged([], None, want_argmax=True, want_h_last=True)
+    assert outs == [] and args == [] and hl.shape == (0, 1024)
