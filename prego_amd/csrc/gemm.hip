@@ -236,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_big_kernel(
     if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");                      // no LDS access may be scheduled above the barrier
     // (staggering waves 4-7 - prefetch after their MFMAs - measured 8 % slower here: 828 vs 905 TFLOP/s)
     if (kt + 2 < nk) stage((kt + 2) % 3, kt + 2);
     compute(kt % 3);

@@ -94,11 +94,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
     }
   };
   const int nk = K / XBK;
+  if constexpr (NSPLIT == 2) {
+    // De-synchronise the CUs once: every workgroup of the first round sleeps a different fraction of one tile time, so
+    // that the 256 KB epilogue bursts (HBM-write bound when all 256 CUs store at once) spread over the main loops.
+    if (blockIdx.x < 256) {
+      const int phase = (blockIdx.x * 37) & 15;
+      const int n = (phase * nk * 3600 / 16) / 8128;
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (nothing newer is in flight yet)
     __builtin_amdgcn_s_barrier();
-    if constexpr (NSPLIT == 0) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
+    asm volatile("" ::: "memory");                      // no LDS access may be scheduled above the barrier
+    if constexpr (NSPLIT != 1) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
     compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
   }
 #pragma unroll
@@ -124,5 +134,8 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
   } else if (variant == 3 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<1><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 4 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<2><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
   }
 }

@@ -273,10 +273,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         if (stamp) st_acc[5] += spins;
         STAMP(0);
         f32x4 acc[3][UT];
-#pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-          for (int ut = 0; ut < UT; ++ut) acc[gate][ut] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           u32x4 v = hb[ks];
@@ -287,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
               for (int ut = 0; ut < UT; ++ut)
-                acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[gate][ut][ks], bfrag, acc[gate][ut], 0, 0, 0);
+                acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut], 0, 0, 0);
           } else {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut)
-                  acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gate][ut][ks][jj], bj, acc[gate][ut], 0, 0, 0);
+                  acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gate][ut][ks][jj], bj, (ks == 0 && jj == 0) ? zero4 : acc[gate][ut], 0, 0, 0);
             }
           }
         }
@@ -325,21 +322,29 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 
         // ---- (3) gates + state update for the registers this lane owns
         {
-          f32x4 part[3][4];
-#pragma unroll
-          for (int gate = 0; gate < 3; ++gate)
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) part[gate][qq] = redw[((qq * 3 + gate) * UT + own_ut) * 64 + lane];
           float gh[3][OWN_R];
+          if constexpr (OWN_R == 2) {
+            // this lane owns registers {own_r0, own_r0+1} of its tile: 8-byte reads instead of the whole 16-byte quad
+            float2 part[3][4];
 #pragma unroll
-          for (int gate = 0; gate < 3; ++gate) {
-            const f32x4 s = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
-            if constexpr (OWN_R == 2) {
-              gh[gate][0] = own_r0 ? s[2] : s[0];
-              gh[gate][1] = own_r0 ? s[3] : s[1];
-            } else {
-              gh[gate][0] = own_r0 == 0 ? s[0] : own_r0 == 1 ? s[1] : own_r0 == 2 ? s[2] : s[3];
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq)
+                part[gate][qq] = *(const float2*)((const float*)&redw[((qq * 3 + gate) * UT + own_ut) * 64 + lane] + own_r0);
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) {
+              gh[gate][0] = (part[gate][0].x + part[gate][1].x) + (part[gate][2].x + part[gate][3].x);
+              gh[gate][1] = (part[gate][0].y + part[gate][1].y) + (part[gate][2].y + part[gate][3].y);
             }
+          } else {
+            float part[3][4];
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq)
+                part[gate][qq] = *((const float*)&redw[((qq * 3 + gate) * UT + own_ut) * 64 + lane] + own_r0);
+#pragma unroll
+            for (int gate = 0; gate < 3; ++gate) gh[gate][0] = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
           }
           if (sidx[ct] < na) {
 #pragma unroll

@@ -3,12 +3,14 @@
 //   probs  = softmax(logits, -1)            eval branch,      model/rnn/rnn.py:66-70
 //   pred   = argmax(probs, axis=1)          trainer/eval.py:53
 // and the scatter from packed time-major rows back to the caller's per-clip [T, C] arrays.
-// C <= 128.  One wave owns 16 packed rows and all C (padded to 16*NTC) columns: the row softmax is a
-// 16-lane shuffle reduce over the MFMA accumulator layout (col = lane&15, row = (lane>>4)*4 + reg).
-// HBM-bound on reading relu(h) (2 KB/row in bf16); W_c (<= 256 KB) stays in L2.
+// C <= 128.  One wave owns HM x 16 packed rows and all C (padded to 16*NTC) columns: every W_c fragment it pulls
+// from L2 feeds HM row tiles (with one row tile per wave the kernel moved 6x more W_c bytes than relu(h) bytes); the
+// row softmax is a 16-lane shuffle reduce over the MFMA accumulator layout (col = lane&15, row = (lane>>4)*4 + reg).
+// HBM-bound on reading relu(h) (2 KB/row in bf16).
 #include "common.h"
 #include "kernels.h"
 
+#define HM 4      // 16-row tiles per wave
 template <typename WT, int NTC>
 __global__ __launch_bounds__(256) void head_softmax_kernel(
     const WT* __restrict__ Hrelu,      // [nrows][HID] chunk-relative packed rows
@@ -20,42 +22,54 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
   constexpr bool BF = (sizeof(WT) == 2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int rbase = (blockIdx.x * 4 + wave) * 16;
+  const int rbase = (blockIdx.x * 4 + wave) * 16 * HM;
   if (rbase >= nrows) return;
-  int arow = rbase + l15; if (arow > nrows - 1) arow = nrows - 1;
-
-  f32x4 acc[NTC];
+  int arow[HM];
 #pragma unroll
-  for (int j = 0; j < NTC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < HM; ++m) { arow[m] = rbase + m * 16 + l15; if (arow[m] > nrows - 1) arow[m] = nrows - 1; }
+
+  f32x4 acc[HM][NTC];
+#pragma unroll
+  for (int m = 0; m < HM; ++m)
+#pragma unroll
+    for (int j = 0; j < NTC; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if constexpr (BF) {
-    const bf16_t* ap = (const bf16_t*)Hrelu + (size_t)arow * HID + 8 * l4;
     const bf16_t* bp = (const bf16_t*)Wc + (size_t)l15 * HID + 8 * l4;
     for (int k = 0; k < HID; k += 32) {
-      const bf16x8 af = *(const bf16x8*)(ap + k);
+      bf16x8 af[HM];
+#pragma unroll
+      for (int m = 0; m < HM; ++m) af[m] = *(const bf16x8*)((const bf16_t*)Hrelu + (size_t)arow[m] * HID + 8 * l4 + k);
 #pragma unroll
       for (int j = 0; j < NTC; ++j) {
         const bf16x8 bfr = *(const bf16x8*)(bp + (size_t)j * 16 * HID + k);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < HM; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][j], 0, 0, 0);
       }
     }
   } else {
-    const float* ap = (const float*)Hrelu + (size_t)arow * HID + 4 * l4;
     const float* bp = (const float*)Wc + (size_t)l15 * HID + 4 * l4;
     for (int k = 0; k < HID; k += 16) {
-      const float4 af = *(const float4*)(ap + k);
+      float4 af[HM];
+#pragma unroll
+      for (int m = 0; m < HM; ++m) af[m] = *(const float4*)((const float*)Hrelu + (size_t)arow[m] * HID + 4 * l4 + k);
 #pragma unroll
       for (int j = 0; j < NTC; ++j) {
         const float4 bv = *(const float4*)(bp + (size_t)j * 16 * HID + k);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bv.x, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bv.y, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bv.z, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bv.w, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < HM; ++m) {
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].x, bv.x, acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].y, bv.y, acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].z, bv.z, acc[m][j], 0, 0, 0);
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m].w, bv.w, acc[m][j], 0, 0, 0);
+        }
       }
     }
   }
 
-  // lane holds, for rows r = l4*4 + e (e = 0..3), columns c = j*16 + l15
+  // lane holds, for rows r = m*16 + l4*4 + e (e = 0..3), columns c = j*16 + l15
+#pragma unroll
+  for (int m = 0; m < HM; ++m)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float v[NTC];
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
 #pragma unroll
     for (int j = 0; j < NTC; ++j) {
       const int c = j * 16 + l15;
-      v[j] = acc[j][e] + bc[c];
+      v[j] = acc[m][j][e] + bc[c];
       if (c < C && v[j] > mx) { mx = v[j]; mi = c; }    // ascending c: first max wins inside the lane
     }
     // reduce (max, lowest index) over the 16 lanes that share this row
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
 #pragma unroll
       for (int j = 0; j < NTC; ++j) v[j] *= inv;
     }
-    const int r = rbase + l4 * 4 + e;
+    const int r = rbase + m * 16 + l4 * 4 + e;
     if (r < nrows) {
       const int row = row0 + r;
       int clip, t;
@@ -115,7 +129,7 @@ int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const floa
                         float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s) {
   if (nrows <= 0) return 0;
   const int ntc = (C + 15) / 16;
-  const int grid = (nrows + 63) / 64;
+  const int grid = (nrows + 64 * HM - 1) / (64 * HM);
 #define HL(WT, N)                                                                                             \
   head_softmax_kernel<WT, N><<<grid, 256, 0, s>>>((const WT*)Hrelu, (const WT*)Wc, bc, plan, row0, nrows,     \
                                                   hid, C, apply_softmax, out_ptrs, argmax_ptrs)

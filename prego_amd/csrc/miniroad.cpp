@@ -107,7 +107,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   *out = nullptr;
   if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16) return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
   if (hid != 1024) return fail(PREGO_EINVAL, "hidden_dim %d unsupported: the register-resident recurrence is built for 1024", hid);
-  if (emb <= 0 || emb % 256 || emb > 4096) return fail(PREGO_EINVAL, "embedding_dim %d must be a multiple of 256, <= 4096", emb);
+  if (emb <= 0 || emb % 512 || emb > 4096) return fail(PREGO_EINVAL, "embedding_dim %d must be a multiple of 512, <= 4096", emb);
   if (d_rgb < 0 || d_flow < 0 || d_rgb + d_flow <= 0 || (d_rgb % 64) || (d_flow % 64))
     return fail(PREGO_EINVAL, "feature sizes %d/%d must be multiples of 64", d_rgb, d_flow);
   if (n_classes <= 0 || n_classes > 128) return fail(PREGO_EINVAL, "num_classes %d must be in 1..128", n_classes);

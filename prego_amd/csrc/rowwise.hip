@@ -45,9 +45,10 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
   }
 }
 
-// One wave per row, 4 rows per block.  E multiple of 256 and <= 4096 (16 float4 per lane max).
-// Two-pass statistics in registers (mean, then centred sum of squares) = what torch's CPU
-// LayerNorm computes up to summation order; biased variance, eps inside the sqrt.
+// One wave per row, 4 rows per block.  E multiple of 512 and <= 4096: each lane owns 8 consecutive columns per
+// 512-column slab (two 16-byte loads, ONE 16-byte bf16 store: 8-byte stores run at 0.5-0.7x the 16-byte rate).
+// Two-pass statistics in registers (mean, then centred sum of squares) = what torch's CPU LayerNorm computes up to
+// summation order; biased variance, eps inside the sqrt.
 template <typename OutT, int MAXV>
 __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
     const float* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -59,50 +60,51 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int nv = E / 256;                      // float4 per lane
+  const int nv = E / 512;                      // 8-column groups per lane
   for (int r = blockIdx.x * 4 + wave; r < nrows; r += gridDim.x * 4) {
-    const float4* y = (const float4*)(Y + (size_t)r * E);
-    float4 v[MAXV];
+    const float* y = Y + (size_t)r * E;
+    float v[MAXV][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
-        v[i] = y[i * 64 + lane];
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        const float4 a = nt_load4(y + (i * 64 + lane) * 8);
+        const float4 b = nt_load4(y + (i * 64 + lane) * 8 + 4);
+        v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
+        s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
       }
     const float mu = wave_sum(s) / (float)E;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
-        float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-        q += (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
       }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
     if (stats && lane == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
-        const int c = (i * 64 + lane) * 4;
-        const float4 g = *(const float4*)(gamma + c);
-        const float4 b = *(const float4*)(beta + c);
-        float o0 = (v[i].x - mu) * rstd * g.x + b.x;
-        float o1 = (v[i].y - mu) * rstd * g.y + b.y;
-        float o2 = (v[i].z - mu) * rstd * g.z + b.z;
-        float o3 = (v[i].w - mu) * rstd * g.w + b.w;
-        if (relu) { o0 = fmaxf(o0, 0.f); o1 = fmaxf(o1, 0.f); o2 = fmaxf(o2, 0.f); o3 = fmaxf(o3, 0.f); }
-        if (thresh) {
-          const size_t e0 = (size_t)(row0_abs + r) * E + c;
-          o0 = dropout_keep_(seed, e0 + 0, thresh) ? o0 * keep_scale : 0.f;
-          o1 = dropout_keep_(seed, e0 + 1, thresh) ? o1 * keep_scale : 0.f;
-          o2 = dropout_keep_(seed, e0 + 2, thresh) ? o2 * keep_scale : 0.f;
-          o3 = dropout_keep_(seed, e0 + 3, thresh) ? o3 * keep_scale : 0.f;
+        const int c = (i * 64 + lane) * 8;
+        const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
+        const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          o[k] = (v[i][k] - mu) * rstd * gg[k] + bb[k];
+          if (relu) o[k] = fmaxf(o[k], 0.f);
+          if (thresh) o[k] = dropout_keep_(seed, (size_t)(row0_abs + r) * E + c + k, thresh) ? o[k] * keep_scale : 0.f;
         }
         if constexpr (sizeof(OutT) == 2) {
-          uint2 o; o.x = pack_bf16x2(o0, o1); o.y = pack_bf16x2(o2, o3);
-          *(uint2*)(out + (size_t)r * E + c) = o;
+          uint4 w;
+          w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]); w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+          *(uint4*)(out + (size_t)r * E + c) = w;
         } else {
-          *(float4*)(out + (size_t)r * E + c) = make_float4(o0, o1, o2, o3);
+          *(float4*)(out + (size_t)r * E + c) = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(out + (size_t)r * E + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
       }
   }
@@ -146,11 +148,11 @@ void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* 
   int grid = (nrows + 3) / 4;
   if (grid > 16384) grid = 16384;
   if (E <= 2048) {
+    if (bf16) ln_relu_rows_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    else ln_relu_rows_kernel<float, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
+  } else {
     if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
     else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
-  } else {
-    if (bf16) ln_relu_rows_kernel<bf16_t, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
-    else ln_relu_rows_kernel<float, 16><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
   }
 }
 

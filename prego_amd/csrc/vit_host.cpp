@@ -45,7 +45,7 @@ extern "C" int prego_vit_create(prego_vit** out, int d_rgb, int d_flow, int emb,
   *out = nullptr;
   const int din = d_rgb + d_flow;
   if (din <= 0 || din % 64) return prego_fail_(PREGO_EINVAL, "feature size %d must be a multiple of 64", din);
-  if (emb % 256 || emb > 4096) return prego_fail_(PREGO_EINVAL, "embedding_dim %d must be a multiple of 256, <= 4096", emb);
+  if (emb % 512 || emb > 4096) return prego_fail_(PREGO_EINVAL, "embedding_dim %d must be a multiple of 512, <= 4096", emb);
   if (mlp % 128) return prego_fail_(PREGO_EINVAL, "hidden_dim (mlp) %d must be a multiple of 128", mlp);
   if (heads <= 0 || emb % heads) return prego_fail_(PREGO_EINVAL, "num_heads %d must divide embedding_dim", heads);
   const int dh = emb / heads;
