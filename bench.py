@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--rows-per-chunk", type=int, default=0, help="pipeline chunk size in packed rows (debug)")
     ap.add_argument("--no-zero-flow", action="store_true", help="skip the extra zero-flow fast-path timing")
     return ap.parse_args()
 
@@ -72,6 +73,8 @@ def main():
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     model.eval()
     eng = model.engine()
+    if args.rows_per_chunk:
+        eng.rows_per_chunk = args.rows_per_chunk
 
     lens = assembly101_eval_lengths(seed=20 + rank)
     if args.clips:
