@@ -55,6 +55,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
+  // NSPLIT == 3: waves 4-7 (the second wave of every SIMD) issue ALL 64 DMA pieces of the next tile; waves 0-3 go
+  // straight to their MFMAs, so the DMA issue of one wave runs beside the matrix work of its SIMD partner
+  const bf16_t* l_src[16];
+  if constexpr (NSPLIT == 3) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int piece = ((wave & 3) * 16 + i);             // 0..63: pieces 0..31 = A rows, 32..63 = B rows
+      const int r = (piece & 31) * 8 + sr;
+      const int c = scp ^ ((r >> 1) & 7);
+      if (piece < 32) { int ar = m0 + r; if (ar > M - 1) ar = M - 1; l_src[i] = A + (size_t)ar * lda + c * 8; }
+      else l_src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+    }
+  }
+  auto stage_loader = [&](int buf, int kt) {
+    char* base = smem + buf * XSTAGE;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int piece = ((wave & 3) * 16 + i);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(l_src[i] + (size_t)kt * XBK),
+                                       (__attribute__((address_space(3))) void*)(base + piece * 1024), 16, 0, 0);
+    }
+  };
   auto stage_piece = [&](int buf, int kt, int i) {
     char* la = smem + buf * XSTAGE;
     char* lb = la + 32768;
@@ -93,6 +115,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
       }
     }
   };
+  // NSPLIT == 4: the fragment reads of phase p+1 are issued before the MFMAs of phase p (register double buffer), so the
+  // LDS latency hides under the wave's own matrix work instead of in an lgkmcnt(0) stall per 16-MFMA cluster
+  auto lda_frag = [&](const char* la, int ks, int h, bf16x8 (&af)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ra = wm * 128 + h * 64 + i * 16 + fr;
+      af[i] = *(const bf16x8*)(la + ra * 128 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 4));
+    }
+  };
+  auto ldb_frag = [&](const char* lb, int ks, bf16x8 (&bfr)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rb = wn * 64 + j * 16 + fr;
+      bfr[j] = *(const bf16x8*)(lb + rb * 128 + (((ks * 4 + fq) ^ ((rb >> 1) & 7)) << 4));
+    }
+  };
+  auto mma = [&](int h, const bf16x8 (&af)[4], const bf16x8 (&bfr)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto compute_piped = [&](int buf) {
+    const char* la = smem + buf * XSTAGE;
+    const char* lb = la + 32768;
+    bf16x8 a0[4], a1[4], b0[4], b1[4];
+    ldb_frag(lb, 0, b0); lda_frag(la, 0, 0, a0);
+    lda_frag(la, 0, 1, a1);                 // phase 1 operands in flight ...
+    mma(0, a0, b0);                         // ... under phase 0's MFMAs
+    ldb_frag(lb, 1, b1); lda_frag(la, 1, 0, a0);
+    mma(1, a1, b0);
+    lda_frag(la, 1, 1, a1);
+    mma(0, a0, b1);
+    mma(1, a1, b1);
+  };
   const int nk = K / XBK;
   if constexpr (NSPLIT == 2) {
     // De-synchronise the CUs once: every workgroup of the first round sleeps a different fraction of one tile time, so
@@ -103,13 +163,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
       for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
     }
   }
-  stage(0, 0);
+  if constexpr (NSPLIT == 3) { if (wave >= 4) stage_loader(0, 0); } else stage(0, 0);
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (nothing newer is in flight yet)
+    if constexpr (NSPLIT != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (nothing newer is in flight yet)
+    // (NSPLIT == 5 is a TIMING-ONLY build without this wait: wrong results, prices the DMA latency)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                      // no LDS access may be scheduled above the barrier
-    if constexpr (NSPLIT != 1) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
-    compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
+    if constexpr (NSPLIT == 3) { if (wave >= 4 && kt + 1 < nk) stage_loader((kt + 1) & 1, kt + 1); }
+    else if constexpr (NSPLIT != 1) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
+    if constexpr (NSPLIT == 4) compute_piped(kt & 1); else compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -134,6 +196,15 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
   } else if (variant == 3 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<1><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 5 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<3><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 6 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<4><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 7 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<5><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
   } else if (variant == 4 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<2><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
