@@ -2,6 +2,9 @@
 // win move into gemm.hip.
 #include "common.h"
 #include "kernels.h"
+#include <cstdio>
+
+__device__ unsigned long long g_gemm_dbg[8];      // diagnostic build (NSPLIT == 6) only: cycle sums of block 0 / wave 0
 
 __device__ __forceinline__ int xcd_remap2(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -140,6 +143,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
         acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
   };
+  // NSPLIT == 7: like compute_piped, but the next tile's 8 DMA pieces are issued in the first two phases (4 + 4), each
+  // group right behind a phase's fragment reads, so that one wave's DMA issue (80-190 cycles per piece, measured) runs
+  // beside its SIMD partner's MFMAs instead of both waves issuing at the top of the tile with the matrix pipe idle
+  auto compute_piped_dma = [&](int buf, int nbuf, int nkt, bool pre) {
+    const char* la = smem + buf * XSTAGE;
+    const char* lb = la + 32768;
+    bf16x8 a0[4], a1[4], b0[4], b1[4];
+    ldb_frag(lb, 0, b0); lda_frag(la, 0, 0, a0);
+    lda_frag(la, 0, 1, a1);
+    if (pre) { stage_piece(nbuf, nkt, 0); stage_piece(nbuf, nkt, 1); }
+    mma(0, a0, b0);
+    ldb_frag(lb, 1, b1); lda_frag(la, 1, 0, a0);
+    if (pre) { stage_piece(nbuf, nkt, 2); stage_piece(nbuf, nkt, 3); }
+    mma(1, a1, b0);
+    lda_frag(la, 1, 1, a1);
+    mma(0, a0, b1);
+    mma(1, a1, b1);
+  };
   auto compute_piped = [&](int buf) {
     const char* la = smem + buf * XSTAGE;
     const char* lb = la + 32768;
@@ -164,15 +185,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
     }
   }
   if constexpr (NSPLIT == 3) { if (wave >= 4) stage_loader(0, 0); } else stage(0, 0);
+  unsigned long long t_wait = 0, t_issue = 0, t_comp = 0, t0 = 0;
+  const bool dbg = (NSPLIT == 6) && blockIdx.x == 0 && (wave == 0 || wave == 4);
   for (int kt = 0; kt < nk; ++kt) {
+    if (dbg) t0 = __builtin_amdgcn_s_memtime();
     if constexpr (NSPLIT != 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile kt landed (nothing newer is in flight yet)
     // (NSPLIT == 5 is a TIMING-ONLY build without this wait: wrong results, prices the DMA latency)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");                      // no LDS access may be scheduled above the barrier
+    if (dbg) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_wait += n - t0; t0 = n; }
     if constexpr (NSPLIT == 3) { if (wave >= 4 && kt + 1 < nk) stage_loader((kt + 1) & 1, kt + 1); }
-    else if constexpr (NSPLIT != 1) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
-    if constexpr (NSPLIT == 4) compute_piped(kt & 1); else compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
+    else if constexpr (NSPLIT != 1 && NSPLIT != 7) { if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1); }
+    if (dbg) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_issue += n - t0; t0 = n; }
+    if constexpr (NSPLIT == 7) compute_piped_dma(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
+    else if constexpr (NSPLIT == 4 || NSPLIT == 6) compute_piped(kt & 1); else compute(kt & 1, (kt + 1) & 1, kt + 1, kt + 1 < nk);
+    if (dbg) { const unsigned long long n = __builtin_amdgcn_s_memtime(); t_comp += n - t0; t0 = n; }
   }
+  if (dbg && lane == 0) { const int o = wave == 0 ? 0 : 4; g_gemm_dbg[o] = t_wait; g_gemm_dbg[o + 1] = t_issue; g_gemm_dbg[o + 2] = t_comp; g_gemm_dbg[o + 3] = nk; }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -205,6 +234,17 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
   } else if (variant == 7 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<5><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 8 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<6><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+    unsigned long long h[8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_dbg), sizeof h);
+    printf("gemm dbg (cycles per K tile): wave0 wait+barrier %.0f, dma issue %.0f, compute %.0f | wave4 wait+barrier %.0f, dma issue %.0f, compute %.0f\n",
+           (double)h[0] / h[3], (double)h[1] / h[3], (double)h[2] / h[3], (double)h[4] / h[7], (double)h[5] / h[7], (double)h[6] / h[7]);
+  } else if (variant == 9 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_kernel<7><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
   } else if (variant == 4 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<2><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
