@@ -54,7 +54,7 @@ const char* prego_last_error(void);
 
 /* MROAD.__init__ (rnn.py:21-49): d_rgb/d_flow = FEATURE_SIZES of cfg['rgb_type'/'flow_type'] (0 when
  * --no_rgb/--no_flow), emb = cfg['embedding_dim'], hid = cfg['hidden_dim'], n_classes = cfg['num_classes'].
- * Supported on gfx950: hid == 1024, emb % 256 == 0 (<= 4096), (d_rgb + d_flow) % 64 == 0, n_classes <= 128. */
+ * Supported on gfx950: hid == 1024, emb % 512 == 0 (<= 4096), d_rgb % 64 == 0, d_flow % 64 == 0, n_classes <= 128. */
 int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
                           int compute_dtype);
 void prego_miniroad_destroy(prego_miniroad* h);
@@ -68,7 +68,10 @@ int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1_w, const f
                                const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih,
                                const float* b_hh, const float* fc_w, const float* fc_b, prego_stream_t stream);
 
-/* Largest number of clips one forward() call can advance together (clips beyond it: call again). */
+/* Largest number of clips one forward() call accepts (8192).  The call packs them, longest first, into its recurrence
+ * slots (continuous batching: a slot runs several clips back to back, h restarts from 0 at every clip boundary), so
+ * the number of sequential steps is max(longest clip, frames / slots).  Calls that pass h0 or h_last, or keep
+ * activations for backward, need one clip per slot: at most 512 clips (bf16) / 256 (fp32). */
 int prego_miniroad_max_clips(const prego_miniroad* h);
 
 /* Workspace size (bytes) that lets forward() process `rows_per_chunk` packed rows (frames) per pipeline
@@ -130,7 +133,7 @@ typedef struct prego_vit prego_vit;
 
 /* ViTEnc.__init__ (ViT.py:26-90) with patch_dim = 1: emb = cfg['embedding_dim'], mlp = cfg['hidden_dim'] (ViT.py:75),
  * heads = cfg['num_heads'], layers = cfg['num_layers'], window = cfg['window_size'] (the learned positional table pins
- * T == window, PositionalEncoding.py:25-41).  Supported: head dim 64/128/256, emb % 256 == 0, mlp % 128 == 0. */
+ * T == window, PositionalEncoding.py:25-41).  Supported: head dim 64/128/256, emb % 512 == 0, mlp % 128 == 0. */
 int prego_vit_create(prego_vit** out, int d_rgb, int d_flow, int emb, int mlp, int heads, int layers, int window,
                      int n_classes);
 void prego_vit_destroy(prego_vit* h);
