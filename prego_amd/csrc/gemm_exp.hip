@@ -216,6 +216,197 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
     }
 }
 
+// variant 10: producer/consumer wave specialisation.  12 waves per workgroup: waves 0-7 (two per SIMD) only compute
+// (128x64 per wave, 128 accumulator registers), waves 8-11 (one more per SIMD) only issue the LDS-DMA pieces of the next
+// K tile (16 each) - the DMA issue (80-190 cycles per 1 KiB piece) then runs beside the matrix work instead of in front
+// of it.  Register allocation is uniform per kernel, so every wave gets <= 168 VGPRs (3 waves per SIMD).
+__global__ __launch_bounds__(768, 3) void gemm_bf16_nt_256sq_pc_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 32 KB | B 32 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntn = N / XBN;
+  const int ntm = (M + XBM - 1) / XBM;
+  const int tile = xcd_remap2(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * XBM, n0 = (tile % ntn) * XBN;
+  const int nk = K / XBK;
+  if (wave >= 8) {
+    // ---------------- loader waves ----------------
+    __builtin_amdgcn_s_setprio(3);
+    const int sr = lane >> 3, scp = lane & 7;
+    const int lw = wave - 8;
+    const bf16_t* src[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int piece = lw * 16 + i;                       // 0..63: 0..31 A rows, 32..63 B rows
+      const int r = (piece & 31) * 8 + sr;
+      const int c = scp ^ ((r >> 1) & 7);
+      if (piece < 32) { int ar = m0 + r; if (ar > M - 1) ar = M - 1; src[i] = A + (size_t)ar * lda + c * 8; }
+      else src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+      char* base = smem + buf * XSTAGE;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * XBK),
+                                         (__attribute__((address_space(3))) void*)(base + (lw * 16 + i) * 1024), 16, 0, 0);
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    }
+    return;
+  }
+  // ---------------- compute waves ----------------
+  const int wm = wave >> 2, wn = wave & 3;                      // 2 x 4
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* la = smem + (kt & 1) * XSTAGE;
+    const char* lb = la + 32768;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rb = wn * 64 + j * 16 + fr;
+        bfr[j] = *(const bf16x8*)(lb + rb * 128 + (((ks * 4 + fq) ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ra = wm * 128 + h * 64 + i * 16 + fr;
+          af[i] = *(const bf16x8*)(la + ra * 128 + (((ks * 4 + fq) ^ ((ra >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 128 + i * 16 + fq * 4 + e;
+        if (m < M) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+      }
+    }
+}
+
+// variant 11: 256x256x32 tiles, FOUR 32 KB LDS stages (A 16 KB + B 16 KB), prefetch three small tiles ahead with a
+// counted vmcnt, and the 4 DMA pieces a wave owes per tile are issued ONE AT A TIME between its MFMA groups, so a wave's
+// DMA-issue stall (80-190 cycles per piece) always has the SIMD partner's MFMAs beside it and still leaves the data two
+// whole tiles of lead time.  Rows are 64 B in LDS: chunk swizzle c ^ ((row >> 2) & 3).
+#define YBK 32
+#define YSTAGE 32768
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_k32_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [4][A 16 KB | B 16 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int ntn = N / XBN;
+  const int ntm = (M + XBM - 1) / XBM;
+  const int tile = xcd_remap2(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * XBM, n0 = (tile % ntn) * XBN;
+  // DMA pieces: 1 KB = 16 rows x 64 B.  A: 16 pieces, B: 16 pieces per tile; wave w issues A pieces {2w, 2w+1}, B {2w, 2w+1}
+  const int pr = lane >> 2, pp = lane & 3;
+  const bf16_t* src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int piece = wave * 2 + (i & 1);                  // 0..15
+    const int r = piece * 16 + pr;                         // tile row 0..255
+    const int c = pp ^ ((r >> 2) & 3);
+    if (i < 2) { int ar = m0 + r; if (ar > M - 1) ar = M - 1; src[i] = A + (size_t)ar * lda + c * 8; }
+    else src[i] = B + (size_t)(n0 + r) * ldb + c * 8;
+  }
+  auto piece_issue = [&](int buf, int kt, int i) {
+    char* base = smem + buf * YSTAGE + (i < 2 ? 0 : 16384) + (wave * 2 + (i & 1)) * 1024;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * YBK),
+                                     (__attribute__((address_space(3))) void*)base, 16, 0, 0);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = K / YBK;
+  // prologue: tiles 0, 1, 2 in flight
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (t < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) piece_issue(t, t, i);
+    }
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt landed: the two newer tiles (8 pieces of this wave) may stay in flight
+    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char* la = smem + (kt & 3) * YSTAGE;
+    const char* lb = la + 16384;
+    const bool pre = kt + 3 < nk;
+    const int nbuf = (kt + 3) & 3;
+    bf16x8 bfr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rb = wn * 64 + j * 16 + fr;
+      bfr[j] = *(const bf16x8*)(lb + rb * 64 + ((fq ^ ((rb >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 128 + h * 64 + i * 16 + fr;
+        af[i] = *(const bf16x8*)(la + ra * 64 + ((fq ^ ((ra >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((i & 1) == 0 && pre) piece_issue(nbuf, kt + 3, h * 2 + (i >> 1));      // one DMA piece per 8 MFMAs
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[h * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[h * 4 + i][j], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 128 + i * 16 + fq * 4 + e;
+        if (m < M) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+      }
+    }
+}
+
 void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
                                    int ldc, int M, int N, int K, hipStream_t s) {
   const int ntm = (M + XBM - 1) / XBM, ntn = N / XBN;
@@ -245,6 +436,12 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
   } else if (variant == 9 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<7><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 10 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
+    gemm_bf16_nt_256sq_pc_kernel<<<ntm * ntn, 768, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 11 && N % 256 == 0) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_k32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * YSTAGE);
+    gemm_bf16_nt_256sq_k32_kernel<<<ntm * ntn, 512, 4 * YSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
   } else if (variant == 4 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<2><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
