@@ -181,7 +181,7 @@ def main():
             "output_sane": ok,
         }
         line.update(extra)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(sd, lens, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if dist is not None:
