@@ -85,10 +85,8 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward.argtypes = [i32] * 5 + [vp] * 10 + [vp, sz, vp]
     lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
-    for name in SYMBOLS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("prego_abi_version", "prego_miniroad_max_clips"):
-            pass
+    for name in SYMBOLS:          # fail loudly at load time if the library is stale
+        getattr(lib, name)
     _lib = lib
     return lib
 
