@@ -92,10 +92,18 @@ for _name in ("ASSEMBLY101-O", "EPIC-TENT-O"):
 
 
 def build_data_loader(cfg, mode):
-    """datasets/dataset_builder.py:15-24"""
+    """datasets/dataset_builder.py:15-24.  Under torch.distributed the TRAIN loader shards the windows across ranks
+    (DistributedSampler pads the last batch so that every rank takes the same number of steps: the loss is a batch mean,
+    criterions/loss.py:30-31, so equal local batches + a gradient all-reduce-mean reproduce the single-process step with
+    global batch = world * batch_size; set cfg['batch_size'] = 16 / world to keep the reference's global batch)."""
+    import torch.distributed as dist
     ds = DATA_LAYERS[cfg["data_name"]](cfg, mode)
+    sampler = None
+    if mode == "train" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        sampler = data.distributed.DistributedSampler(ds, shuffle=True, drop_last=False)
     return data.DataLoader(dataset=ds, batch_size=cfg["batch_size"] if mode == "train" else cfg["test_batch_size"],
-                           shuffle=mode == "train", num_workers=cfg["num_workers"], pin_memory=True)
+                           shuffle=(mode == "train" and sampler is None), sampler=sampler,
+                           num_workers=cfg["num_workers"], pin_memory=True)
 
 
 # ---- clip sharding for data-parallel inference (SURVEY.md section 8e) --------------------------------

@@ -16,6 +16,7 @@ import time
 
 import numpy as np
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from .metrics import perframe_average_precision
@@ -57,22 +58,49 @@ class Evaluate(nn.Module):
         model.eval()
         output = {}
         max_clips = model.engine().max_clips
+        # data-parallel eval: videos are independent, so under torch.distributed rank r takes every world-th video of
+        # the loader's order (no data-path collective); rank 0 gathers the per-video results once at the end
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank() if world > 1 else 0
         with torch.no_grad():
             pred_scores, gt_targets = [], []
+            per_video = []                       # (loader position, n_frames) to restore the loader's order on rank 0
             t_begin = time.time()
-            batch, frames = [], 0
+            batch, frames, pos = [], 0, 0
             for rgb_input, flow_input, target, vid, start, end in dataloader:
                 # loader items carry a leading batch dim of test_batch_size == 1 (dataset_builder.py:19)
                 for b in range(rgb_input.shape[0]):
+                    mine = (pos % world) == rank
+                    pos += 1
+                    if not mine:
+                        continue
                     name = vid[b] if isinstance(vid, (list, tuple)) else vid
                     batch.append((rgb_input[b].float().contiguous(), flow_input[b].float().contiguous(),
                                   target[b], name))
+                    per_video.append((pos - 1, int(rgb_input.shape[1])))
                     frames += rgb_input.shape[1]
                 if len(batch) >= max_clips or frames >= self.max_frames_per_batch:
                     self._flush(model, batch, pred_scores, gt_targets, output, device)
                     frames = 0
             self._flush(model, batch, pred_scores, gt_targets, output, device)
             model.engine().check()
+            if world > 1:
+                gathered = [None] * world if rank == 0 else None
+                dist.gather_object((per_video, [np.asarray(p) for p in pred_scores], [np.asarray(g) for g in gt_targets], output),
+                                   gathered, dst=0)
+                if rank != 0:
+                    return float("nan")          # only rank 0 reports (main.py logs / checkpoints on rank 0)
+                chunks = []
+                output = {}
+                for pv, ps, gs, out in gathered:
+                    o = 0
+                    for p_idx, n in pv:
+                        chunks.append((p_idx, ps[o:o + n], gs[o:o + n]))
+                        o += n
+                    output.update(out)
+                chunks.sort(key=lambda c: c[0])
+                pred_scores = [r for c in chunks for r in c[1]]
+                gt_targets = [r for c in chunks for r in c[2]]
             if self.cfg["eval"] is not None:
                 os.makedirs(self.output_dir, exist_ok=True)
                 with open(os.path.join(self.output_dir, "output_miniROAD.json"), "w") as file:
