@@ -7,8 +7,11 @@
 //    workgroups (bf16: P = 32, G = 8; fp32: P = 64, G = 4).  A workgroup owns 16*UT hidden units
 //    (all three gates) and holds its 3*16*UT x H weight slice as MFMA A-fragments in VGPRs: wave q
 //    (one wave per SIMD, 512-VGPR budget) keeps the K-quarter [q*H/4, (q+1)*H/4) = 192 VGPRs.
-//  * Clips are independent (h0 = 0 per clip, rnn.py:49,60): sorted clip i runs on group i % G,
-//    slot i / G, so every group advances its own <= 16*NCT clips and groups never talk.
+//  * Clips are independent (h0 = 0 per clip, rnn.py:49,60): the sorted slots are dealt to the groups 16 at a
+//    time (layer ct = slots [ct*16G, (ct+1)*16G), group g takes [g*16, g*16+16) of each layer), so every group
+//    advances its own <= 16*NCT slots and groups never talk.  Slots are sorted by load, so the groups finish one
+//    after the other (the BASELINE workload: group 7 after 12.6 k of the 34 k steps, group 1 after 21.4 k) and a
+//    finished group's workgroups EXIT, which hands their CUs to whatever else is queued on the device.
 //  * Per step a workgroup needs the whole h_{t-1} of its group: an all-gather inside the group through
 //    a double-buffered exchange buffer in global memory.  THE DATA IS THE FLAG: |h| <= 1 for a GRU state,
 //    so the top exponent bit of every bf16 (bit 14) / fp32 (bit 30) element is free and carries a one-bit
@@ -39,7 +42,17 @@
 #define SPIN_LIMIT (1u << 22)
 #define GRU_MAX_TILES 8                      // clip tiles per group the exchange buffer is laid out for (128 slots)
 
-template <typename WT, int HID, int UT, int NCT>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// two floats -> packed bf16x2 (one v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// TRAIN: also store the gate activations / raw state BPTT needs (a.keep_*, a.h_raw_out); the inference instantiation
+// carries none of that code or its registers.
+template <typename WT, int HID, int UT, int NCT, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   constexpr bool BF = (sizeof(WT) == 2);
   constexpr int UNITS = 16 * UT;              // hidden units owned by this workgroup
@@ -92,7 +105,11 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   const int place = __builtin_amdgcn_readfirstlane(s_place[2]);
   if (place < 0) return;                      // rendezvous timed out (abort word set)
   const bool local = place == 1;              // whole group on one XCD, verified
-  if (g >= a.n_clips) return;                 // group without clips
+  if (g * 16 >= a.n_clips) return;            // group without slots
+  {                                           // group whose slots have all ended before this launch (nact never grows)
+    typedef const __attribute__((address_space(4))) int* cint_p0;
+    if (g * 16 >= ((cint_p0)a.nact)[a.t0]) return;
+  }
   const int l15 = lane & 15, l4 = lane >> 4;
 
   // ---- resident weights -------------------------------------------------------------------
@@ -127,8 +144,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   for (int e = 0; e < OWN_R; ++e) bhn[e] = a.b_hn[ucol + e];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    sidx[ct] = (ct * 16 + l15) * a.G + g;
-    tfirst[ct] = ct * 16 * a.G + g;
+    sidx[ct] = ct * 16 * a.G + g * 16 + l15;
+    tfirst[ct] = ct * 16 * a.G + g * 16;
 #pragma unroll
     for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = (sidx[ct] < a.n_clips) ? a.h_state[(size_t)sidx[ct] * HID + ucol + e] : 0.f;
   }
@@ -170,7 +187,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const int off = buf * buf_stride + ((ucol / KF) * GRU_MAX_TILES + ct) * 1024 + ((((ucol % KF) / EPL) << 4) + l15) * 16 +
                     (ucol % EPL) * (int)sizeof(WT);
     if constexpr (BF) {
-      const unsigned v = tag_bf(zero ? 0.f : hreg[ct][0], tag) | (tag_bf(zero ? 0.f : hreg[ct][1], tag) << 16);
+      f32x2 hv = {zero ? 0.f : hreg[ct][0], zero ? 0.f : hreg[ct][1]};
+      hv[0] = __builtin_amdgcn_fmed3f(hv[0], -1.9921875f, 1.9921875f);
+      hv[1] = __builtin_amdgcn_fmed3f(hv[1], -1.9921875f, 1.9921875f);
+      const unsigned v = (cvt_pk_bf16(hv) & 0xBFFFBFFFu) | (tag ? 0x40004000u : 0u);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
     } else {
@@ -322,21 +342,46 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 
         // ---- (3) gates + state update for the registers this lane owns
         {
-          float gh[3][OWN_R];
           if constexpr (OWN_R == 2) {
-            // this lane owns registers {own_r0, own_r0+1} of its tile: 8-byte reads instead of the whole 16-byte quad
-            float2 part[3][4];
+            // this lane owns registers {own_r0, own_r0+1} of its tile: 8-byte LDS reads at immediate offsets, and the two
+            // elements go through the gate math as one f32x2 (v_pk_add/mul/fma_f32): the step runs one wave per SIMD,
+            // so every VALU instruction is ~4 cycles of its critical path
+            const f32x2* rp = (const f32x2*)((const float*)&redw[own_ut * 64 + lane] + own_r0);
+            f32x2 part[3][4];
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-              for (int qq = 0; qq < 4; ++qq)
-                part[gate][qq] = *(const float2*)((const float*)&redw[((qq * 3 + gate) * UT + own_ut) * 64 + lane] + own_r0);
+              for (int qq = 0; qq < 4; ++qq) part[gate][qq] = rp[((qq * 3 + gate) * UT) * 64 * 2];
+            // all twelve reads in flight before the first add (left alone, hipcc recycles registers and serialises the
+            // LDS round trips: read 2, wait, add, read 2, wait, ...)
+            asm volatile("" : "+v"(part[0][0]), "+v"(part[0][1]), "+v"(part[0][2]), "+v"(part[0][3]), "+v"(part[1][0]), "+v"(part[1][1]),
+                              "+v"(part[1][2]), "+v"(part[1][3]), "+v"(part[2][0]), "+v"(part[2][1]), "+v"(part[2][2]), "+v"(part[2][3]));
+            f32x2 gh[3];
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate) {
-              gh[gate][0] = (part[gate][0].x + part[gate][1].x) + (part[gate][2].x + part[gate][3].x);
-              gh[gate][1] = (part[gate][0].y + part[gate][1].y) + (part[gate][2].y + part[gate][3].y);
+            for (int gate = 0; gate < 3; ++gate) gh[gate] = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
+            if (sidx[ct] < na) {
+              const f32x2 one = {1.f, 1.f};
+              const f32x2 gr = {gir[ct][0][0], gir[ct][0][1]}, gz = {gir[ct][1][0], gir[ct][1][1]}, gn = {gir[ct][2][0], gir[ct][2][1]};
+              const f32x2 hp = {hreg[ct][0], hreg[ct][1]}, bh = {bhn[0], bhn[1]};
+              const f32x2 xr = gr + gh[0], xz = gz + gh[1];
+              f32x2 r, z, n;
+              r[0] = sigmoidf_(xr[0]); r[1] = sigmoidf_(xr[1]);
+              z[0] = sigmoidf_(xz[0]); z[1] = sigmoidf_(xz[1]);
+              const f32x2 ghn = gh[2] + bh;
+              const f32x2 xn = gn + r * ghn;
+              n[0] = tanhf_(xn[0]); n[1] = tanhf_(xn[1]);
+              const f32x2 hn = (one - z) * n + z * hp;
+              hreg[ct][0] = hn[0]; hreg[ct][1] = hn[1];
+              if constexpr (TRAIN) {
+                if (a.keep_r) {                                      // training: gate activations for BPTT
+                  const size_t ko = (size_t)(rbase + sidx[ct]) * HID + ucol;
+                  *(f32x2*)(a.keep_r + ko) = r; *(f32x2*)(a.keep_z + ko) = z;
+                  *(f32x2*)(a.keep_n + ko) = n; *(f32x2*)(a.keep_ghn + ko) = ghn;
+                }
+              }
             }
           } else {
+            float gh[3][OWN_R];
             float part[3][4];
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate)
@@ -345,18 +390,20 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
                 part[gate][qq] = *((const float*)&redw[((qq * 3 + gate) * UT + own_ut) * 64 + lane] + own_r0);
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) gh[gate][0] = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
-          }
-          if (sidx[ct] < na) {
+            if (sidx[ct] < na) {
 #pragma unroll
-            for (int e = 0; e < OWN_R; ++e) {
-              const float r = sigmoidf_(gir[ct][0][e] + gh[0][e]);
-              const float z = sigmoidf_(gir[ct][1][e] + gh[1][e]);
-              const float ghn = gh[2][e] + bhn[e];
-              const float n = tanhf_(gir[ct][2][e] + r * ghn);
-              hreg[ct][e] = (1.0f - z) * n + z * hreg[ct][e];
-              if (a.keep_r) {                                      // training: gate activations for BPTT
-                const size_t ko = (size_t)(rbase + sidx[ct]) * HID + ucol + e;
-                a.keep_r[ko] = r; a.keep_z[ko] = z; a.keep_n[ko] = n; a.keep_ghn[ko] = ghn;
+              for (int e = 0; e < OWN_R; ++e) {
+                const float r = sigmoidf_(gir[ct][0][e] + gh[0][e]);
+                const float z = sigmoidf_(gir[ct][1][e] + gh[1][e]);
+                const float ghn = gh[2][e] + bhn[e];
+                const float n = tanhf_(gir[ct][2][e] + r * ghn);
+                hreg[ct][e] = (1.0f - z) * n + z * hreg[ct][e];
+                if constexpr (TRAIN) {
+                  if (a.keep_r) {
+                    const size_t ko = (size_t)(rbase + sidx[ct]) * HID + ucol + e;
+                    a.keep_r[ko] = r; a.keep_z[ko] = z; a.keep_n[ko] = n; a.keep_ghn[ko] = ghn;
+                  }
+                }
               }
             }
           }
@@ -371,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           if (a.h_relu_out) {
             if constexpr (BF) {
               bf16_t* p = (bf16_t*)a.h_relu_out + o;
-              if constexpr (OWN_R == 2) *(unsigned*)p = pack_bf16x2(fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f));
+              if constexpr (OWN_R == 2) *(unsigned*)p = cvt_pk_bf16((f32x2){fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f)});
               else p[0] = f2bf(fmaxf(hreg[ct][0], 0.f));
             } else {
               float* p = (float*)a.h_relu_out + o;
@@ -379,9 +426,11 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               for (int e = 0; e < OWN_R; ++e) p[e] = fmaxf(hreg[ct][e], 0.f);
             }
           }
-          if (a.h_raw_out) {
+          if constexpr (TRAIN) {
+            if (a.h_raw_out) {
 #pragma unroll
-            for (int e = 0; e < OWN_R; ++e) a.h_raw_out[o + e] = hreg[ct][e];
+              for (int e = 0; e < OWN_R; ++e) a.h_raw_out[o + e] = hreg[ct][e];
+            }
           }
         }
         if (restart) {
@@ -398,6 +447,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     return true;
   };
   for (int tl = 0; tl < nsteps; tl += 2) {
+    if (tfirst[0] >= na_c) break;             // every slot of this group has ended: leave, free the CU
     if (!step(tl, giA, giB)) return;
     if (tl + 1 < nsteps && !step(tl + 1, giB, giA)) return;
   }
@@ -433,10 +483,12 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
   (void)hipMemsetAsync((char*)a.hx + buf_bytes, 0, buf_bytes, s);
   if (a.sync) (void)hipMemsetAsync(a.sync, 0, 16 * sizeof(unsigned), s);
   const int grid = a.G * P;
+  const bool train = a.keep_r != nullptr || a.h_raw_out != nullptr;
 #define LAUNCH(WT, UT, NCT)                                                                            \
   do {                                                                                                 \
     const size_t lds = (size_t)2 * 4 * 3 * UT * 64 * 16;                                               \
-    gru_recurrence_kernel<WT, 1024, UT, NCT><<<grid, 256, lds, s>>>(a);                                \
+    if (train) gru_recurrence_kernel<WT, 1024, UT, NCT, true><<<grid, 256, lds, s>>>(a);              \
+    else gru_recurrence_kernel<WT, 1024, UT, NCT, false><<<grid, 256, lds, s>>>(a);                    \
   } while (0)
   if (bf16) {
     if (nct == 1) LAUNCH(bf16_t, 2, 1);
