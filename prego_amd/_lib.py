@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprego_amd.so")
+LIB_PATH = os.environ.get("PREGO_AMD_LIB") or os.path.join(_HERE, "lib", "libprego_amd.so")   # override: A/B builds
 
 PREGO_F32, PREGO_BF16 = 0, 1
 FWD_SOFTMAX, FWD_KEEP = 1, 2

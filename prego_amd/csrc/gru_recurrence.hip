@@ -40,6 +40,9 @@
 #include "kernels.h"
 
 #define SPIN_LIMIT (1u << 22)
+#ifndef GRU_NSEG
+#define GRU_NSEG 4                           // segments of the gather validated and multiplied one after the other
+#endif
 #define GRU_MAX_TILES 8                      // clip tiles per group the exchange buffer is laid out for (128 slots)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -226,26 +229,29 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   cint_p rowoff_c = (cint_p)a.rowoff;
   const int nsteps = a.t1 - a.t0;
   // plan scalars one step ahead of their use (s_load latency off the critical path)
-  int na_c = nact_c[a.t0], rb_c = rowoff_c[a.t0] - a.row_base;         // step tl
-  int na_n = nsteps > 1 ? nact_c[a.t0 + 1] : 0, rb_n = nsteps > 1 ? rowoff_c[a.t0 + 1] - a.row_base : 0;   // step tl+1
+  // (rowoff is carried RAW and row_base subtracted where it is used: a subtraction next to the look-ahead s_load makes
+  // hipcc wait for that load at the top of every step)
+  int na_c = nact_c[a.t0], rb_c = rowoff_c[a.t0];                      // step tl
+  int na_n = nsteps > 1 ? nact_c[a.t0 + 1] : 0, rb_n = nsteps > 1 ? rowoff_c[a.t0 + 1] : 0;   // step tl+1
   // prologue: h_{t0-1} -> buffer 1 with the tag of step "-1" (= 1); gi of the first step
   float giA[NCT][3][OWN_R], giB[NCT][3][OWN_R];                         // ping-pong: no register copies
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
-    if (tfirst[ct] < na_c) { publish(ct, 1, 1u, false); load_gi(giA[ct], ct, na_c, rb_c); }
+    if (tfirst[ct] < na_c) { publish(ct, 1, 1u, false); load_gi(giA[ct], ct, na_c, rb_c - a.row_base); }
   int parity = 0;
 
   // one time step; gir = gi of this step (loaded a step ago), gin = where the next step's gi lands
   auto step = [&](const int tl, float (&gir)[NCT][3][OWN_R], float (&gin)[NCT][3][OWN_R]) -> bool {
     const int t = a.t0 + tl;
     const int na = na_c;
-    const int rbase = rb_c;
+    const int rbase = rb_c - a.row_base;
     const bool more = tl + 1 < nsteps;
     const int t2 = (tl + 2 < nsteps) ? t + 2 : t;                       // look-ahead index (clamped)
-    const int na_2 = nact_c[t2], rb_2 = rowoff_c[t2] - a.row_base;
+    const int na_2 = nact_c[t2], rb_2 = rowoff_c[t2];
     const int rbuf = (tl + 1) & 1;
     const unsigned etag = (unsigned)(((tl - 1) >> 1) & 1);              // tag of the step that produced h_{t-1}
     const unsigned eword = etag ? TAGM : 0u;
+    const unsigned untag = etag ? ~TAGM : 0xFFFFFFFFu;
     if (stamp) st_t = __builtin_amdgcn_s_memtime();
 
 #pragma unroll
@@ -257,66 +263,80 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         // per-fragment bookkeeping.  (Tracking stale fragments individually made hipcc carry the fragment registers
         // through the spin loop in AGPRs - 165 v_accvgpr moves and ~100 scalar branches per step - for a retry that
         // happens 0.3 times per step and costs one L2-served 8 KB re-read.)
-        u32x4 hb[NKS];
-        unsigned spins = 0;
-        for (;;) {
-          if (local && spins < 6u) {
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
-          } else {
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
-          }
-          unsigned bad;
-          if (etag) {                                   // every element must have the tag bit SET
-            unsigned all1 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) all1 &= hb[ks][0] & hb[ks][1] & hb[ks][2] & hb[ks][3];
-            bad = ~all1 & TAGM;
-          } else {                                      // every element must have it CLEAR
-            unsigned any1 = 0u;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) any1 |= hb[ks][0] | hb[ks][1] | hb[ks][2] | hb[ks][3];
-            bad = any1 & TAGM;
-          }
-          if (__all(bad == 0u)) break;
-          if (++spins > SPIN_LIMIT) {
-            if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-          }
-          if ((spins & 255u) == 0u) {
-            if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-          }
-        }
-        if (stamp) st_acc[5] += spins;
-        STAMP(0);
+        // The fragments are consumed in NSEG segments: segment s is validated and multiplied while the later segments are
+        // still on their way (loads retire in order: vmcnt counts down), so most of the gather's transfer - 32 KB per CU
+        // and step at 64 B/clk - runs under the MFMAs.  A stale segment (its producers are late) re-loads itself AND
+        // every later segment until it is valid; the summation order stays fixed (ks ascending) whatever happens.
+        constexpr int NSEG = GRU_NSEG, SEGK = NKS / NSEG;
         f32x4 acc[3][UT];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        u32x4 hb[NKS];
+        unsigned spins = 0;
+        if (local) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-          u32x4 v = hb[ks];
-          if (etag) { v[0] &= ~TAGM; v[1] &= ~TAGM; v[2] &= ~TAGM; v[3] &= ~TAGM; }
-          if constexpr (BF) {
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
+          for (int ks = 0; ks < NKS; ++ks)
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+        } else {
 #pragma unroll
-            for (int gate = 0; gate < 3; ++gate)
+          for (int ks = 0; ks < NKS; ++ks)
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+        }
 #pragma unroll
-              for (int ut = 0; ut < UT; ++ut)
-                acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut], 0, 0, 0);
-          } else {
+        for (int sg = 0; sg < NSEG; ++sg) {
+          auto seg_stale = [&]() -> bool {
+            unsigned badv = 0u;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const float bj = __uint_as_float(v[jj]);
+            for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks)
+              badv |= ((hb[ks][0] ^ eword) | (hb[ks][1] ^ eword)) | ((hb[ks][2] ^ eword) | (hb[ks][3] ^ eword));   // tag bit survives iff stale
+            return !__all((badv & TAGM) == 0u);
+          };
+          if (seg_stale()) {
+            for (;;) {
+              if (++spins > SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+              }
+              if ((spins & 255u) == 0u) {
+                if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+              }
+              if (local && spins < 6u) {
+#pragma unroll
+                for (int ks = sg * SEGK; ks < NKS; ++ks)
+                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+              } else {
+#pragma unroll
+                for (int ks = sg * SEGK; ks < NKS; ++ks)
+                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+              }
+              if (!seg_stale()) break;
+            }
+          }
+#pragma unroll
+          for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks) {
+            u32x4 v = hb[ks];
+            v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;     // scalar mask: one VALU per register
+            if constexpr (BF) {
+              const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
               for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut)
-                  acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gate][ut][ks][jj], bj, (ks == 0 && jj == 0) ? zero4 : acc[gate][ut], 0, 0, 0);
+                  acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const float bj = __uint_as_float(v[jj]);
+#pragma unroll
+                for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                  for (int ut = 0; ut < UT; ++ut)
+                    acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[gate][ut][ks][jj], bj, (ks == 0 && jj == 0) ? zero4 : acc[gate][ut], 0, 0, 0);
+              }
             }
           }
         }
+        if (stamp) st_acc[5] += spins;
+        STAMP(0);
         // (issuing the next tile's gather here, under this tile's reduction and gate phase, measured SLOWER: hipcc
         // answers the loop-carried loads with vmcnt(0) waits that drag the prefetch's latency into the gate phase;
         // it needs asm-issued loads with hand-counted waits - next round)
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
           for (int e = 0; e < OWN_R; ++e) asm volatile("" : "+v"(gir[ct][gate][e]));
-        if (more && tfirst[ct] < na_n) load_gi(gin[ct], ct, na_n, rb_n);
+        if (more && tfirst[ct] < na_n) load_gi(gin[ct], ct, na_n, rb_n - a.row_base);
 
         // ---- (2) cross-wave (K-quarter) reduction through LDS, double buffered: one barrier per tile
         f32x4* redw = red + parity * RED_STRIDE;
