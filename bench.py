@@ -150,7 +150,7 @@ def main():
             except Exception:
                 traffic = {}
         step_ms = dt / args.steps * 1e3
-        gemm_name = ("gemm_bf16_nt_256sq_kernel<7>" if args.dtype == "bf16" else "gemm_f32_nt_kernel") + " (layer1 + W_ih projections)"
+        gemm_name = ("gemm_bf16_nt_pingpong_kernel" if args.dtype == "bf16" else "gemm_f32_nt_kernel") + " (layer1 + W_ih projections)"
         rl_gemm = {"bound": "mfma", "kernel": gemm_name, "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s",
                    "frac": gemm_tflops / peak, "traffic": traffic.get("gemm_bytes_per_launch"),
                    "avg_launch_ms": kt["gemm_ms"] / n_l, "launches": kt["gemm_launches"], "ms_per_step": kt["gemm_ms"] / args.steps}

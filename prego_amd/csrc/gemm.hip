@@ -361,8 +361,10 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                          int N, int K, hipStream_t s) {
   static const bool no_big = getenv("PREGO_GEMM_NO_BIG") != nullptr;
-  if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles, two 64 KB stages, fragment reads one phase ahead, DMA pieces inside the first two phases (gemm_exp.hip variant 9)
-    launch_gemm_bf16_experimental(9, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+  if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles: ping-pong 8-phase schedule with 16-byte stores (gemm_pp.hip)
+    static const bool no_pp = getenv("PREGO_GEMM_NO_PINGPONG") != nullptr;      // A/B knob: the previous production kernel
+    if (no_pp || launch_gemm_bf16_pingpong(A, lda, B, ldb, bias, C, ldc, M, N, K, s) != 0)
+      launch_gemm_bf16_experimental(9, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
     return;
   }
   if (M >= 2048 && !no_big) {            // enough 256-row tiles to fill the chip
