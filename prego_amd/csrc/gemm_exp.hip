@@ -410,8 +410,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_k32_kernel(
 void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
                                    int ldc, int M, int N, int K, hipStream_t s) {
   const int ntm = (M + XBM - 1) / XBM, ntn = N / XBN;
-  if (variant == 12) {
-    (void)launch_gemm_bf16_pingpong(A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+  if (variant >= 12 && variant <= 15) {            // 12 = per-tile, 13 = persistent, 14 / 15 = their timing-only no-store builds
+    (void)launch_gemm_bf16_pingpong_mode(variant - 11, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
   } else if (variant == 2 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
     gemm_bf16_nt_256sq_kernel<0><<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);

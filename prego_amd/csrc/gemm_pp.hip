@@ -24,6 +24,8 @@
 // later group's lgkmcnt(0) has retired those reads too.
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
+#include <cstdio>
 
 #define PBM 256
 #define PBN 256
@@ -36,43 +38,72 @@ __device__ __forceinline__ int pp_xcd_remap(int bid, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+#ifdef PP_DIAG
+__device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle sums over workgroups (wave 0)
+#endif
 #define PP_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// PERSIST: one workgroup per CU walks the tile list (stride gridDim.x, a multiple of 8 so that a workgroup's XCD label
+// stays put); the next tile's first seven half-tiles are put in flight BEFORE the finished tile's C stores, and the stores
+// are left in flight (counted vmcnt) while the next tile's K loop starts: neither the prologue's DMA latency nor the store
+// tail of a tile idles the matrix pipe.
+template <bool PERSIST, bool NOSTORE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int skew) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1]
+  if constexpr (PERSIST) {
+    // De-synchronise the CUs once (skew = s_sleep(127) units per eighth of a tile time; 0 = off): workgroups that start
+    // together reach their C stores together, 64 MB at once, and the HBM write burst stalls every CU's next tile
+    if (skew > 0) {
+      const int phase = (blockIdx.x >> 3) & 7;
+      for (int i = 0; i < phase * skew; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;                     // group (= M position wr), N position
   const int ntn = N / PBN;
   const int ntm = (M + PBM - 1) / PBM;
-  const int tile = pp_xcd_remap(blockIdx.x, ntm * ntn);
-  const int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
+  const int ntiles = ntm * ntn;
   const int nk = K / PBK;
+  int idx = blockIdx.x;
+  int tile = pp_xcd_remap(idx, ntiles);
+  int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
 
-  // ---- LDS-DMA sources: this lane's two pieces (8 rows x 128 B) of every half-tile -----------------------------------
+  // ---- LDS-DMA sources: this lane's two pieces (8 rows x 128 B) of every half-tile.  One buffer resource per operand and
+  // tile (base = the tile's first row, num_records = its valid rows: rows past M read as zeros, no clamp), a 32-bit lane
+  // offset per piece, and the half-tile / K-tile displacement in the scalar offset: 4 VGPRs of addressing in all
   const int sr = lane >> 3, scp = lane & 7;
-  const bf16_t* a_src[2][2];       // [half][piece]
-  const bf16_t* b_src[2][2];
+  int a_off[2], b_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + sr;                      // row inside the half-tile, 0..127
     const int c = scp ^ ((r >> 1) & 7);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      int ar = m0 + hf * 128 + r; if (ar > M - 1) ar = M - 1;
-      a_src[hf][i] = A + (size_t)ar * lda + c * 8;
-      b_src[hf][i] = B + (size_t)(n0 + hf * 128 + r) * ldb + c * 8;
-    }
+    a_off[i] = r * lda * 2 + c * 16;
+    b_off[i] = r * ldb * 2 + c * 16;
   }
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  auto set_sources = [&](int tm0, int tn0) {
+    const int rows = M - tm0 < PBM ? M - tm0 : PBM;
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)tm0 * lda), 0, rows * lda * 2, 0x00020000);
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)tn0 * ldb), 0, PBN * ldb * 2, 0x00020000);
+  };
+  set_sources(m0, n0);
   // slot X of buffer b: A0 = 0, A1 = 1, B0 = 2, B1 = 3
-  auto stage = [&](const bf16_t* const (&src)[2], int slot, int kt) {
-    char* dst = smem + (kt & 1) * PBUF + slot * PHALF + wave * 2048;
+  auto stage_a = [&](int hf, int kt) {
+    char* dst = smem + (kt & 1) * PBUF + hf * PHALF + wave * 2048;
+    const int so = hf * 128 * lda * 2 + kt * (PBK * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * PBK),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, a_off[i], so, 0, 0);
+  };
+  auto stage_b = [&](int hf, int kt) {
+    char* dst = smem + (kt & 1) * PBUF + (2 + hf) * PHALF + wave * 2048;
+    const int so = hf * 128 * ldb * 2 + kt * (PBK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, b_off[i], so, 0, 0);
   };
 
   // ---- fragments ------------------------------------------------------------------------------------------------------
@@ -127,71 +158,194 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   };
 
   // ---- prologue: the stream up to (not including) phase 1 of tile 0's issue ------------------------------------------
-  stage(a_src[0], 0, 0); stage(b_src[0], 2, 0); stage(b_src[1], 3, 0); stage(a_src[1], 1, 0);     // A0 B0 B1 A1 of tile 0
-  if (nk > 1) { stage(a_src[0], 0, 1); stage(b_src[0], 2, 1); stage(b_src[1], 3, 1); PP_WAIT(10); }   // A0 B0 B1 of tile 1
-  else PP_WAIT(0);
+  auto prologue = [&]() {
+    stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);     // A0 B0 B1 A1 of K tile 0
+    stage_a(0, 1); stage_b(0, 1); stage_b(1, 1);                            // A0 B0 B1 of K tile 1 (nk >= 2)
+  };
+  prologue();
+  PP_WAIT(10);
+  bool carry = false;        // PERSIST: the previous tile's 32 stores sit between the prologue's DMA and this tile's issues
+  for (;;) {
   bar();
   read_a(a0, 0, 0);
   if (grp == 1) bar();                                           // group 1 runs one barrier behind
+#ifdef PP_DIAG
+  const unsigned long long t_loop0 = __builtin_amdgcn_s_memtime();
+  unsigned long long dacc[5] = {0, 0, 0, 0, 0}, dt = t_loop0;
+#define DS(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dacc[i] += n_ - dt; dt = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DS(i) do { } while (0)
+#endif
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool full = kt + 2 < nk;                               // every issue of this tile's phases is real
+    // the first five waits of a tile that follows another: the half-tile waited for is older than the previous tile's 32
+    // stores, the five younger half-tiles are not: 10 + 32 (vmcnt counts loads and stores together, in issue order)
+    const bool c0 = PERSIST && carry && kt == 0 && full, c1 = PERSIST && carry && kt == 1 && full;
     // phase 1
     read_b(b0, 2, kt);
-    if (kt + 1 < nk) stage(a_src[1], 1, kt + 1);
-    if (full) PP_WAIT(10); else PP_WAIT(0);
+    if (kt + 1 < nk) stage_a(1, kt + 1);
+    if (c0 || c1) PP_WAIT(42); else if (full) PP_WAIT(10); else PP_WAIT(0);
     bar();
     mma(acc[0][0], a0, b0);
     bar();
     // phase 2
     read_b(b1, 3, kt);
-    if (full) { stage(a_src[0], 0, kt + 2); PP_WAIT(10); } else PP_WAIT(0);
+    if (full) { stage_a(0, kt + 2); if (c0) PP_WAIT(42); else PP_WAIT(10); } else PP_WAIT(0);
     bar();
     mma(acc[0][1], a0, b1);
     bar();
     // phase 3
+    DS(4);
     read_a(a1, 1, kt);
-    if (full) { stage(b_src[0], 2, kt + 2); PP_WAIT(10); } else PP_WAIT(0);
+    if (full) { stage_b(0, kt + 2); DS(0); if (c0) PP_WAIT(42); else PP_WAIT(10); } else { DS(0); PP_WAIT(0); }
+    DS(1);
     bar();
+    DS(2);
     mma(acc[1][1], a1, b1);
+    DS(3);
     bar();
+    DS(2);
     // phase 4
     if (kt + 1 < nk) read_a(a0, 0, kt + 1);
-    if (full) { stage(b_src[1], 3, kt + 2); PP_WAIT(10); } else PP_WAIT(0);
+    if (full) { stage_b(1, kt + 2); if (c0) PP_WAIT(42); else PP_WAIT(10); } else PP_WAIT(0);
     bar();
     mma(acc[1][0], a1, b0);
     bar();
   }
-  if (grp == 0) bar();                                           // pairs with group 1's last barrier
+  if (grp == 0) bar();                                           // pairs with group 1's last barrier: every LDS read of this tile has retired
 
+  // ---- next tile's prologue in flight before this tile's stores -------------------------------------------------------
+  const int cm0 = m0, cn0 = n0;
+  bool has_next = false;
+  if constexpr (PERSIST) {
+    idx += gridDim.x;
+    has_next = idx < ntiles;
+    if (has_next) {
+      tile = pp_xcd_remap(idx, ntiles);
+      m0 = (tile / ntn) * PBM; n0 = (tile % ntn) * PBN;
+      set_sources(m0, n0);
+    }
+  }
+  float4 bv[2][2];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[y][j] = *(const float4*)(bias + cn0 + y * 128 + wc * 32 + j * 16 + fq * 4);
+  // the bias has to be IN before the next tile's DMA is issued: behind it, hipcc could only wait for it with vmcnt(0),
+  // which would drain that DMA too (an L2-hot 16-byte load: a few hundred cycles per tile, once)
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bv[y][j].x), "+v"(bv[y][j].y), "+v"(bv[y][j].z), "+v"(bv[y][j].w));
+  if (has_next) prologue();
   // ---- epilogue: the products were taken as (B-fragment) x (A-fragment), i.e. transposed 16x16 tiles, so a lane holds FOUR
   // CONSECUTIVE COLUMNS of one row of C: 16-byte stores (4x fewer store instructions than the row-major accumulator
   // layout's dword stores; the store tail of a tile is issue-bound)
+#ifdef PP_DIAG
+  const unsigned long long t_epi0 = __builtin_amdgcn_s_memtime();
+#endif
+  const bool whole = cm0 + PBM <= M;                             // wave-uniform: all 32 stores of this wave are issued
+  if (whole) {
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y)
+      for (int y = 0; y < 2; ++y)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + y * 128 + wc * 32 + j * 16 + fq * 4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *(const float4*)(bias + n);
+        for (int j = 0; j < 2; ++j) {
+          const int n = cn0 + y * 128 + wc * 32 + j * 16 + fq * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = m0 + x * 128 + grp * 64 + i * 16 + fr;
-          if (m < M) {
-            const f32x4 v = acc[x][y][i][j];
-            *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w);
+          for (int i = 0; i < 4; ++i) {
+            const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
+            f32x4 v = acc[x][y][i][j];
+            if constexpr (NOSTORE) {      // TIMING-ONLY build (wrong results): prices the store tail
+              asm volatile("" :: "v"(v), "v"(m), "v"(n), "v"(bv[y][j].x));
+            } else {
+              *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+            }
+            acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
-      }
+  } else {
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = cn0 + y * 128 + wc * 32 + j * 16 + fq * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
+            const f32x4 v = acc[x][y][i][j];
+            if (m < M) *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+            acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+  }
+#ifdef PP_DIAG
+  if (wave == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+      atomicAdd(&g_pp_diag[0], t1 - t_epi0);      // store issue
+      atomicAdd(&g_pp_diag[1], t2 - t1);          // drain after the last store was issued
+      atomicAdd(&g_pp_diag[2], t_epi0 - t_loop0); // K loop
+      atomicAdd(&g_pp_diag[3], 1ull);
+      atomicAdd(&g_pp_diag[4], dacc[0]); atomicAdd(&g_pp_diag[5], dacc[1]); atomicAdd(&g_pp_diag[6], dacc[2]); atomicAdd(&g_pp_diag[7], dacc[3]);
+    }
+  }
+#endif
+  if (!has_next) break;
+  // first two half-tiles of the next tile: everything but the 5 youngest half-tiles (10 DMA) and this tile's 32 stores
+  if (whole && !NOSTORE) { PP_WAIT(42); carry = true; } else if (whole) { PP_WAIT(10); carry = false; } else { PP_WAIT(0); carry = false; }
+  }
 }
 
+// mode: 0 = production choice, 1 = one workgroup per tile, 2 = persistent, 3 / 4 = timing-only builds of 1 / 2 without the C stores
+int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
+                                   int M, int N, int K, hipStream_t s) {
+  if (N % PBN || K % PBK || K < 2 * PBK || bias == nullptr) return -1;
+  const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0; hipDeviceProp_t pr;
+    (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
+    n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+  }
+  const int grid = (n_cu / 8) * 8;                               // 128 KB of LDS: one workgroup per CU
+  static const int skew_env = getenv("PREGO_GEMM_SKEW") ? atoi(getenv("PREGO_GEMM_SKEW")) : 0;
+  // one tile is about (K / 64) * 3400 cycles; s_sleep(127) is 64 * 127 cycles
+  const int skew = skew_env > 0 ? (int)((long long)(K / PBK) * 3400 * skew_env / 100 / 8 / 8128) : 0;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+  if (mode == 0) mode = 2;
+  if (mode == 2 && ntiles <= grid) mode = 1;
+  if (mode == 4 && ntiles <= grid) mode = 3;
+  if (mode == 1) gemm_bf16_nt_pingpong_kernel<false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else if (mode == 2) gemm_bf16_nt_pingpong_kernel<true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else if (mode == 3) gemm_bf16_nt_pingpong_kernel<false, true><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else gemm_bf16_nt_pingpong_kernel<true, true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  return 0;
+}
+#ifdef PP_DIAG
+void pp_diag_print() {
+  unsigned long long h[8];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_diag), sizeof h);
+  if (h[3]) printf("pp diag per tile (wave 0, cycles): K loop %.0f, store issue %.0f, drain after last issue %.0f (tiles %llu)\n",
+                   (double)h[2] / h[3], (double)h[0] / h[3], (double)h[1] / h[3], h[3]);
+  if (h[3]) printf("   phase 3 per tile: reads+DMA issue %.0f, vmcnt wait %.0f, two barriers %.0f, 16 MFMA %.0f\n", (double)h[4] / h[3], (double)h[5] / h[3],
+                   (double)h[6] / h[3], (double)h[7] / h[3]);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_diag), z, sizeof z);
+}
+#endif
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s) {
-  if (N % PBN || K % PBK || K < 2 * PBK) return -1;
-  const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN;
-  (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-  gemm_bf16_nt_pingpong_kernel<<<ntm * ntn, 512, 2 * PBUF, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
-  return 0;
+  return launch_gemm_bf16_pingpong_mode(0, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
 }
