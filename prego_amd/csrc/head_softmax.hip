@@ -28,6 +28,38 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
 #pragma unroll
   for (int m = 0; m < HM; ++m) { arow[m] = rbase + m * 16 + l15; if (arow[m] > nrows - 1) arow[m] = nrows - 1; }
 
+  // ---- where do this wave's 64 rows go?  ONE plan lookup per row, all 64 in parallel (lane L looks up row rbase + L), issued
+  // before the K loop: a binary search per row inside the epilogue (16 in a row per lane, ~15 dependent L2 loads each) was
+  // 2/3 of this kernel's time.  The wave's first row is located on the scalar path, the lanes search the <= 64 steps behind it.
+  __shared__ unsigned long long s_out[4][64], s_arg[4][64];
+  {
+    typedef const __attribute__((address_space(4))) int* cint_p;
+    cint_p ro_c = (cint_p)plan.rowoff;
+    int lo = 0, hi = plan.s_max;                 // wave-uniform: rowoff[lo] <= first row < rowoff[hi]
+    const int first = __builtin_amdgcn_readfirstlane(row0 + rbase);
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (ro_c[mid] <= first) lo = mid; else hi = mid;
+    }
+    int myrow = rbase + lane; if (myrow > nrows - 1) myrow = nrows - 1;
+    myrow += row0;
+    int a = lo, b = lo + 64 < plan.s_max ? lo + 64 : plan.s_max;     // 64 rows span at most 64 steps
+    if (plan.rowoff[b] <= myrow) { a = b; b = plan.s_max; }          // (only when a step has < 1 row: never; kept for safety)
+    while (b - a > 1) {
+      const int mid = (a + b) >> 1;
+      if (plan.rowoff[mid] <= myrow) a = mid; else b = mid;
+    }
+    const int slot = myrow - plan.rowoff[a];
+    int k = plan.seg_off[slot];
+    const int kend = plan.seg_off[slot + 1];
+    while (k + 1 < kend && plan.seg_start[k + 1] <= a) ++k;
+    const int clip = plan.seg_clip[k], t = a - plan.seg_start[k];
+    float* op = out_ptrs ? out_ptrs[clip] : nullptr;
+    int* ap = argmax_ptrs ? argmax_ptrs[clip] : nullptr;
+    s_out[wave][lane] = op ? (unsigned long long)(op + (size_t)t * C) : 0ull;
+    s_arg[wave][lane] = ap ? (unsigned long long)(ap + t) : 0ull;
+  }
+
   f32x4 acc[HM][NTC];
 #pragma unroll
   for (int m = 0; m < HM; ++m)
@@ -102,23 +134,19 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
 #pragma unroll
       for (int j = 0; j < NTC; ++j) v[j] *= inv;
     }
-    const int r = rbase + m * 16 + l4 * 4 + e;
-    if (r < nrows) {
-      const int row = row0 + r;
-      int clip, t;
-      plan_clip_of_row(plan, row, clip, t);
-      float* op = out_ptrs ? out_ptrs[clip] : nullptr;
+    const int rr = m * 16 + l4 * 4 + e;            // row inside the wave's tile: its destinations were looked up by lane rr
+    if (rbase + rr < nrows) {
+      float* op = (float*)s_out[wave][rr];
       if (op) {
-        op += (size_t)t * C;
 #pragma unroll
         for (int j = 0; j < NTC; ++j) {
           const int c = j * 16 + l15;
           if (c < C) op[c] = v[j];
         }
       }
-      if (argmax_ptrs && l15 == 0) {
-        int* aptr = argmax_ptrs[clip];
-        if (aptr) aptr[t] = mi;
+      if (l15 == 0) {
+        int* aptr = (int*)s_arg[wave][rr];
+        if (aptr) *aptr = mi;
       }
     }
   }

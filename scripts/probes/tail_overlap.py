@@ -12,6 +12,8 @@ sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
 model = build_model(cfg, dev); model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); model.eval()
 eng = model.engine(); lib = _lib.load()
 ncl = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+ng = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 T = 20000
 rgb = [torch.randn((T, 2048), device=dev).clamp_(min=0) for _ in range(ncl)]
 M, N, K = 65536, 2048, 4096
@@ -23,11 +25,13 @@ def fwd():
         eng.forward_ragged(rgb, None, softmax=True, want_out=True, want_argmax=True)
 def gemms(n):
     for _ in range(n):
-        lib.prego_debug_gemm_bf16(9, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(bias.data_ptr()),
+        lib.prego_debug_gemm_bf16(variant, C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(bias.data_ptr()),
                                   C.c_void_p(Cm.data_ptr()), M, N, K, C.c_void_p(sB.cuda_stream))
 def wall(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); return (time.perf_counter() - t0) * 1e3
 fwd(); gemms(3); torch.cuda.synchronize(); eng.check()
 for rnd in range(2):
-    a = wall(fwd); b = wall(lambda: gemms(40)); c = wall(lambda: (fwd(), gemms(40))); eng.check()
-    print(f"{ncl} clip(s) x {T}: pass alone {a:.1f} ms, 40 gemms alone {b:.1f} ms, together {c:.1f} ms")
+    eng.timing_enable(True); a = wall(fwd); k1 = eng.timing_read()
+    b = wall(lambda: gemms(ng)); eng.timing_read()
+    c = wall(lambda: (fwd(), gemms(ng))); k2 = eng.timing_read(); eng.timing_enable(False); eng.check()
+    print(f"{ncl} clip(s) x {T}: pass alone {a:.1f} ms, {ng} gemms (variant {variant}) alone {b:.1f} ms, together {c:.1f} ms; recurrence {k1['gru_ms']:.1f} -> {k2['gru_ms']:.1f} ms")
