@@ -410,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_k32_kernel(
 void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
                                    int ldc, int M, int N, int K, hipStream_t s) {
   const int ntm = (M + XBM - 1) / XBM, ntn = N / XBN;
-  if (variant >= 12 && variant <= 15) {            // 12 = per-tile, 13 = persistent, 14 / 15 = their timing-only no-store builds
+  if (variant >= 12 && variant <= 16) {            // 12 = per-tile, 13 = persistent, 14 / 15 = their timing-only no-store builds, 16 = persistent + whole-line stores
     (void)launch_gemm_bf16_pingpong_mode(variant - 11, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
   } else if (variant == 2 && N % 256 == 0) {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);

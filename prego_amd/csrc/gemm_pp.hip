@@ -47,7 +47,7 @@ __device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle
 // stays put); the next tile's first seven half-tiles are put in flight BEFORE the finished tile's C stores, and the stores
 // are left in flight (counted vmcnt) while the next tile's K loop starts: neither the prologue's DMA latency nor the store
 // tail of a tile idles the matrix pipe.
-template <bool PERSIST, bool NOSTORE>
+template <bool PERSIST, bool NOSTORE, bool FULLLINE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
     float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int skew) {
@@ -247,6 +247,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #endif
   const bool whole = cm0 + PBM <= M;                             // wave-uniform: all 32 stores of this wave are issued
   if (whole) {
+    if constexpr (FULLLINE) {
+      // Whole 128-byte lines per row and store instruction: a row's 32 columns of this wave sit in two registers sets (j = 0, 1)
+      // of four lanes each; lanes fr and fr ^ 8 swap one of them (DPP row_ror:8) so that a store instruction covers 8 rows x
+      // 128 B instead of 16 rows x 64 B (half the requests per instruction).
+      const bool low = fr < 8;
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+          const int n = cn0 + y * 128 + wc * 32 + (low ? 0 : 16) + fq * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = cm0 + x * 128 + grp * 64 + i * 16 + (fr & 7);
+            f32x4 j0 = acc[x][y][i][0], j1 = acc[x][y][i][1];
+            j0[0] += bv[y][0].x; j0[1] += bv[y][0].y; j0[2] += bv[y][0].z; j0[3] += bv[y][0].w;
+            j1[0] += bv[y][1].x; j1[1] += bv[y][1].y; j1[2] += bv[y][1].z; j1[3] += bv[y][1].w;
+            f32x4 da, db;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float send = low ? j1[e] : j0[e];
+              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
+              da[e] = low ? j0[e] : recv;
+              db[e] = low ? recv : j1[e];
+            }
+            *(float4*)(C + (size_t)m * ldc + n) = make_float4(da[0], da[1], da[2], da[3]);
+            *(float4*)(C + (size_t)(m + 8) * ldc + n) = make_float4(db[0], db[1], db[2], db[3]);
+            acc[x][y][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[x][y][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        }
+    } else {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -261,11 +292,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
             if constexpr (NOSTORE) {      // TIMING-ONLY build (wrong results): prices the store tail
               asm volatile("" :: "v"(v), "v"(m), "v"(n), "v"(bv[y][j].x));
             } else {
+#ifdef PP_NT
+              __builtin_nontemporal_store((f32x4){v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w}, (f32x4*)(C + (size_t)m * ldc + n));
+#else
               *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+#endif
             }
             acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
+    }
   } else {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -303,7 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   }
 }
 
-// mode: 0 = production choice, 1 = one workgroup per tile, 2 = persistent, 3 / 4 = timing-only builds of 1 / 2 without the C stores
+// mode: 0 = production choice, 1 = one workgroup per tile, 2 = persistent, 3 / 4 = timing-only builds of 1 / 2 without the C stores,
+// 5 = persistent with whole-line stores (DPP lane exchange)
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
                                    int M, int N, int K, hipStream_t s) {
   if (N % PBN || K % PBK || K < 2 * PBK || bias == nullptr) return -1;
@@ -313,10 +350,10 @@ int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void*
     int dev = 0; hipDeviceProp_t pr;
     (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
     n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
   }
   const int grid = (n_cu / 8) * 8;                               // 128 KB of LDS: one workgroup per CU
   static const int skew_env = getenv("PREGO_GEMM_SKEW") ? atoi(getenv("PREGO_GEMM_SKEW")) : 0;
@@ -326,10 +363,15 @@ int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void*
   if (mode == 0) mode = 2;
   if (mode == 2 && ntiles <= grid) mode = 1;
   if (mode == 4 && ntiles <= grid) mode = 3;
-  if (mode == 1) gemm_bf16_nt_pingpong_kernel<false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else if (mode == 2) gemm_bf16_nt_pingpong_kernel<true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else if (mode == 3) gemm_bf16_nt_pingpong_kernel<false, true><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else gemm_bf16_nt_pingpong_kernel<true, true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  if (mode == 1) gemm_bf16_nt_pingpong_kernel<false, false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else if (mode == 2) gemm_bf16_nt_pingpong_kernel<true, false, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else if (mode == 3) gemm_bf16_nt_pingpong_kernel<false, true, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  else if (mode == 5) {
+    static bool attr5 = false;
+    if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF); attr5 = true; }
+    gemm_bf16_nt_pingpong_kernel<true, false, true><<<ntiles < grid ? ntiles : grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  }
+  else gemm_bf16_nt_pingpong_kernel<true, true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
   return 0;
 }
 #ifdef PP_DIAG

@@ -51,7 +51,8 @@ class MiniRoadEngine:
         self.h = h
         self.max_clips = self.lib.prego_miniroad_max_clips(self.h)
         self._ws: Optional[torch.Tensor] = None
-        self.rows_per_chunk = 65536
+        self.rows_per_chunk = 49152      # packed rows per chunk: 192 M tiles = whole rounds of 256x256 tiles on 256 CUs for N = 2048 (6) and 3072 (9);
+                                         # X + GI of a chunk (1 GB) stay close to the 256 MB Infinity Cache (sweep 32 k..256 k rows: 137..142 ms)
         self._weights_version = None
 
     def __del__(self):
