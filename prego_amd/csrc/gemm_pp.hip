@@ -141,7 +141,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&af)[2][4], const bf16x8 (&bf)[2][2]) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+#ifndef PP_PRIO
+#define PP_PRIO 1
+#endif
+    __builtin_amdgcn_s_setprio(PP_PRIO);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
