@@ -163,7 +163,7 @@ int prego_attention_layer_forward(int batch, int len, int d_model, int heads, in
                                   prego_stream_t stream);
 
 /* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
- * recurrence kernel: out8[0..4] = gather + mfma (one phase since the segmented gather), unused, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
+ * recurrence kernel: out8[0..4] = rest of gather + mfma, step top -> first gather segment valid, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
  * [6] = time steps.  Synchronises the device. */
 int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
 

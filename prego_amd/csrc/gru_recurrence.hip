@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               if (!seg_stale()) break;
             }
           }
+          if (sg == 0) STAMP(1);                   // stamps only: top of step -> first segment valid (the hand-off latency)
 #pragma unroll
           for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks) {
             u32x4 v = hb[ks];
@@ -340,7 +341,6 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         // (issuing the next tile's gather here, under this tile's reduction and gate phase, measured SLOWER: hipcc
         // answers the loop-carried loads with vmcnt(0) waits that drag the prefetch's latency into the gate phase;
         // it needs asm-issued loads with hand-counted waits - next round)
-        STAMP(1);
         // ---- (1b) the gather's vmcnt(0) has just retired every older vector-memory op, including the loads of this
         // step's gi (issued one step ago).  Pin that fact for the compiler (it would otherwise put a vmcnt(0) in front
         // of the first use of the loop-carried registers, i.e. behind the prefetch issued next), then prefetch gi(t+1)

@@ -22,7 +22,7 @@ for n in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "8,128,182,400"
     eng.timing_enable(True); eng.forward_ragged(rgb, None); kt = eng.timing_read(); eng.timing_enable(False)
     eng.lib.prego_miniroad_debug_stamps(eng.h, out)
     steps = out[6]
-    names = ["gather+mfma", "(unused)", "reduce+barrier", "gates+publish", "outputs"]
+    names = ["rest of gather + mfma", "step top -> first segment valid", "reduce+barrier", "gates+publish", "outputs"]
     tot = sum(out[i] for i in range(5))
     print(f"clips={n} {dtype}: kernel {kt['gru_ms']*1e3/steps:.2f} us/step (events); wave0 cycles/step total {tot/steps:.0f}: " +
           ", ".join(f"{names[i]} {out[i]/steps:.0f}" for i in range(5)) + f"; retry rounds/step {out[5]/steps:.2f}")
