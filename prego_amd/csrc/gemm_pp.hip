@@ -43,23 +43,17 @@ __device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle
 #endif
 #define PP_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// PERSIST: one workgroup per CU walks the tile list (stride gridDim.x, a multiple of 8 so that a workgroup's XCD label
-// stays put); the next tile's first seven half-tiles are put in flight BEFORE the finished tile's C stores, and the stores
-// are left in flight (counted vmcnt) while the next tile's K loop starts: neither the prologue's DMA latency nor the store
-// tail of a tile idles the matrix pipe.
-template <bool PERSIST, bool NOSTORE, bool FULLLINE>
+// PERSIST (variant 13 of the measurement hook; NOT the production form): one workgroup per CU walks the tile list (stride
+// gridDim.x, a multiple of 8 so that a workgroup's XCD label stays put); the next tile's first seven half-tiles are put in
+// flight BEFORE the finished tile's C stores, and the stores are left in flight (counted vmcnt) while the next tile's K loop
+// starts.  Measured against one workgroup per tile: -4 % at K = 2048, +-1 % at K = 4096 - a wave cannot use a load that is
+// younger than its own stores (one in-order vmcnt for both), so only the first five phases of the next tile overlap the
+// store tail, and the extra control flow in the K loop costs as much.
+template <bool PERSIST>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int skew) {
+    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1]
-  if constexpr (PERSIST) {
-    // De-synchronise the CUs once (skew = s_sleep(127) units per eighth of a tile time; 0 = off): workgroups that start
-    // together reach their C stores together, 64 MB at once, and the HBM write burst stalls every CU's next tile
-    if (skew > 0) {
-      const int phase = (blockIdx.x >> 3) & 7;
-      for (int i = 0; i < phase * skew; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;                     // group (= M position wr), N position
@@ -250,37 +244,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #endif
   const bool whole = cm0 + PBM <= M;                             // wave-uniform: all 32 stores of this wave are issued
   if (whole) {
-    if constexpr (FULLLINE) {
-      // Whole 128-byte lines per row and store instruction: a row's 32 columns of this wave sit in two registers sets (j = 0, 1)
-      // of four lanes each; lanes fr and fr ^ 8 swap one of them (DPP row_ror:8) so that a store instruction covers 8 rows x
-      // 128 B instead of 16 rows x 64 B (half the requests per instruction).
-      const bool low = fr < 8;
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y) {
-          const int n = cn0 + y * 128 + wc * 32 + (low ? 0 : 16) + fq * 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = cm0 + x * 128 + grp * 64 + i * 16 + (fr & 7);
-            f32x4 j0 = acc[x][y][i][0], j1 = acc[x][y][i][1];
-            j0[0] += bv[y][0].x; j0[1] += bv[y][0].y; j0[2] += bv[y][0].z; j0[3] += bv[y][0].w;
-            j1[0] += bv[y][1].x; j1[1] += bv[y][1].y; j1[2] += bv[y][1].z; j1[3] += bv[y][1].w;
-            f32x4 da, db;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float send = low ? j1[e] : j0[e];
-              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0x128, 0xf, 0xf, false));
-              da[e] = low ? j0[e] : recv;
-              db[e] = low ? recv : j1[e];
-            }
-            *(float4*)(C + (size_t)m * ldc + n) = make_float4(da[0], da[1], da[2], da[3]);
-            *(float4*)(C + (size_t)(m + 8) * ldc + n) = make_float4(db[0], db[1], db[2], db[3]);
-            acc[x][y][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[x][y][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-        }
-    } else {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -291,20 +254,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
-            f32x4 v = acc[x][y][i][j];
-            if constexpr (NOSTORE) {      // TIMING-ONLY build (wrong results): prices the store tail
-              asm volatile("" :: "v"(v), "v"(m), "v"(n), "v"(bv[y][j].x));
-            } else {
-#ifdef PP_NT
-              __builtin_nontemporal_store((f32x4){v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w}, (f32x4*)(C + (size_t)m * ldc + n));
-#else
-              *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
-#endif
-            }
+            const f32x4 v = acc[x][y][i][j];
+            *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
             acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
-    }
   } else {
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -338,12 +292,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #endif
   if (!has_next) break;
   // first two half-tiles of the next tile: everything but the 5 youngest half-tiles (10 DMA) and this tile's 32 stores
-  if (whole && !NOSTORE) { PP_WAIT(42); carry = true; } else if (whole) { PP_WAIT(10); carry = false; } else { PP_WAIT(0); carry = false; }
+  if (whole) { PP_WAIT(42); carry = true; } else { PP_WAIT(0); carry = false; }
   }
 }
 
-// mode: 0 = production choice, 1 = one workgroup per tile, 2 = persistent, 3 / 4 = timing-only builds of 1 / 2 without the C stores,
-// 5 = persistent with whole-line stores (DPP lane exchange)
+// mode: 0 / 1 = one workgroup per tile (production: 1.14 vs 1.10 PFLOP/s at K = 2048, equal at K = 4096), 2 = persistent tile loop
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
                                    int M, int N, int K, hipStream_t s) {
   if (N % PBN || K % PBK || K < 2 * PBK || bias == nullptr) return -1;
@@ -353,43 +306,15 @@ int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void*
     int dev = 0; hipDeviceProp_t pr;
     (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
     n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
   }
   const int grid = (n_cu / 8) * 8;                               // 128 KB of LDS: one workgroup per CU
-  static const int skew_env = getenv("PREGO_GEMM_SKEW") ? atoi(getenv("PREGO_GEMM_SKEW")) : 0;
-  // one tile is about (K / 64) * 3400 cycles; s_sleep(127) is 64 * 127 cycles
-  const int skew = skew_env > 0 ? (int)((long long)(K / PBK) * 3400 * skew_env / 100 / 8 / 8128) : 0;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (mode == 0) mode = 2;
-  if (mode == 2 && ntiles <= grid) mode = 1;
-  if (mode == 4 && ntiles <= grid) mode = 3;
-  if (mode == 1) gemm_bf16_nt_pingpong_kernel<false, false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else if (mode == 2) gemm_bf16_nt_pingpong_kernel<true, false, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else if (mode == 3) gemm_bf16_nt_pingpong_kernel<false, true, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  else if (mode == 5) {
-    static bool attr5 = false;
-    if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF); attr5 = true; }
-    gemm_bf16_nt_pingpong_kernel<true, false, true><<<ntiles < grid ? ntiles : grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
-  }
-  else gemm_bf16_nt_pingpong_kernel<true, true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, skew);
+  if (mode == 2 && ntiles > grid) gemm_bf16_nt_pingpong_kernel<true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
+  else gemm_bf16_nt_pingpong_kernel<false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
   return 0;
 }
-#ifdef PP_DIAG
-void pp_diag_print() {
-  unsigned long long h[8];
-  (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_diag), sizeof h);
-  if (h[3]) printf("pp diag per tile (wave 0, cycles): K loop %.0f, store issue %.0f, drain after last issue %.0f (tiles %llu)\n",
-                   (double)h[2] / h[3], (double)h[0] / h[3], (double)h[1] / h[3], h[3]);
-  if (h[3]) printf("   phase 3 per tile: reads+DMA issue %.0f, vmcnt wait %.0f, two barriers %.0f, 16 MFMA %.0f\n", (double)h[4] / h[3], (double)h[5] / h[3],
-                   (double)h[6] / h[3], (double)h[7] / h[3]);
-  unsigned long long z[8] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_diag), z, sizeof z);
-}
-#endif
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s) {
   return launch_gemm_bf16_pingpong_mode(0, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
