@@ -1,0 +1,257 @@
+// Persistent reverse-time recurrence of BPTT through nn.GRU's cell (model/rnn/rnn.py:61; loss.backward(), trainer/train.py:23).
+// Replaces the step-by-step loop "elementwise kernel + 16-row GEMM" (two dependent launches per time step, 8 workgroups
+// in the GEMM: 27 us per step on a 128-frame window) by ONE launch that keeps W_hh in registers, like the forward
+// recurrence (gru_recurrence.hip):
+//   for t = T-1 .. 0, for the clips alive at t (sorted prefix) and every hidden unit j:
+//     dh      = dHout[row(t,b)][j] + (clip alive at t+1 ? dh_{t+1} z_{t+1} + (dGH_{t+1} W_hh)[b][j] : 0)
+//     dn = dh (1-z); dz = dh (h_{t-1} - n); dpre_n = dn (1-n^2); dpre_r = dpre_n ghn r (1-r); dpre_z = dz z (1-z)
+//     dGI[row] = [dpre_r | dpre_z | dpre_n]      dGH[row] = [dpre_r | dpre_z | dpre_n r]      (fp32 + operand-dtype copies)
+// Decomposition = the forward kernel's: G groups x P workgroups, a workgroup owns 16*UT output units j (columns of dh) and
+// holds its slice of W_hh^T ([j][3H], K = 3H = 3072) as MFMA A-fragments in VGPRs, wave q the K-quarter q (192 VGPRs).
+// Per step a workgroup needs the whole dGH_{t+1} of its group's clips (3 x the forward's h): an all-gather through a
+// double-buffered exchange buffer in fragment-major layout.  Gradients are not bounded, so the forward's tag-in-the-data
+// validity trick does not apply: the hand-off is a per-group step counter.  Producers drain their publish stores
+// (s_waitcnt vmcnt(0)) and then bump the counter; consumers wait for the counter and then load.  As in the forward kernel the
+// launch first VERIFIES placement (every workgroup of a group reports its XCC id): a group that sits on one XCD hands off
+// with plain stores + L1-bypassing nt loads through that XCD's L2, any other placement with sc1 stores + sc1 loads (the
+// agent-scope release/acquire FENCES this replaced wrote back and invalidated the whole L2 every step: 30 us per step).
+// Every spin is bounded (abort word).
+// Training batches are small (16 windows x 128 frames in the reference, one clip tile of one group), so this kernel is
+// written for low launch count first: the 128-step loop drops from 3.5 ms to < 0.5 ms (train step 6.2 -> 2.7 ms).
+#include "common.h"
+#include "kernels.h"
+
+#define BPTT_SPIN_LIMIT (1u << 22)
+#define BPTT_MAX_TILES 4
+
+template <typename WT, int HID, int UT, int NCT>
+__global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
+  constexpr bool BF = (sizeof(WT) == 2);
+  constexpr int UNITS = 16 * UT;              // output units (columns of dh) owned by this workgroup
+  constexpr int K3 = 3 * HID;                 // contraction length
+  constexpr int KQ = K3 / 4;                  // K range per wave
+  constexpr int KF = BF ? 32 : 16;            // k per fragment
+  constexpr int EPL = BF ? 8 : 4;             // elements per lane and fragment
+  constexpr int NKS = KQ / KF;                // fragments per wave and clip tile
+  constexpr int NFR = K3 / KF;                // fragments of one clip tile's dGH
+  constexpr int OWN_R = UT == 2 ? 2 : 1;
+  constexpr int GROUP_BYTES = NFR * BPTT_MAX_TILES * 1024;
+  constexpr int P = HID / UNITS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* red = (f32x4*)smem;                  // [2 parities][4 waves][UT][64 lanes]
+  constexpr int RED_STRIDE = 4 * UT * 64;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x % a.G, w = blockIdx.x / a.G;
+  if (g * 16 >= a.n_clips) return;            // group without clips
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // ---- placement: does the whole group sit on one XCD? (sync[16+g] = XCC id mask, sync[32+g] = arrivals) ----------------
+  __shared__ int s_local;
+  if (tid == 0) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;          // HW_REG_XCC_ID[2:0]
+    __hip_atomic_fetch_or(a.sync + 16 + g, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(a.sync + 32 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int loc = 1;
+    while (__hip_atomic_load(a.sync + 32 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
+      if (++spins > BPTT_SPIN_LIMIT) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); loc = -1; break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    if (loc > 0) {
+      const unsigned m = __hip_atomic_load(a.sync + 16 + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      loc = (m & (m - 1)) == 0u ? 1 : 0;
+    }
+    s_local = loc;
+  }
+  __syncthreads();
+  if (s_local < 0) return;
+  const bool local = s_local == 1 && !a.force_sc1;
+
+  // ---- resident weights: W_hh^T rows (unit j) x this wave's K-quarter -------------------------------------------------
+  bf16x8 wb[BF ? UT : 1][BF ? NKS : 1];
+  float wf[BF ? 1 : UT][BF ? 1 : NKS][4];
+#pragma unroll
+  for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const size_t row = (size_t)(w * UNITS + ut * 16 + l15);
+      const int k = q * KQ + ks * KF + EPL * l4;
+      if constexpr (BF) {
+        wb[ut][ks] = *(const bf16x8*)((const bf16_t*)a.whhT + row * K3 + k);
+      } else {
+        const float4 v = *(const float4*)((const float*)a.whhT + row * K3 + k);
+        wf[ut][ks][0] = v.x; wf[ut][ks][1] = v.y; wf[ut][ks][2] = v.z; wf[ut][ks][3] = v.w;
+      }
+    }
+
+  // ---- ownership in the elementwise phase (as in the forward kernel) ---------------------------------------------------
+  const int own_ut = UT == 2 ? (q & 1) : 0;
+  const int own_r0 = UT == 2 ? (q >> 1) * 2 : q;
+  const int ucol = w * UNITS + own_ut * 16 + l4 * 4 + own_r0;
+  int sidx[NCT], tfirst[NCT];
+  float carry[NCT][OWN_R];                    // dh_{t+1} * z_{t+1} of my (unit, clip) pairs
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    sidx[ct] = ct * 16 * a.G + g * 16 + l15;
+    tfirst[ct] = ct * 16 * a.G + g * 16;
+#pragma unroll
+    for (int e = 0; e < OWN_R; ++e) carry[ct][e] = 0.f;
+  }
+  const int buf_stride = a.G * GROUP_BYTES;
+  char* hx_base = (char*)a.hx + (size_t)g * GROUP_BYTES;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hx_base, 0, buf_stride + GROUP_BYTES, 0x00020000);
+  unsigned* counter = a.sync + g;             // steps published by the group's workgroups, summed
+  unsigned arrived = 0;                       // publishes this workgroup has announced
+
+  for (int t = a.t_max - 1; t >= 0; --t) {
+    const int na = a.nact[t];
+    const int na_next = t + 1 < a.t_max ? a.nact[t + 1] : 0;
+    const int row_t = a.rowoff[t];
+    const int row_tm1 = t > 0 ? a.rowoff[t - 1] : 0;
+    const int rbuf = (t + 1) & 1;             // where step t+1 published
+    if (tfirst[0] >= na) continue;            // nothing of this group alive yet (clips are sorted longest first)
+
+    // ---- wait until every workgroup of the group has published step t+1 (acquire) ------------------------------------
+    const bool need = tfirst[0] < na_next;
+    if (need) {
+      if (tid == 0) {
+        const unsigned target = (unsigned)P * arrived;
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          if (++spins > BPTT_SPIN_LIMIT) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 255u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __syncthreads();
+      if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    }
+
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (tfirst[ct] >= na) continue;
+      // ---- (1) dhpart = dGH_{t+1} . W_hh for my units: gather + MFMA + cross-wave reduction -------------------------------
+      float dhp[OWN_R];
+#pragma unroll
+      for (int e = 0; e < OWN_R; ++e) dhp[e] = 0.f;
+      if (tfirst[ct] < na_next) {
+        f32x4 acc[UT];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const int goff = rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16;
+          const u32x4 v = local ? __builtin_amdgcn_raw_buffer_load_b128(rs, goff, 0, AUX_NT) : __builtin_amdgcn_raw_buffer_load_b128(rs, goff, 0, AUX_SC1);
+          if constexpr (BF) {
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut)
+              acc[ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ut][ks], bfrag, ks == 0 ? zero4 : acc[ut], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const float bj = __uint_as_float(v[jj]);
+#pragma unroll
+              for (int ut = 0; ut < UT; ++ut)
+                acc[ut] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[ut][ks][jj], bj, (ks == 0 && jj == 0) ? zero4 : acc[ut], 0, 0, 0);
+            }
+          }
+        }
+        f32x4* redw = red + ((t + ct) & 1) * RED_STRIDE;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) redw[(q * UT + ut) * 64 + lane] = acc[ut];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < OWN_R; ++e) {
+          float p[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) p[qq] = *((const float*)&redw[(qq * UT + own_ut) * 64 + lane] + own_r0 + e);
+          dhp[e] = (p[0] + p[1]) + (p[2] + p[3]);
+        }
+      }
+      // ---- (2) gate gradients of my (unit, clip) pairs ----------------------------------------------------------------------
+      if (sidx[ct] < na) {
+        const size_t eo = (size_t)(row_t + sidx[ct]) * HID + ucol;
+        const size_t go = (size_t)(row_t + sidx[ct]) * K3 + ucol;
+        const bool cont = sidx[ct] < na_next;
+        float dpr[OWN_R], dpz[OWN_R], dpn[OWN_R], dpnr[OWN_R];
+#pragma unroll
+        for (int e = 0; e < OWN_R; ++e) {
+          float dh = a.dHout[eo + e];
+          if (cont) dh += carry[ct][e] + dhp[e];
+          const float r = a.R[eo + e], z = a.Z[eo + e], n = a.N[eo + e], ghn = a.GHN[eo + e];
+          const float hprev = t > 0 ? a.Hraw[(size_t)(row_tm1 + sidx[ct]) * HID + ucol + e] : 0.f;
+          const float dn = dh * (1.f - z);
+          const float dz = dh * (hprev - n);
+          dpn[e] = dn * (1.f - n * n);
+          dpr[e] = dpn[e] * ghn * r * (1.f - r);
+          dpz[e] = dz * z * (1.f - z);
+          dpnr[e] = dpn[e] * r;
+          carry[ct][e] = dh * z;
+          a.dGI[go + e] = dpr[e]; a.dGI[go + HID + e] = dpz[e]; a.dGI[go + 2 * HID + e] = dpn[e];
+          a.dGH[go + e] = dpr[e]; a.dGH[go + HID + e] = dpz[e]; a.dGH[go + 2 * HID + e] = dpnr[e];
+          if constexpr (BF) {
+            ((bf16_t*)a.dGIop)[go + e] = f2bf(dpr[e]); ((bf16_t*)a.dGIop)[go + HID + e] = f2bf(dpz[e]); ((bf16_t*)a.dGIop)[go + 2 * HID + e] = f2bf(dpn[e]);
+            ((bf16_t*)a.dGHop)[go + e] = f2bf(dpr[e]); ((bf16_t*)a.dGHop)[go + HID + e] = f2bf(dpz[e]); ((bf16_t*)a.dGHop)[go + 2 * HID + e] = f2bf(dpnr[e]);
+          } else {
+            ((float*)a.dGIop)[go + e] = dpr[e]; ((float*)a.dGIop)[go + HID + e] = dpz[e]; ((float*)a.dGIop)[go + 2 * HID + e] = dpn[e];
+            ((float*)a.dGHop)[go + e] = dpr[e]; ((float*)a.dGHop)[go + HID + e] = dpz[e]; ((float*)a.dGHop)[go + 2 * HID + e] = dpnr[e];
+          }
+        }
+        // ---- (3) publish dGH_t of this tile for step t-1: element (clip l15, k = gate*H + unit) ----------------------------
+        if (t > 0) {
+#pragma unroll
+          for (int gate = 0; gate < 3; ++gate) {
+            const int k = gate * HID + ucol;
+            const int off = (t & 1) * buf_stride + ((k / KF) * BPTT_MAX_TILES + ct) * 1024 + ((((k % KF) / EPL) << 4) + l15) * 16 +
+                            (k % EPL) * (int)sizeof(WT);
+            const float v0 = gate == 0 ? dpr[0] : (gate == 1 ? dpz[0] : dpnr[0]);
+            unsigned pv;
+            if constexpr (BF) {
+              const float v1 = gate == 0 ? dpr[OWN_R - 1] : (gate == 1 ? dpz[OWN_R - 1] : dpnr[OWN_R - 1]);
+              pv = pack_bf16x2(v0, v1);
+            } else {
+              pv = __float_as_uint(v0);
+            }
+            if (local) __builtin_amdgcn_raw_buffer_store_b32(pv, rs, off, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(pv, rs, off, 0, AUX_SC1);
+          }
+        }
+      }
+    }
+    // ---- announce this step's publish (release): every wave's stores first, then one counter increment per workgroup -------
+    if (t > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's publish stores have reached the L2 (local) / memory (sc1)
+      __syncthreads();
+      ++arrived;
+      if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+size_t gru_bptt_hx_bytes(bool bf16, int hid, int G) { return (size_t)2 * G * (3 * hid / (bf16 ? 32 : 16)) * BPTT_MAX_TILES * 1024; }
+
+// returns 0 on success, -1 for an unsupported shape (the caller falls back to the step-by-step loop)
+int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
+  if (hid != 1024 || nct > BPTT_MAX_TILES) return -1;
+  const int P = bf16 ? 32 : 64;
+  const int grid = a.G * P;
+  (void)hipMemsetAsync(a.sync, 0, 64 * sizeof(unsigned), s);
+#define LAUNCHB(WT, UT, NCT)                                                                       \
+  do {                                                                                             \
+    const size_t lds = (size_t)2 * 4 * UT * 64 * 16;                                               \
+    gru_bptt_kernel<WT, 1024, UT, NCT><<<grid, 256, lds, s>>>(a);                                  \
+  } while (0)
+  if (bf16) {
+    if (nct == 1) LAUNCHB(bf16_t, 2, 1);
+    else if (nct == 2) LAUNCHB(bf16_t, 2, 2);
+    else LAUNCHB(bf16_t, 2, 4);
+  } else {
+    if (nct == 1) LAUNCHB(float, 1, 1);
+    else if (nct == 2) LAUNCHB(float, 1, 2);
+    else LAUNCHB(float, 1, 4);
+  }
+#undef LAUNCHB
+  return 0;
+}

@@ -35,6 +35,24 @@ struct GruArgs {
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
 };
 
+// persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward
+struct BpttArgs {
+  const void* whhT;            // [H][3H] operand dtype: W_hh transposed (the contraction runs over the 3H gate rows)
+  const float* dHout;          // [rows][H] dL/dh_t from the head (after the relu mask)
+  const float* R; const float* Z; const float* N; const float* GHN;   // [rows][H] kept gate activations of the forward
+  const float* Hraw;           // [rows][H] h_t of the forward
+  float* dGI; float* dGH;      // [rows][3H] fp32 gradients of the two pre-activation terms
+  void* dGIop; void* dGHop;    // the same in the operand dtype (wgrad GEMM operands)
+  void* hx;                    // exchange buffers, gru_bptt_hx_bytes()
+  unsigned* sync;              // [64] per-group step counters (zeroed by the launcher)
+  unsigned* abort_word;
+  const int* rowoff; const int* nact;
+  int t_max, n_clips, G;
+  int force_sc1;               // test knob: skip the XCD-local fast path
+};
+size_t gru_bptt_hx_bytes(bool bf16, int hid, int G);
+int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s);
+
 // GEMM epilogues (bf16 kernel): what happens to acc + bias
 enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU_BF16 = 2, EPI_STORE_BF16 = 3, EPI_QKV = 4 };
 struct GemmEpi {

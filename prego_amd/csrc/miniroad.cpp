@@ -570,7 +570,7 @@ extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* con
 
 struct BwdLayout {
   size_t total;
-  size_t dLp, dLf, dLt, HRt, WcT, dWc, dHR, carry, dhpart, WhhT, dGI, dGH, dGIop, dGHop, part, T1, T2, WihT, dE, dY, Hprev, vec;
+  size_t dLp, dLf, dLt, HRt, WcT, dWc, dHR, carry, dhpart, WhhT, dGI, dGH, dGIop, dGHop, part, T1, T2, WihT, dE, dY, Hprev, vec, bhx, bsync;
 };
 static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   const size_t es = h->bf16 ? 2 : 4;
@@ -593,6 +593,7 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   L.dE = put((size_t)R * E * 4); L.dY = put((size_t)R * E * 4);
   L.Hprev = put((size_t)R * H * es);
   L.vec = put(4 * E * 4);
+  L.bhx = put(gru_bptt_hx_bytes(h->bf16, h->hid, h->G)); L.bsync = put(64 * 4);     // persistent BPTT: exchange buffers, step counters
   L.total = off;
   return L;
 }
@@ -671,7 +672,24 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   const size_t Bp = align_up((size_t)n_clips, 16);
   float* carry[2] = {(float*)(bw + L.carry), (float*)(bw + L.carry) + Bp * H};
   float* dhpart = (float*)(bw + L.dhpart);
-  for (int t = h->t_max - 1; t >= 0; --t) {
+  // one persistent launch (gru_bptt.hip); the step-by-step loop below is the fallback for shapes it does not take and the
+  // A/B reference (PREGO_BPTT_STEPWISE=1)
+  bool persistent = false;
+  {
+    static const bool stepwise = getenv("PREGO_BPTT_STEPWISE") != nullptr;
+    const int slots = (h->n_slots + h->G - 1) / h->G;
+    const int nct = (slots + 15) / 16;
+    if (!stepwise) {
+      BpttArgs ba;
+      ba.whhT = bw + L.WhhT; ba.dHout = (const float*)(bw + L.dHR); ba.R = KR; ba.Z = KZ; ba.N = KN; ba.GHN = KG; ba.Hraw = HRAW;
+      ba.dGI = (float*)(bw + L.dGI); ba.dGH = (float*)(bw + L.dGH); ba.dGIop = bw + L.dGIop; ba.dGHop = bw + L.dGHop;
+      ba.hx = bw + L.bhx; ba.sync = (unsigned*)(bw + L.bsync); ba.abort_word = h->abort_word;
+      ba.rowoff = h->d_rowoff; ba.nact = h->d_nact; ba.t_max = h->t_max; ba.n_clips = h->n_slots; ba.G = h->G;
+      ba.force_sc1 = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
+      persistent = launch_gru_bptt(bf, H, nct, ba, s) == 0;
+    }
+  }
+  for (int t = h->t_max - 1; t >= 0 && !persistent; --t) {
     const int na = h->h_nact[t];
     const int na_next = t + 1 < h->t_max ? h->h_nact[t + 1] : 0;
     const int row_t = h->h_rowoff[t], row_tm1 = t > 0 ? h->h_rowoff[t - 1] : 0;

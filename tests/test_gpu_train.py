@@ -176,3 +176,27 @@ def test_empty_clip_list_is_a_noop():
     model, _ = _build(cfg, sd)
     outs, args, hl = model.engine().forward_ragged([], None, want_argmax=True, want_h_last=True)
     assert outs == [] and args == [] and hl.shape == (0, 1024)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bptt_many_windows_multi_tile(dtype):
+    """130 windows x 5 frames: more clips than one 16-slot tile per group (bf16: 8 groups x 2 tiles, fp32: 4 groups x 3 tiles,
+    last tile partly filled) through the persistent reverse-time kernel; gradients against the numpy BPTT oracle"""
+    cfg = assembly101_cfg(dropout=0.0, compute_dtype=dtype, assume_zero_flow=True)
+    sd = W.miniroad_state_dict(cfg, 21)
+    model, crit = _build(cfg, sd)
+    B, T = 130, 5
+    rgb = W.tsn_features((B, T, 2048), 5, "mt.rgb")
+    tgt = _targets(B, T, 86, 5, "mt.tgt")
+    t_rgb, t_tgt = torch.from_numpy(rgb).cuda(), torch.from_numpy(tgt).cuda()
+    loss = crit(model(t_rgb, torch.zeros_like(t_rgb)), t_tgt)
+    loss.backward()
+    model.engine().check()
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+    ref_loss, ref_g = O.miniroad_loss_and_grads(sd64, rgb, None, tgt)
+    assert abs(float(loss.detach()) - ref_loss) < (2e-2 if dtype == "bf16" else 1e-4)
+    rel = 1e-1 if dtype == "bf16" else 2e-3
+    for k, p in model.named_parameters():
+        gr = p.grad.detach().cpu().numpy().astype(np.float64)
+        n = np.linalg.norm(ref_g[k])
+        assert np.linalg.norm(gr - ref_g[k]) < rel * n + 1e-9, (k, np.linalg.norm(gr - ref_g[k]), n)
