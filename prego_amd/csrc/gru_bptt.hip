@@ -10,8 +10,9 @@
 // holds its slice of W_hh^T ([j][3H], K = 3H = 3072) as MFMA A-fragments in VGPRs, wave q the K-quarter q (192 VGPRs).
 // Per step a workgroup needs the whole dGH_{t+1} of its group's clips (3 x the forward's h): an all-gather through a
 // double-buffered exchange buffer in fragment-major layout.  Gradients are not bounded, so the forward's tag-in-the-data
-// validity trick does not apply: the hand-off is a per-group step counter.  Producers drain their publish stores
-// (s_waitcnt vmcnt(0)) and then bump the counter; consumers wait for the counter and then load.  As in the forward kernel the
+// validity trick does not apply: the hand-off is one EPOCH WORD per producer workgroup.  Producers drain their publish
+// stores (s_waitcnt vmcnt(0)) and then store their epoch; a consumer's wave 0 polls the group's P epoch words with one load
+// instruction (one lane per producer) and then everybody gathers.  (An atomic step counter polled by one lane cost 4 us.)  As in the forward kernel the
 // launch first VERIFIES placement (every workgroup of a group reports its XCC id): a group that sits on one XCD hands off
 // with plain stores + L1-bypassing nt loads through that XCD's L2, any other placement with sc1 stores + sc1 loads (the
 // agent-scope release/acquire FENCES this replaced wrote back and invalidated the whole L2 every step: 30 us per step).
@@ -102,33 +103,65 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
   const int buf_stride = a.G * GROUP_BYTES;
   char* hx_base = (char*)a.hx + (size_t)g * GROUP_BYTES;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hx_base, 0, buf_stride + GROUP_BYTES, 0x00020000);
-  unsigned* counter = a.sync + g;             // steps published by the group's workgroups, summed
+  // epoch words of the group's workgroups: a.sync[64 + g*64 + w]
+  __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc((void*)(a.sync + 64 + g * 64), 0, 64 * 4, 0x00020000);
   unsigned arrived = 0;                       // publishes this workgroup has announced
 
+  // plan tables through the scalar path (constant address space), one step ahead: vector loads here put a vmcnt(0) and an
+  // L2 round trip at the top of every step
+  typedef const __attribute__((address_space(4))) int* cint_p;
+  cint_p nact_c = (cint_p)a.nact;
+  cint_p rowoff_c = (cint_p)a.rowoff;
+  int na_cur = nact_c[a.t_max - 1], na_prev = 0;                           // nact[t], nact[t+1]
+  int ro_cur = rowoff_c[a.t_max - 1];                                       // rowoff[t]
+  int na_nx = a.t_max > 1 ? nact_c[a.t_max - 2] : 0, ro_nx = a.t_max > 1 ? rowoff_c[a.t_max - 2] : 0;   // step t-1
   for (int t = a.t_max - 1; t >= 0; --t) {
-    const int na = a.nact[t];
-    const int na_next = t + 1 < a.t_max ? a.nact[t + 1] : 0;
-    const int row_t = a.rowoff[t];
-    const int row_tm1 = t > 0 ? a.rowoff[t - 1] : 0;
+    const int na = na_cur;
+    const int na_next = na_prev;
+    const int row_t = ro_cur;
+    const int row_tm1 = ro_nx;                                              // rowoff[t-1] (0 at t == 0: unused)
+    const int t2 = t >= 2 ? t - 2 : 0;
+    const int na_2 = nact_c[t2], ro_2 = rowoff_c[t2];                       // look-ahead for step t-2
+    na_prev = na_cur; na_cur = na_nx; ro_cur = ro_nx; na_nx = na_2; ro_nx = ro_2;
     const int rbuf = (t + 1) & 1;             // where step t+1 published
     if (tfirst[0] >= na) continue;            // nothing of this group alive yet (clips are sorted longest first)
 
-    // ---- wait until every workgroup of the group has published step t+1 (acquire) ------------------------------------
+    // ---- this step's inputs (HBM) go out BEFORE the wait for the other workgroups: their latency runs under the spin,
+    // the gather and the MFMAs instead of in front of the gate math
+    float in_dh[NCT][OWN_R], in_r[NCT][OWN_R], in_z[NCT][OWN_R], in_n[NCT][OWN_R], in_g[NCT][OWN_R], in_hp[NCT][OWN_R];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int sl = sidx[ct] < na ? sidx[ct] : 0;             // inactive lanes read row 0 of the step (exists) and ignore it
+      const size_t eo = (size_t)(row_t + sl) * HID + ucol;
+      const size_t ep = (size_t)(row_tm1 + sl) * HID + ucol;   // t == 0: row 0 of step 0, ignored
+#pragma unroll
+      for (int e = 0; e < OWN_R; ++e) {
+        in_dh[ct][e] = a.dHout[eo + e]; in_r[ct][e] = a.R[eo + e]; in_z[ct][e] = a.Z[eo + e];
+        in_n[ct][e] = a.N[eo + e]; in_g[ct][e] = a.GHN[eo + e]; in_hp[ct][e] = a.Hraw[ep + e];
+      }
+    }
+    // ---- wait until every workgroup of the group has published step t+1: wave 0 polls the group's P epoch words (one per
+    // producer workgroup, one lane each, ONE load instruction per poll) through the same path as the data
     const bool need = tfirst[0] < na_next;
     if (need) {
-      if (tid == 0) {
-        const unsigned target = (unsigned)P * arrived;
+      if (q == 0) {
         unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          if (++spins > BPTT_SPIN_LIMIT) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        for (;;) {
+          unsigned ep = 0xFFFFFFFFu;
+          if (lane < P) {
+            const int foff = lane * 4;
+            ep = local ? __builtin_amdgcn_raw_buffer_load_b32(rs_f, foff, 0, AUX_NT) : __builtin_amdgcn_raw_buffer_load_b32(rs_f, foff, 0, AUX_SC1);
+          }
+          if (__all(ep >= arrived)) break;
+          if (++spins > BPTT_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
           if ((spins & 255u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-          __builtin_amdgcn_s_sleep(1);
         }
       }
       __syncthreads();
       if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     }
 
+    float dpr[NCT][OWN_R], dpz[NCT][OWN_R], dpn[NCT][OWN_R], dpnr[NCT][OWN_R];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       if (tfirst[ct] >= na) continue;
@@ -139,10 +172,20 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
       if (tfirst[ct] < na_next) {
         f32x4 acc[UT];
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // all of the wave's fragments in flight first (one L2 round trip, not NKS of them), then the products
+        u32x4 hb[NKS];
+        if (local) {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+        }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          const int goff = rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16;
-          const u32x4 v = local ? __builtin_amdgcn_raw_buffer_load_b128(rs, goff, 0, AUX_NT) : __builtin_amdgcn_raw_buffer_load_b128(rs, goff, 0, AUX_SC1);
+          const u32x4 v = hb[ks];
           if constexpr (BF) {
             const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
@@ -172,32 +215,20 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
       }
       // ---- (2) gate gradients of my (unit, clip) pairs ----------------------------------------------------------------------
       if (sidx[ct] < na) {
-        const size_t eo = (size_t)(row_t + sidx[ct]) * HID + ucol;
-        const size_t go = (size_t)(row_t + sidx[ct]) * K3 + ucol;
         const bool cont = sidx[ct] < na_next;
-        float dpr[OWN_R], dpz[OWN_R], dpn[OWN_R], dpnr[OWN_R];
 #pragma unroll
         for (int e = 0; e < OWN_R; ++e) {
-          float dh = a.dHout[eo + e];
+          float dh = in_dh[ct][e];
           if (cont) dh += carry[ct][e] + dhp[e];
-          const float r = a.R[eo + e], z = a.Z[eo + e], n = a.N[eo + e], ghn = a.GHN[eo + e];
-          const float hprev = t > 0 ? a.Hraw[(size_t)(row_tm1 + sidx[ct]) * HID + ucol + e] : 0.f;
+          const float r = in_r[ct][e], z = in_z[ct][e], n = in_n[ct][e], ghn = in_g[ct][e];
+          const float hprev = t > 0 ? in_hp[ct][e] : 0.f;
           const float dn = dh * (1.f - z);
           const float dz = dh * (hprev - n);
-          dpn[e] = dn * (1.f - n * n);
-          dpr[e] = dpn[e] * ghn * r * (1.f - r);
-          dpz[e] = dz * z * (1.f - z);
-          dpnr[e] = dpn[e] * r;
+          dpn[ct][e] = dn * (1.f - n * n);
+          dpr[ct][e] = dpn[ct][e] * ghn * r * (1.f - r);
+          dpz[ct][e] = dz * z * (1.f - z);
+          dpnr[ct][e] = dpn[ct][e] * r;
           carry[ct][e] = dh * z;
-          a.dGI[go + e] = dpr[e]; a.dGI[go + HID + e] = dpz[e]; a.dGI[go + 2 * HID + e] = dpn[e];
-          a.dGH[go + e] = dpr[e]; a.dGH[go + HID + e] = dpz[e]; a.dGH[go + 2 * HID + e] = dpnr[e];
-          if constexpr (BF) {
-            ((bf16_t*)a.dGIop)[go + e] = f2bf(dpr[e]); ((bf16_t*)a.dGIop)[go + HID + e] = f2bf(dpz[e]); ((bf16_t*)a.dGIop)[go + 2 * HID + e] = f2bf(dpn[e]);
-            ((bf16_t*)a.dGHop)[go + e] = f2bf(dpr[e]); ((bf16_t*)a.dGHop)[go + HID + e] = f2bf(dpz[e]); ((bf16_t*)a.dGHop)[go + 2 * HID + e] = f2bf(dpnr[e]);
-          } else {
-            ((float*)a.dGIop)[go + e] = dpr[e]; ((float*)a.dGIop)[go + HID + e] = dpz[e]; ((float*)a.dGIop)[go + 2 * HID + e] = dpn[e];
-            ((float*)a.dGHop)[go + e] = dpr[e]; ((float*)a.dGHop)[go + HID + e] = dpz[e]; ((float*)a.dGHop)[go + 2 * HID + e] = dpnr[e];
-          }
         }
         // ---- (3) publish dGH_t of this tile for step t-1: element (clip l15, k = gate*H + unit) ----------------------------
         if (t > 0) {
@@ -206,10 +237,10 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
             const int k = gate * HID + ucol;
             const int off = (t & 1) * buf_stride + ((k / KF) * BPTT_MAX_TILES + ct) * 1024 + ((((k % KF) / EPL) << 4) + l15) * 16 +
                             (k % EPL) * (int)sizeof(WT);
-            const float v0 = gate == 0 ? dpr[0] : (gate == 1 ? dpz[0] : dpnr[0]);
+            const float v0 = gate == 0 ? dpr[ct][0] : (gate == 1 ? dpz[ct][0] : dpnr[ct][0]);
             unsigned pv;
             if constexpr (BF) {
-              const float v1 = gate == 0 ? dpr[OWN_R - 1] : (gate == 1 ? dpz[OWN_R - 1] : dpnr[OWN_R - 1]);
+              const float v1 = gate == 0 ? dpr[ct][OWN_R - 1] : (gate == 1 ? dpz[ct][OWN_R - 1] : dpnr[ct][OWN_R - 1]);
               pv = pack_bf16x2(v0, v1);
             } else {
               pv = __float_as_uint(v0);
@@ -220,12 +251,35 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
         }
       }
     }
-    // ---- announce this step's publish (release): every wave's stores first, then one counter increment per workgroup -------
+    // ---- announce this step's publish: only the publish stores (and older loads) are outstanding here, so the drain is short;
+    // one counter increment per workgroup
     if (t > 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's publish stores have reached the L2 (local) / memory (sc1)
       __syncthreads();
       ++arrived;
-      if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {                                             // my epoch word: "this workgroup has published `arrived` steps"
+        if (local) __builtin_amdgcn_raw_buffer_store_b32(arrived, rs_f, w * 4, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(arrived, rs_f, w * 4, 0, AUX_SC1);
+      }
+    }
+    // ---- the step's results for the weight-gradient GEMMs, fire and forget (behind the hand-off, not in front of it) ------------
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (tfirst[ct] < na && sidx[ct] < na) {
+        const size_t go = (size_t)(row_t + sidx[ct]) * K3 + ucol;
+#pragma unroll
+        for (int e = 0; e < OWN_R; ++e) {
+          a.dGI[go + e] = dpr[ct][e]; a.dGI[go + HID + e] = dpz[ct][e]; a.dGI[go + 2 * HID + e] = dpn[ct][e];
+          a.dGH[go + e] = dpr[ct][e]; a.dGH[go + HID + e] = dpz[ct][e]; a.dGH[go + 2 * HID + e] = dpnr[ct][e];
+          if constexpr (BF) {
+            ((bf16_t*)a.dGIop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGIop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGIop)[go + 2 * HID + e] = f2bf(dpn[ct][e]);
+            ((bf16_t*)a.dGHop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGHop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGHop)[go + 2 * HID + e] = f2bf(dpnr[ct][e]);
+          } else {
+            ((float*)a.dGIop)[go + e] = dpr[ct][e]; ((float*)a.dGIop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGIop)[go + 2 * HID + e] = dpn[ct][e];
+            ((float*)a.dGHop)[go + e] = dpr[ct][e]; ((float*)a.dGHop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGHop)[go + 2 * HID + e] = dpnr[ct][e];
+          }
+        }
+      }
     }
   }
 }
@@ -237,7 +291,7 @@ int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
   if (hid != 1024 || nct > BPTT_MAX_TILES) return -1;
   const int P = bf16 ? 32 : 64;
   const int grid = a.G * P;
-  (void)hipMemsetAsync(a.sync, 0, 64 * sizeof(unsigned), s);
+  (void)hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), s);      // [0,64): placement words; [64 + 64 g + w]: epoch words
 #define LAUNCHB(WT, UT, NCT)                                                                       \
   do {                                                                                             \
     const size_t lds = (size_t)2 * 4 * UT * 64 * 16;                                               \

@@ -44,7 +44,7 @@ struct BpttArgs {
   float* dGI; float* dGH;      // [rows][3H] fp32 gradients of the two pre-activation terms
   void* dGIop; void* dGHop;    // the same in the operand dtype (wgrad GEMM operands)
   void* hx;                    // exchange buffers, gru_bptt_hx_bytes()
-  unsigned* sync;              // [64] per-group step counters (zeroed by the launcher)
+  unsigned* sync;              // [1024] placement words + one epoch word per producer workgroup (zeroed by the launcher)
   unsigned* abort_word;
   const int* rowoff; const int* nact;
   int t_max, n_clips, G;

@@ -593,7 +593,7 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   L.dE = put((size_t)R * E * 4); L.dY = put((size_t)R * E * 4);
   L.Hprev = put((size_t)R * H * es);
   L.vec = put(4 * E * 4);
-  L.bhx = put(gru_bptt_hx_bytes(h->bf16, h->hid, h->G)); L.bsync = put(64 * 4);     // persistent BPTT: exchange buffers, step counters
+  L.bhx = put(gru_bptt_hx_bytes(h->bf16, h->hid, h->G)); L.bsync = put(1024 * 4);     // persistent BPTT: exchange buffers, step counters
   L.total = off;
   return L;
 }

@@ -14,13 +14,20 @@
 #include "kernels.h"
 
 // ---- loss -------------------------------------------------------------------------------------
-// one wave per clip; block of 64 threads loops over clips; loss = mean_b sum_k -(y/||y||)_k log_softmax(l)_k
-__global__ void oad_loss_kernel(const float* const* __restrict__ logit_ptrs, const float* const* __restrict__ target_ptrs,
-                                const int* __restrict__ lens, int n_clips, int C, float* __restrict__ loss_out,
-                                float* const* __restrict__ dlogit_ptrs /*nullable*/, float grad_scale) {
-  const int lane = threadIdx.x;
+// one workgroup of 16 waves, wave v takes clips v, v+16, ... (the per-clip work - zeroing dlogits of the T-1 unused frames -
+// is what costs time); the per-clip terms are summed by one thread IN CLIP ORDER, so the loss is bit-identical to a serial
+// loop over the clips.  loss = mean_b sum_k -(y/||y||)_k log_softmax(l)_k
+#define OAD_WAVES 16
+#define OAD_MAX_LDS_CLIPS 4096
+__global__ __launch_bounds__(64 * OAD_WAVES) void oad_loss_kernel(
+    const float* const* __restrict__ logit_ptrs, const float* const* __restrict__ target_ptrs,
+    const int* __restrict__ lens, int n_clips, int C, float* __restrict__ loss_out,
+    float* const* __restrict__ dlogit_ptrs /*nullable*/, float grad_scale) {
+  __shared__ float s_per[OAD_MAX_LDS_CLIPS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool serial = n_clips > OAD_MAX_LDS_CLIPS;       // more clips than the LDS table holds: one wave does all, as before
   float total = 0.f;
-  for (int b = 0; b < n_clips; ++b) {
+  for (int b = serial ? 0 : wave; b < n_clips && (!serial || wave == 0); b += serial ? 1 : OAD_WAVES) {
     const int T = lens[b];
     const float* lg = logit_ptrs[b] + (size_t)(T - 1) * C;
     const float* tg = target_ptrs[b] + (size_t)(T - 1) * C;
@@ -49,7 +56,8 @@ __global__ void oad_loss_kernel(const float* const* __restrict__ logit_ptrs, con
     }
     per = wave_sum(per);
     ysum = wave_sum(ysum);
-    total += per;
+    if (serial) total += per;
+    else if (lane == 0) s_per[b] = per;
     if (dlogit_ptrs) {
       float* dl = dlogit_ptrs[b];
       // zero everything but the last frame (loss.py:18 uses logits[:, -1, :] only)
@@ -61,7 +69,11 @@ __global__ void oad_loss_kernel(const float* const* __restrict__ logit_ptrs, con
       }
     }
   }
-  if (lane == 0) loss_out[0] = total / (float)n_clips;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (!serial) for (int b = 0; b < n_clips; ++b) total += s_per[b];
+    loss_out[0] = total / (float)n_clips;
+  }
 }
 
 // ---- layout helpers -----------------------------------------------------------------------------
@@ -115,12 +127,26 @@ __global__ void colsum_stage1_kernel(const float* __restrict__ src, int M, int N
   for (int m = m0; m < m0 + COLSUM_RB && m < M; ++m) s += src[(size_t)m * N + n];
   part[(size_t)blockIdx.y * N + n] = s;
 }
-__global__ void colsum_stage2_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// 64 columns x 16 row slices per workgroup: slice y sums its contiguous share of the partials in order, the 16 slice sums are
+// added in slice order (fixed order = bit-reproducible; one thread per column walking all nb partials took 30 us at nb = 512)
+__global__ __launch_bounds__(1024) void colsum_stage2_kernel(const float* __restrict__ part, int nb, int N, float* __restrict__ out) {
+  __shared__ float s_sl[16][64];
+  const int cx = threadIdx.x & 63, sy = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
+  const int per = (nb + 15) / 16;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(size_t)b * N + n];
-  out[n] = s;
+  if (n < N) {
+    const int b1 = (sy + 1) * per < nb ? (sy + 1) * per : nb;
+    for (int b = sy * per; b < b1; ++b) s += part[(size_t)b * N + n];
+  }
+  s_sl[sy][cx] = s;
+  __syncthreads();
+  if (sy == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int y = 0; y < 16; ++y) t += s_sl[y][cx];
+    out[n] = t;
+  }
 }
 
 // ---- GRU backward, elementwise part of one reverse step ---------------------------------------------
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
 // ---- launchers -------------------------------------------------------------------------------------
 void launch_oad_loss(const float* const* logit_ptrs, const float* const* target_ptrs, const int* lens, int n_clips, int C,
                      float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s) {
-  oad_loss_kernel<<<1, 64, 0, s>>>(logit_ptrs, target_ptrs, lens, n_clips, C, loss_out, dlogit_ptrs, grad_scale);
+  oad_loss_kernel<<<1, 64 * OAD_WAVES, 0, s>>>(logit_ptrs, target_ptrs, lens, n_clips, C, loss_out, dlogit_ptrs, grad_scale);
 }
 void launch_gather_dlogits(bool bf16, const float* const* dl_ptrs, const int* rowoff, const int* sorted_clip, int t_max,
                            int nrows, int C, int Cpad, void* out, hipStream_t s) {
@@ -281,10 +307,10 @@ void launch_colsum(const float* src, int M, int N, float* part, float* out, hipS
   const int nb = (M + COLSUM_RB - 1) / COLSUM_RB;
   dim3 g1((N + 255) / 256, nb);
   colsum_stage1_kernel<<<g1, 256, 0, s>>>(src, M, N, part);
-  colsum_stage2_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, nb, N, out);
+  colsum_stage2_kernel<<<(N + 63) / 64, 1024, 0, s>>>(part, nb, N, out);
 }
 void launch_colsum_stage2(const float* part, int nb, int N, float* out, hipStream_t s) {
-  colsum_stage2_kernel<<<(N + 255) / 256, 256, 0, s>>>(part, nb, N, out);
+  colsum_stage2_kernel<<<(N + 63) / 64, 1024, 0, s>>>(part, nb, N, out);
 }
 void launch_gru_bwd_step(bool bf16, int t, int na, int na_next, int row_t, int row_tm1, int H, const float* dHout,
                          const float* carry_in, const float* dhpart, const float* R, const float* Z, const float* Nn,
