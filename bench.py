@@ -32,8 +32,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)      # >= 10 timed runs
+    ap.add_argument("--warmup", type=int, default=3)     # ... after 3 warm-ups
     ap.add_argument("--clips", type=int, default=0, help="override clip count (debug)")
     ap.add_argument("--len-scale", type=float, default=1.0, help="scale clip lengths (debug)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
