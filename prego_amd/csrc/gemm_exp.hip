@@ -128,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
 void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
                                    int ldc, int M, int N, int K, hipStream_t s) {
   if (variant == 12 || variant == 13) {
-    (void)launch_gemm_bf16_pingpong_mode(variant - 11, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+    (void)launch_gemm_bf16_pingpong_mode(variant - 11, A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
     return;
   }
   if (N % XBN) return;

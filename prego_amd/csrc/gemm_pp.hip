@@ -49,10 +49,13 @@ __device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle
 // starts.  Measured against one workgroup per tile: -4 % at K = 2048, +-1 % at K = 4096 - a wave cannot use a load that is
 // younger than its own stores (one in-order vmcnt for both), so only the first five phases of the next tile overlap the
 // store tail, and the extra control flow in the K loop costs as much.
-template <bool PERSIST>
+// OUT_BF16: C is bf16 (the inference path keeps the layer1 and W_ih projections in bf16 between the kernels: half the C bytes;
+// the store tail of a tile is bound by bytes).
+template <bool PERSIST, bool OUT_BF16>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    float* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc) {
+    void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc) {
+  float* C = (float*)Cv;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -255,7 +258,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
           for (int i = 0; i < 4; ++i) {
             const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
             const f32x4 v = acc[x][y][i][j];
-            *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+            if constexpr (OUT_BF16) {
+              uint2 pk;
+              pk.x = pack_bf16x2(v[0] + bv[y][j].x, v[1] + bv[y][j].y); pk.y = pack_bf16x2(v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+              *(uint2*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
+            } else {
+              *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+            }
             acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
@@ -271,7 +280,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
           for (int i = 0; i < 4; ++i) {
             const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
             const f32x4 v = acc[x][y][i][j];
-            if (m < M) *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+            if (m < M) {
+              if constexpr (OUT_BF16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v[0] + bv[y][j].x, v[1] + bv[y][j].y); pk.y = pack_bf16x2(v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+                *(uint2*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
+              } else {
+                *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
+              }
+            }
             acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
         }
@@ -296,9 +313,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   }
 }
 
-// mode: 0 / 1 = one workgroup per tile (production: 1.14 vs 1.10 PFLOP/s at K = 2048, equal at K = 4096), 2 = persistent tile loop
-int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
-                                   int M, int N, int K, hipStream_t s) {
+// mode: 0 / 1 = one workgroup per tile (production: 1.14 vs 1.10 PFLOP/s at K = 2048, equal at K = 4096), 2 = persistent tile loop;
+// out_bf16: C is bf16 with leading dimension ldc (elements)
+int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
+                                   int M, int N, int K, bool out_bf16, hipStream_t s) {
   if (N % PBN || K % PBK || K < 2 * PBK || bias == nullptr) return -1;
   const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
   static int n_cu = 0;
@@ -306,16 +324,31 @@ int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void*
     int dev = 0; hipDeviceProp_t pr;
     (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
     n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
   }
   const int grid = (n_cu / 8) * 8;                               // 128 KB of LDS: one workgroup per CU
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (mode == 2 && ntiles > grid) gemm_bf16_nt_pingpong_kernel<true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
-  else gemm_bf16_nt_pingpong_kernel<false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
+  if (out_bf16) gemm_bf16_nt_pingpong_kernel<false, true><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
+  else if (mode == 2 && ntiles > grid) gemm_bf16_nt_pingpong_kernel<true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
+  else gemm_bf16_nt_pingpong_kernel<false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
   return 0;
 }
+#ifdef PP_DIAG
+void pp_diag_print() {
+  unsigned long long h[8];
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_pp_diag), sizeof h);
+  if (h[3]) printf("pp diag per tile (wave 0, cycles): K loop %.0f, store issue %.0f, drain after last issue %.0f (tiles %llu)\n",
+                   (double)h[2] / h[3], (double)h[0] / h[3], (double)h[1] / h[3], h[3]);
+  if (h[3]) printf("   phase 3 per tile: reads+DMA issue %.0f, vmcnt wait %.0f, two barriers %.0f, 16 MFMA %.0f\n", (double)h[4] / h[3], (double)h[5] / h[3],
+                   (double)h[6] / h[3], (double)h[7] / h[3]);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pp_diag), z, sizeof z);
+}
+#endif
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s) {
-  return launch_gemm_bf16_pingpong_mode(0, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
+  return launch_gemm_bf16_pingpong_mode(0, A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
 }

@@ -55,7 +55,8 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) {
 
 // TRAIN: also store the gate activations / raw state BPTT needs (a.keep_*, a.h_raw_out); the inference instantiation
 // carries none of that code or its registers.
-template <typename WT, int HID, int UT, int NCT, bool TRAIN>
+// GI16: the input projection rows (a.gi) are bf16 (inference path with bf16 intermediates)
+template <typename WT, int HID, int UT, int NCT, bool TRAIN, bool GI16 = false>
 __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   constexpr bool BF = (sizeof(WT) == 2);
   constexpr int UNITS = 16 * UT;              // hidden units owned by this workgroup
@@ -208,12 +209,19 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const int r = rbase + (sidx[ct] < na ? sidx[ct] : 0);
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
-      const float* p = a.gi + (size_t)r * (3 * HID) + gate * HID + ucol;
-      if constexpr (OWN_R == 2) {
-        const float2 v = *(const float2*)p;
-        dst[gate][0] = v.x; dst[gate][1] = v.y;
+      if constexpr (GI16) {
+        const bf16_t* p = (const bf16_t*)a.gi + (size_t)r * (3 * HID) + gate * HID + ucol;
+        // RAW bits only: unpacking here would make hipcc wait for the prefetch right behind its issue; the gate phase unpacks
+        if constexpr (OWN_R == 2) dst[gate][0] = __uint_as_float(*(const unsigned*)p);
+        else dst[gate][0] = __uint_as_float((unsigned)p[0]);
       } else {
-        dst[gate][0] = p[0];
+        const float* p = (const float*)a.gi + (size_t)r * (3 * HID) + gate * HID + ucol;
+        if constexpr (OWN_R == 2) {
+          const float2 v = *(const float2*)p;
+          dst[gate][0] = v.x; dst[gate][1] = v.y;
+        } else {
+          dst[gate][0] = p[0];
+        }
       }
     }
   };
@@ -381,7 +389,15 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             for (int gate = 0; gate < 3; ++gate) gh[gate] = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
             if (sidx[ct] < na) {
               const f32x2 one = {1.f, 1.f};
-              const f32x2 gr = {gir[ct][0][0], gir[ct][0][1]}, gz = {gir[ct][1][0], gir[ct][1][1]}, gn = {gir[ct][2][0], gir[ct][2][1]};
+              f32x2 gr, gz, gn;
+              if constexpr (GI16) {          // one dword = the bf16 pair of my two units
+                const unsigned ur = __float_as_uint(gir[ct][0][0]), uz = __float_as_uint(gir[ct][1][0]), un = __float_as_uint(gir[ct][2][0]);
+                gr = (f32x2){__uint_as_float(ur << 16), __uint_as_float(ur & 0xFFFF0000u)};
+                gz = (f32x2){__uint_as_float(uz << 16), __uint_as_float(uz & 0xFFFF0000u)};
+                gn = (f32x2){__uint_as_float(un << 16), __uint_as_float(un & 0xFFFF0000u)};
+              } else {
+                gr = (f32x2){gir[ct][0][0], gir[ct][0][1]}; gz = (f32x2){gir[ct][1][0], gir[ct][1][1]}; gn = (f32x2){gir[ct][2][0], gir[ct][2][1]};
+              }
               const f32x2 hp = {hreg[ct][0], hreg[ct][1]}, bh = {bhn[0], bhn[1]};
               const f32x2 xr = gr + gh[0], xz = gz + gh[1];
               f32x2 r, z, n;
@@ -413,10 +429,13 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             if (sidx[ct] < na) {
 #pragma unroll
               for (int e = 0; e < OWN_R; ++e) {
-                const float r = sigmoidf_(gir[ct][0][e] + gh[0][e]);
-                const float z = sigmoidf_(gir[ct][1][e] + gh[1][e]);
+                const float g_r = GI16 ? __uint_as_float(__float_as_uint(gir[ct][0][e]) << 16) : gir[ct][0][e];
+                const float g_z = GI16 ? __uint_as_float(__float_as_uint(gir[ct][1][e]) << 16) : gir[ct][1][e];
+                const float g_n = GI16 ? __uint_as_float(__float_as_uint(gir[ct][2][e]) << 16) : gir[ct][2][e];
+                const float r = sigmoidf_(g_r + gh[0][e]);
+                const float z = sigmoidf_(g_z + gh[1][e]);
                 const float ghn = gh[2][e] + bhn[e];
-                const float n = tanhf_(gir[ct][2][e] + r * ghn);
+                const float n = tanhf_(g_n + r * ghn);
                 hreg[ct][e] = (1.0f - z) * n + z * hreg[ct][e];
                 if constexpr (TRAIN) {
                   if (a.keep_r) {
@@ -508,6 +527,7 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
   do {                                                                                                 \
     const size_t lds = (size_t)2 * 4 * 3 * UT * 64 * 16;                                               \
     if (train) gru_recurrence_kernel<WT, 1024, UT, NCT, true><<<grid, 256, lds, s>>>(a);              \
+    else if (a.gi_bf16) gru_recurrence_kernel<WT, 1024, UT, NCT, false, true><<<grid, 256, lds, s>>>(a); \
     else gru_recurrence_kernel<WT, 1024, UT, NCT, false><<<grid, 256, lds, s>>>(a);                    \
   } while (0)
   if (bf16) {

@@ -16,7 +16,7 @@ struct SlotPlan {
 struct GruArgs {
   const void* whh;       // [3H][H] bf16 or f32, reference layout of gru.weight_hh_l0 (rows r|z|n)
   const float* b_hn;     // [H]  = gru.bias_hh_l0[2H:3H]
-  const float* gi;       // [rows][3H] fp32, chunk-relative packed rows
+  const void* gi;        // [rows][3H] fp32 (or bf16 when gi_bf16), chunk-relative packed rows
   void* h_relu_out;      // [rows][H] WT  relu(h_t)  (operand of the classification GEMM), nullable
   float* h_raw_out;      // [rows][H] fp32 h_t (kept for BPTT), nullable
   float* h_state;        // [n_clips][H] fp32, indexed by SORTED clip position; in: h_{t0-1}, out: h_{t1-1}
@@ -33,6 +33,7 @@ struct GruArgs {
   float* keep_r; float* keep_z; float* keep_n; float* keep_ghn;   // [rows][H] gate activations for BPTT, nullable
   unsigned* sync;              // [16] placement rendezvous words (8 per-XCD tickets + total), zeroed per launch; nullable
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
+  int gi_bf16;                 // gi rows are bf16 (inference path with bf16 intermediates)
 };
 
 // persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward
@@ -67,14 +68,15 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
                       int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s);
-void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
-                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1);
+void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
+                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
+                    bool in_bf16 = false);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
                         int cols_dst, hipStream_t s);
 // 256x256x64 ping-pong (8-phase) kernel, csrc/gemm_pp.hip; -1 = shape not supported (N % 256, K % 64, K >= 128)
-int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
-                                   int M, int N, int K, hipStream_t s);
+int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
+                                   int M, int N, int K, bool out_bf16, hipStream_t s);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,

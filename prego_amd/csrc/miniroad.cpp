@@ -303,13 +303,23 @@ static SlotPlan device_plan(const prego_miniroad* h) {
 }
 
 struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, total; };
+// bf16 mode, inference (no PREGO_FWD_KEEP): the two projections' outputs stay bf16 between the kernels (what a bf16 autocast
+// of the reference does too).  They are the largest HBM streams of the pass (20 KB per frame in fp32) and the store tail of a
+// GEMM tile is bound by bytes: with fp32 C the projections run 1.23 / 1.10 PFLOP/s (K = 4096 / 2048), without any C store 1.41 /
+// 1.40; the numpy emulation of the whole path moves the worst probability error from 2.0e-3 to 2.5e-3 (tolerance 1e-2).
+// Training keeps them fp32 (LayerNorm backward reads Y).  PREGO_FP32_INTERMEDIATES=1 restores fp32 for A/B.
+static bool inter16(const prego_miniroad* h, int flags) {
+  static const bool force32 = getenv("PREGO_FP32_INTERMEDIATES") != nullptr;
+  return h->bf16 && !(flags & PREGO_FWD_KEEP) && !force32;
+}
 static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
   const size_t es = h->bf16 ? 2 : 4;
+  const size_t is = inter16(h, flags) ? 2 : 4;
   RowBytes r;
   r.x = (size_t)(h->d_rgb + (with_flow ? h->d_flow : 0)) * es;
-  r.y = (size_t)h->emb * 4;
+  r.y = (size_t)h->emb * is;
   r.e = (size_t)h->emb * es;
-  r.gi = (size_t)3 * h->hid * 4;
+  r.gi = (size_t)3 * h->hid * is;
   r.hr = (size_t)h->hid * es;
   const bool keep = (flags & PREGO_FWD_KEEP) != 0;
   r.hraw = keep ? (size_t)h->hid * 4 : 0;
@@ -396,11 +406,21 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   char* wp = (char*)workspace;
   auto carve = [&](size_t bytes) { char* p = wp; wp += align_up(bytes, 256); return (void*)p; };
   void* X = carve((size_t)cap_rows * rb.x);
-  float* Y = (float*)carve((size_t)cap_rows * rb.y);
+  void* Y = carve((size_t)cap_rows * rb.y);
   void* Eb = carve((size_t)cap_rows * rb.e);
-  float* GI = (float*)carve((size_t)cap_rows * rb.gi);
+  void* GI = carve((size_t)cap_rows * rb.gi);
   void* HR = carve((size_t)cap_rows * rb.hr);
   float* HRAW = rb.hraw ? (float*)carve((size_t)cap_rows * rb.hraw) : nullptr;
+  const bool i16 = inter16(h, flags);
+  // projection with fp32 or bf16 output: ping-pong kernel for whole-chip shapes, the 128x128 kernel with a bf16-store epilogue below
+  auto proj = [&](const void* A, int lda, const void* Wt, int ldb, const float* bias, void* Cout, int ldc, int M, int N, int K) {
+    if (!h->bf16) { launch_gemm_f32_nt((const float*)A, lda, (const float*)Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
+    if (!i16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
+    if (M >= 4096 && launch_gemm_bf16_pingpong_mode(0, A, lda, Wt, ldb, bias, Cout, ldc, M, N, K, true, s) == 0) return;
+    GemmEpi epi{};
+    epi.mode = EPI_STORE_BF16; epi.out_b = Cout;
+    launch_gemm_bf16_nt_epi(A, lda, Wt, ldb, bias, nullptr, ldc, M, N, K, epi, s);
+  };
   float* KR = nullptr; float* KZ = nullptr; float* KN = nullptr; float* KG = nullptr; float* STATS = nullptr;
   const bool keep = (flags & PREGO_FWD_KEEP) != 0;
   if (keep) {
@@ -435,18 +455,16 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     if (h->timing) h->pack_bytes += (double)rows * (kx * 4.0 + rb.x);
 
     ev = ev_begin(h, 0, s);
-    if (h->bf16) launch_gemm_bf16_nt(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx, s);
-    else launch_gemm_f32_nt((const float*)X, kx, (const float*)h->w1, din, h->b1, Y, E, rows, E, kx, s);
+    proj(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx);
     ev_end(ev, s);
-    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s);
+    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16);
     ev = ev_begin(h, 0, s);
-    if (h->bf16) launch_gemm_bf16_nt(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E, s);
-    else launch_gemm_f32_nt((const float*)Eb, E, (const float*)h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E, s);
+    proj(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E);
     ev_end(ev, s);
     if (h->timing) h->gemm_flop += 2.0 * rows * ((double)E * kx + 3.0 * H * E);
 
     GruArgs ga;
-    ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
+    ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = i16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
     ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
     ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;

@@ -49,9 +49,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
 // 512-column slab (two 16-byte loads, ONE 16-byte bf16 store: 8-byte stores run at 0.5-0.7x the 16-byte rate).
 // Two-pass statistics in registers (mean, then centred sum of squares) = what torch's CPU LayerNorm computes up to
 // summation order; biased variance, eps inside the sqrt.
-template <typename OutT, int MAXV>
+template <typename OutT, int MAXV, typename InT = float>
 __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
-    const float* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const InT* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
     int nrows, int E, float eps, OutT* __restrict__ out, float* __restrict__ stats /*nullable [nrows][2]*/,
     float drop_p, unsigned long long seed, int row0_abs, int relu) {
   // training-mode Dropout(p) after the ReLU (rnn.py:43): stateless mask = hash(seed, absolute element index),
@@ -62,14 +62,21 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
   const int wave = threadIdx.x >> 6;
   const int nv = E / 512;                      // 8-column groups per lane
   for (int r = blockIdx.x * 4 + wave; r < nrows; r += gridDim.x * 4) {
-    const float* y = Y + (size_t)r * E;
+    const InT* y = Y + (size_t)r * E;
     float v[MAXV][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
-        const float4 a = nt_load4(y + (i * 64 + lane) * 8);
-        const float4 b = nt_load4(y + (i * 64 + lane) * 8 + 4);
+        float4 a, b;
+        if constexpr (sizeof(InT) == 2) {          // bf16 rows (inference path with bf16 intermediates): 8 elements = one 16-byte load
+          const u32x4 w = __builtin_nontemporal_load((const u32x4*)(y + (i * 64 + lane) * 8));
+          a = make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u));
+          b = make_float4(__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xFFFF0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xFFFF0000u));
+        } else {
+          a = nt_load4((const float*)y + (i * 64 + lane) * 8);
+          b = nt_load4((const float*)y + (i * 64 + lane) * 8 + 4);
+        }
         v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w; v[i][4] = b.x; v[i][5] = b.y; v[i][6] = b.z; v[i][7] = b.w;
         s += ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
       }
@@ -142,11 +149,18 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
     pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X);
 }
 
-void launch_ln_relu(bool bf16, const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
-                    void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu) {
+void launch_ln_relu(bool bf16, const void* Yv, const float* gamma, const float* beta, int nrows, int E, float eps, void* out,
+                    float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu, bool in_bf16) {
   if (nrows <= 0) return;
   int grid = (nrows + 3) / 4;
   if (grid > 16384) grid = 16384;
+  const float* Y = (const float*)Yv;
+  if (in_bf16) {        // bf16 in, bf16 out (inference path)
+    const bf16_t* Yb = (const bf16_t*)Yv;
+    if (E <= 2048) ln_relu_rows_kernel<bf16_t, 4, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    else ln_relu_rows_kernel<bf16_t, 8, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    return;
+  }
   if (E <= 2048) {
     if (bf16) ln_relu_rows_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
     else ln_relu_rows_kernel<float, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);

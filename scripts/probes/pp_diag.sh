@@ -7,7 +7,7 @@ cat > alt/diag_main.hip <<'EOC'
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
-int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N, int K, hipStream_t s);
+int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N, int K, bool out_bf16, hipStream_t s);
 void pp_diag_print();
 int main(int argc, char** argv) {
   int M = atoi(argv[1]), N = atoi(argv[2]), K = atoi(argv[3]);
@@ -18,10 +18,10 @@ int main(int argc, char** argv) {
   hipMemcpy(A, h.data(), (size_t)M * K * 2, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
   hipMemset(bias, 0, N * 4);
   for (int mode = 1; mode <= 2; ++mode) {
-    for (int r = 0; r < 3; ++r) launch_gemm_bf16_pingpong_mode(mode, A, K, B, K, bias, C, N, M, N, K, 0);
+    for (int r = 0; r < 3; ++r) launch_gemm_bf16_pingpong_mode(mode, A, K, B, K, bias, C, N, M, N, K, false, 0);
     pp_diag_print();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipEventRecord(e0); for (int r = 0; r < 10; ++r) launch_gemm_bf16_pingpong_mode(mode, A, K, B, K, bias, C, N, M, N, K, 0); hipEventRecord(e1);
+    hipEventRecord(e0); for (int r = 0; r < 10; ++r) launch_gemm_bf16_pingpong_mode(mode, A, K, B, K, bias, C, N, M, N, K, false, 0); hipEventRecord(e1);
     hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("mode %d: %.3f ms per GEMM = %.0f TFLOP/s\n", mode, ms / 10, 2.0 * M * N * K / (ms / 10) / 1e9);
     pp_diag_print();
