@@ -41,6 +41,9 @@ __device__ __forceinline__ int pp_xcd_remap(int bid, int nwg) {
 #ifdef PP_DIAG
 __device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle sums over workgroups (wave 0)
 #endif
+// B half-tiles are read with their rows permuted (read_b below), so their 16-byte-chunk XOR key is a different function of the
+// row than A's (r >> 1) & 7: distinct over the 16 rows one fragment read touches, {8a + 4j + b : a, b = 0..3}
+__device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
 #define PP_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
 // PERSIST (variant 13 of the measurement hook; NOT the production form): one workgroup per CU walks the tile list (stride
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const int r = (wave * 2 + i) * 8 + sr;                      // row inside the half-tile, 0..127
     const int c = scp ^ ((r >> 1) & 7);
     a_off[i] = r * lda * 2 + c * 16;
-    b_off[i] = r * ldb * 2 + c * 16;
+    b_off[i] = r * ldb * 2 + (scp ^ pp_key_b(r)) * 16;
   }
   __amdgpu_buffer_rsrc_t rs_a, rs_b;
   auto set_sources = [&](int tm0, int tn0) {
@@ -122,8 +125,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int r = wc * 32 + j * 16 + fr;
-        bf[ks][j] = *(const bf16x8*)(base + r * 128 + (((ks * 4 + fq) ^ ((r >> 1) & 7)) << 4));
+        // MFMA row fr of tile j <- column 8*(fr >> 2) + 4*j + (fr & 3) of the wave's 32: the transposed accumulators of the two
+        // tiles then hold EIGHT CONSECUTIVE columns per lane (4*fq' .. : j = 0 | j = 1), one 16-byte store in bf16, 32 B in fp32
+        const int r = wc * 32 + (fr >> 2) * 8 + j * 4 + (fr & 3);
+        bf[ks][j] = *(const bf16x8*)(base + r * 128 + (((ks * 4 + fq) ^ pp_key_b(r)) << 4));
       }
   };
   f32x4 acc[2][2][4][2];                                         // [A half][B half][row tile][col tile]
@@ -227,11 +232,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
       set_sources(m0, n0);
     }
   }
+  // lane (fq, fr) holds, for row tile i of quadrant (x, y): row fr, columns y*128 + wc*32 + fq*8 + j*4 + e  (j = tile, e = register)
   float4 bv[2][2];
 #pragma unroll
   for (int y = 0; y < 2; ++y)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bv[y][j] = *(const float4*)(bias + cn0 + y * 128 + wc * 32 + j * 16 + fq * 4);
+    for (int j = 0; j < 2; ++j) bv[y][j] = *(const float4*)(bias + cn0 + y * 128 + wc * 32 + fq * 8 + j * 4);
   // the bias has to be IN before the next tile's DMA is issued: behind it, hipcc could only wait for it with vmcnt(0),
   // which would drain that DMA too (an L2-hot 16-byte load: a few hundred cycles per tile, once)
 #pragma unroll
@@ -239,60 +245,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bv[y][j].x), "+v"(bv[y][j].y), "+v"(bv[y][j].z), "+v"(bv[y][j].w));
   if (has_next) prologue();
-  // ---- epilogue: the products were taken as (B-fragment) x (A-fragment), i.e. transposed 16x16 tiles, so a lane holds FOUR
-  // CONSECUTIVE COLUMNS of one row of C: 16-byte stores (4x fewer store instructions than the row-major accumulator
-  // layout's dword stores; the store tail of a tile is issue-bound)
+  // ---- epilogue: the products were taken as (B-fragment) x (A-fragment), i.e. transposed 16x16 tiles, and the B rows were
+  // permuted on the way in, so a lane holds EIGHT CONSECUTIVE COLUMNS of one row of C: one 16-byte store per row in bf16,
+  // two in fp32 (the store tail of a tile is bound by the number of store instructions first, by bytes second)
 #ifdef PP_DIAG
   const unsigned long long t_epi0 = __builtin_amdgcn_s_memtime();
 #endif
-  const bool whole = cm0 + PBM <= M;                             // wave-uniform: all 32 stores of this wave are issued
-  if (whole) {
+  const bool whole = cm0 + PBM <= M;                             // wave-uniform: all the stores of this wave are issued
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < 2; ++x)
 #pragma unroll
-      for (int y = 0; y < 2; ++y)
+    for (int y = 0; y < 2; ++y) {
+      const int n = cn0 + y * 128 + wc * 32 + fq * 8;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = cn0 + y * 128 + wc * 32 + j * 16 + fq * 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
-            const f32x4 v = acc[x][y][i][j];
-            if constexpr (OUT_BF16) {
-              uint2 pk;
-              pk.x = pack_bf16x2(v[0] + bv[y][j].x, v[1] + bv[y][j].y); pk.y = pack_bf16x2(v[2] + bv[y][j].z, v[3] + bv[y][j].w);
-              *(uint2*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
-            } else {
-              *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
-            }
-            acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) {
+        const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
+        const f32x4 v0 = acc[x][y][i][0], v1 = acc[x][y][i][1];
+        if (whole || m < M) {
+          if constexpr (OUT_BF16) {
+            uint4 pk;
+            pk.x = pack_bf16x2(v0[0] + bv[y][0].x, v0[1] + bv[y][0].y); pk.y = pack_bf16x2(v0[2] + bv[y][0].z, v0[3] + bv[y][0].w);
+            pk.z = pack_bf16x2(v1[0] + bv[y][1].x, v1[1] + bv[y][1].y); pk.w = pack_bf16x2(v1[2] + bv[y][1].z, v1[3] + bv[y][1].w);
+            *(uint4*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
+          } else {
+            *(float4*)(C + (size_t)m * ldc + n) = make_float4(v0[0] + bv[y][0].x, v0[1] + bv[y][0].y, v0[2] + bv[y][0].z, v0[3] + bv[y][0].w);
+            *(float4*)(C + (size_t)m * ldc + n + 4) = make_float4(v1[0] + bv[y][1].x, v1[1] + bv[y][1].y, v1[2] + bv[y][1].z, v1[3] + bv[y][1].w);
           }
         }
-  } else {
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = cn0 + y * 128 + wc * 32 + j * 16 + fq * 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
-            const f32x4 v = acc[x][y][i][j];
-            if (m < M) {
-              if constexpr (OUT_BF16) {
-                uint2 pk;
-                pk.x = pack_bf16x2(v[0] + bv[y][j].x, v[1] + bv[y][j].y); pk.y = pack_bf16x2(v[2] + bv[y][j].z, v[3] + bv[y][j].w);
-                *(uint2*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
-              } else {
-                *(float4*)(C + (size_t)m * ldc + n) = make_float4(v[0] + bv[y][j].x, v[1] + bv[y][j].y, v[2] + bv[y][j].z, v[3] + bv[y][j].w);
-              }
-            }
-            acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-        }
-  }
+        acc[x][y][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[x][y][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
 #ifdef PP_DIAG
   if (wave == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
