@@ -168,8 +168,7 @@ int prego_attention_layer_forward(int batch, int len, int d_model, int heads, in
 int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
 
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
- * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = ping-pong per tile = the production kernel of the
- * projections, 13 = ping-pong with a persistent tile loop; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
+ * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
 int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,
                           prego_stream_t stream);
 

@@ -51,6 +51,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 // tanh(x) = 2 sigmoid(2x) - 1: abs error ~1e-7, saturates cleanly (exp overflow -> rcp(inf) = 0)
 __device__ __forceinline__ float tanhf_(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+// exact-erf GELU (nn.GELU default, Transformer.py:40)
+__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
 // stateless dropout mask: keep iff hash(seed, element index) >= p * 2^32 (same mask in forward and backward)
 __device__ __forceinline__ unsigned mix32_(unsigned long long x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;

@@ -26,7 +26,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // exact (erf) GELU = nn.GELU() default (Transformer.py:40)
-__device__ __forceinline__ float gelu_erf_(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
 template <typename OutT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
@@ -339,6 +338,12 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s) {
   if (M <= 0) return;
+  // whole-chip shapes: the 256x256 ping-pong kernel carries the same epilogues with 16-byte accesses (gemm_pp.hip)
+  static const bool no_pp = getenv("PREGO_GEMM_NO_PINGPONG") != nullptr;
+  if (M >= 4096 && !no_pp) {
+    void* cdst = epi.mode == EPI_STORE_BF16 ? epi.out_b : (void*)C;
+    if (launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, cdst, ldc, M, N, K, epi, s) == 0) return;
+  }
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
 #define GL(E)                                                                                                   \
   do {                                                                                                          \

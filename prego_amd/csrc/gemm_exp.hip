@@ -124,11 +124,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_256sq_kernel(
     }
 }
 
-// variant 9 = the kernel above; 12 = ping-pong, one workgroup per tile (production); 13 = ping-pong, persistent tile loop
+// variant 9 = the kernel above; 12 = the ping-pong kernel (production)
 void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C,
                                    int ldc, int M, int N, int K, hipStream_t s) {
-  if (variant == 12 || variant == 13) {
-    (void)launch_gemm_bf16_pingpong_mode(variant - 11, A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
+  if (variant == 12) {
+    (void)launch_gemm_bf16_pingpong_mode(0, A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
     return;
   }
   if (N % XBN) return;

@@ -46,19 +46,16 @@ __device__ unsigned long long g_pp_diag[8];      // diagnostic build only: cycle
 __device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
 #define PP_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
-// PERSIST (variant 13 of the measurement hook; NOT the production form): one workgroup per CU walks the tile list (stride
-// gridDim.x, a multiple of 8 so that a workgroup's XCD label stays put); the next tile's first seven half-tiles are put in
-// flight BEFORE the finished tile's C stores, and the stores are left in flight (counted vmcnt) while the next tile's K loop
-// starts.  Measured against one workgroup per tile: -4 % at K = 2048, +-1 % at K = 4096 - a wave cannot use a load that is
-// younger than its own stores (one in-order vmcnt for both), so only the first five phases of the next tile overlap the
-// store tail, and the extra control flow in the K loop costs as much.
-// OUT_BF16: C is bf16 (the inference path keeps the layer1 and W_ih projections in bf16 between the kernels: half the C bytes;
-// the store tail of a tile is bound by bytes).
-template <bool PERSIST, bool OUT_BF16>
+// EPI = what happens to acc + bias (kernels.h): EPI_STORE (fp32 C), EPI_STORE_BF16 (bf16 C: the inference path keeps the
+// layer1 and W_ih projections in bf16 between the kernels), and the Transformer path's fused epilogues EPI_RESIDUAL (fp32
+// x += .), EPI_GELU_BF16 (bf16(gelu(.))), EPI_QKV (head split into Q, K [B,h,N,dh] and V^T [B,h,dh,Npad]).  A lane holds 8
+// consecutive columns of a row, so every epilogue but V^T's is 16-byte vector accesses.
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
-    void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc) {
+    void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
   float* C = (float*)Cv;
+  constexpr bool OUT_BF16 = EPI == EPI_STORE_BF16;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A0 | A1 | B0 | B1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,8 +166,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   };
   prologue();
   PP_WAIT(10);
-  bool carry = false;        // PERSIST: the previous tile's 32 stores sit between the prologue's DMA and this tile's issues
-  for (;;) {
   bar();
   read_a(a0, 0, 0);
   if (grp == 1) bar();                                           // group 1 runs one barrier behind
@@ -184,26 +179,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 
   for (int kt = 0; kt < nk; ++kt) {
     const bool full = kt + 2 < nk;                               // every issue of this tile's phases is real
-    // the first five waits of a tile that follows another: the half-tile waited for is older than the previous tile's 32
-    // stores, the five younger half-tiles are not: 10 + 32 (vmcnt counts loads and stores together, in issue order)
-    const bool c0 = PERSIST && carry && kt == 0 && full, c1 = PERSIST && carry && kt == 1 && full;
     // phase 1
     read_b(b0, 2, kt);
     if (kt + 1 < nk) stage_a(1, kt + 1);
-    if (c0 || c1) PP_WAIT(42); else if (full) PP_WAIT(10); else PP_WAIT(0);
+    if (full) PP_WAIT(10); else PP_WAIT(0);
     bar();
     mma(acc[0][0], a0, b0);
     bar();
     // phase 2
     read_b(b1, 3, kt);
-    if (full) { stage_a(0, kt + 2); if (c0) PP_WAIT(42); else PP_WAIT(10); } else PP_WAIT(0);
+    if (full) { stage_a(0, kt + 2); PP_WAIT(10); } else PP_WAIT(0);
     bar();
     mma(acc[0][1], a0, b1);
     bar();
     // phase 3
     DS(4);
     read_a(a1, 1, kt);
-    if (full) { stage_b(0, kt + 2); DS(0); if (c0) PP_WAIT(42); else PP_WAIT(10); } else { DS(0); PP_WAIT(0); }
+    if (full) { stage_b(0, kt + 2); DS(0); PP_WAIT(10); } else { DS(0); PP_WAIT(0); }
     DS(1);
     bar();
     DS(2);
@@ -213,38 +205,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     DS(2);
     // phase 4
     if (kt + 1 < nk) read_a(a0, 0, kt + 1);
-    if (full) { stage_b(1, kt + 2); if (c0) PP_WAIT(42); else PP_WAIT(10); } else PP_WAIT(0);
+    if (full) { stage_b(1, kt + 2); PP_WAIT(10); } else PP_WAIT(0);
     bar();
     mma(acc[1][0], a1, b0);
     bar();
   }
   if (grp == 0) bar();                                           // pairs with group 1's last barrier: every LDS read of this tile has retired
 
-  // ---- next tile's prologue in flight before this tile's stores -------------------------------------------------------
   const int cm0 = m0, cn0 = n0;
-  bool has_next = false;
-  if constexpr (PERSIST) {
-    idx += gridDim.x;
-    has_next = idx < ntiles;
-    if (has_next) {
-      tile = pp_xcd_remap(idx, ntiles);
-      m0 = (tile / ntn) * PBM; n0 = (tile % ntn) * PBN;
-      set_sources(m0, n0);
-    }
-  }
   // lane (fq, fr) holds, for row tile i of quadrant (x, y): row fr, columns y*128 + wc*32 + fq*8 + j*4 + e  (j = tile, e = register)
   float4 bv[2][2];
 #pragma unroll
   for (int y = 0; y < 2; ++y)
 #pragma unroll
     for (int j = 0; j < 2; ++j) bv[y][j] = *(const float4*)(bias + cn0 + y * 128 + wc * 32 + fq * 8 + j * 4);
-  // the bias has to be IN before the next tile's DMA is issued: behind it, hipcc could only wait for it with vmcnt(0),
-  // which would drain that DMA too (an L2-hot 16-byte load: a few hundred cycles per tile, once)
-#pragma unroll
-  for (int y = 0; y < 2; ++y)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(bv[y][j].x), "+v"(bv[y][j].y), "+v"(bv[y][j].z), "+v"(bv[y][j].w));
-  if (has_next) prologue();
   // ---- epilogue: the products were taken as (B-fragment) x (A-fragment), i.e. transposed 16x16 tiles, and the B rows were
   // permuted on the way in, so a lane holds EIGHT CONSECUTIVE COLUMNS of one row of C: one 16-byte store per row in bf16,
   // two in fp32 (the store tail of a tile is bound by the number of store instructions first, by bytes second)
@@ -262,14 +236,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
         const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
         const f32x4 v0 = acc[x][y][i][0], v1 = acc[x][y][i][1];
         if (whole || m < M) {
-          if constexpr (OUT_BF16) {
+          float o[8] = {v0[0] + bv[y][0].x, v0[1] + bv[y][0].y, v0[2] + bv[y][0].z, v0[3] + bv[y][0].w,
+                        v1[0] + bv[y][1].x, v1[1] + bv[y][1].y, v1[2] + bv[y][1].z, v1[3] + bv[y][1].w};
+          if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_GELU_BF16) {
+            if constexpr (EPI == EPI_GELU_BF16) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = gelu_erf_(o[e]);
+            }
             uint4 pk;
-            pk.x = pack_bf16x2(v0[0] + bv[y][0].x, v0[1] + bv[y][0].y); pk.y = pack_bf16x2(v0[2] + bv[y][0].z, v0[3] + bv[y][0].w);
-            pk.z = pack_bf16x2(v1[0] + bv[y][1].x, v1[1] + bv[y][1].y); pk.w = pack_bf16x2(v1[2] + bv[y][1].z, v1[3] + bv[y][1].w);
-            *(uint4*)((bf16_t*)Cv + (size_t)m * ldc + n) = pk;
+            pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+            bf16_t* ob = EPI == EPI_GELU_BF16 ? (bf16_t*)epi.out_b : (bf16_t*)Cv;
+            *(uint4*)(ob + (size_t)m * ldc + n) = pk;
+          } else if constexpr (EPI == EPI_RESIDUAL) {                  // fp32 residual stream, in place
+            float4* xr = (float4*)(C + (size_t)m * ldc + n);
+            const float4 r0 = xr[0], r1 = xr[1];
+            xr[0] = make_float4(r0.x + o[0], r0.y + o[1], r0.z + o[2], r0.w + o[3]);
+            xr[1] = make_float4(r1.x + o[4], r1.y + o[5], r1.z + o[6], r1.w + o[7]);
+          } else if constexpr (EPI == EPI_QKV) {                        // 8 consecutive columns = one head, one of q / k / v
+            const int b = m / epi.n_tok, t = m - b * epi.n_tok;
+            const int which = n / epi.emb, r = n - which * epi.emb;
+            const int hd = r / epi.dh, d = r - hd * epi.dh;
+            const size_t bh = (size_t)b * epi.heads + hd;
+            if (which < 2) {
+              const float sc = which == 0 ? epi.q_scale : 1.f;
+              uint4 pk;
+              pk.x = pack_bf16x2(o[0] * sc, o[1] * sc); pk.y = pack_bf16x2(o[2] * sc, o[3] * sc);
+              pk.z = pack_bf16x2(o[4] * sc, o[5] * sc); pk.w = pack_bf16x2(o[6] * sc, o[7] * sc);
+              bf16_t* dst = which == 0 ? (bf16_t*)epi.q : (bf16_t*)epi.k;
+              *(uint4*)(dst + (bh * epi.n_tok + t) * epi.dh + d) = pk;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) ((bf16_t*)epi.vt)[(bh * epi.dh + d + e) * epi.n_pad + t] = f2bf(o[e]);
+            }
           } else {
-            *(float4*)(C + (size_t)m * ldc + n) = make_float4(v0[0] + bv[y][0].x, v0[1] + bv[y][0].y, v0[2] + bv[y][0].z, v0[3] + bv[y][0].w);
-            *(float4*)(C + (size_t)m * ldc + n + 4) = make_float4(v1[0] + bv[y][1].x, v1[1] + bv[y][1].y, v1[2] + bv[y][1].z, v1[3] + bv[y][1].w);
+            *(float4*)(C + (size_t)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4*)(C + (size_t)m * ldc + n + 4) = make_float4(o[4], o[5], o[6], o[7]);
           }
         }
         acc[x][y][i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -290,33 +291,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     }
   }
 #endif
-  if (!has_next) break;
-  // first two half-tiles of the next tile: everything but the 5 youngest half-tiles (10 DMA) and this tile's 32 stores
-  if (whole) { PP_WAIT(42); carry = true; } else { PP_WAIT(0); carry = false; }
-  }
 }
 
-// mode: 0 / 1 = one workgroup per tile (production: 1.14 vs 1.10 PFLOP/s at K = 2048, equal at K = 4096), 2 = persistent tile loop;
-// out_bf16: C is bf16 with leading dimension ldc (elements)
+__device__ float g_pp_zero_bias[8192];        // stands in for a NULL bias (the kernel's bias loads are unconditional)
+
+// C[M,N] = epilogue(A[M,K] . B[N,K]^T + bias) with the epilogue of epi.mode; bias may be NULL.  -1 = shape not supported.
+int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
+                                  int K, GemmEpi epi, hipStream_t s) {
+  if (N % PBN || K % PBK || K < 2 * PBK || N > 8192) return -1;
+  if (epi.mode == EPI_QKV && (epi.dh % 8 || epi.emb % 8)) return -1;
+  const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
+  static bool init = false;
+  static float* zero_bias = nullptr;
+  if (!init) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_GELU_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipGetSymbolAddress((void**)&zero_bias, HIP_SYMBOL(g_pp_zero_bias));
+    init = true;
+  }
+  if (!bias) bias = zero_bias;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+#define PPL(E) gemm_bf16_nt_pingpong_kernel<E><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi)
+  switch (epi.mode) {
+    case EPI_STORE: PPL(EPI_STORE); break;
+    case EPI_STORE_BF16: PPL(EPI_STORE_BF16); break;
+    case EPI_RESIDUAL: PPL(EPI_RESIDUAL); break;
+    case EPI_GELU_BF16: PPL(EPI_GELU_BF16); break;
+    default: PPL(EPI_QKV); break;
+  }
+#undef PPL
+  return 0;
+}
+
+// fp32 or bf16 C with the bias epilogue (the MiniROAD projections); bias must not be NULL here
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
                                    int M, int N, int K, bool out_bf16, hipStream_t s) {
-  if (N % PBN || K % PBK || K < 2 * PBK || bias == nullptr) return -1;
-  const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0; hipDeviceProp_t pr;
-    (void)hipGetDevice(&dev); (void)hipGetDeviceProperties(&pr, dev);
-    n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-  }
-  const int grid = (n_cu / 8) * 8;                               // 128 KB of LDS: one workgroup per CU
-  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
-  if (out_bf16) gemm_bf16_nt_pingpong_kernel<false, true><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
-  else if (mode == 2 && ntiles > grid) gemm_bf16_nt_pingpong_kernel<true, false><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
-  else gemm_bf16_nt_pingpong_kernel<false, false><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc);
-  return 0;
+  (void)mode;
+  if (bias == nullptr) return -1;
+  GemmEpi epi{};
+  epi.mode = out_bf16 ? EPI_STORE_BF16 : EPI_STORE;
+  return launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
 }
 #ifdef PP_DIAG
 void pp_diag_print() {

@@ -77,6 +77,8 @@ void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src,
 // 256x256x64 ping-pong (8-phase) kernel, csrc/gemm_pp.hip; -1 = shape not supported (N % 256, K % 64, K >= 128)
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
                                    int M, int N, int K, bool out_bf16, hipStream_t s);
+int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
+                                  int K, GemmEpi epi, hipStream_t s);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,

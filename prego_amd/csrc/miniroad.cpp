@@ -751,7 +751,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
 }
 
 // debug / microbenchmark: C[M,N] (fp32) = A[M,K] . B[N,K]^T + bias with a chosen bf16 kernel variant
-// (0 = 128x128 two-stage, 1 = 256x128 three-stage counted-vmcnt, 9 = 256x256 two-stage, 12 / 13 = ping-pong per tile / persistent), scripts/gemm_bench.py
+// (0 = 128x128 two-stage, 1 = 256x128 three-stage counted-vmcnt, 9 = 256x256 two-stage, 12 = ping-pong), scripts/gemm_bench.py
 void launch_gemm_bf16_variant(int variant, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc,
                               int M, int N, int K, hipStream_t s);
 extern "C" int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,
