@@ -298,7 +298,7 @@ __device__ float g_pp_zero_bias[8192];        // stands in for a NULL bias (the 
 // C[M,N] = epilogue(A[M,K] . B[N,K]^T + bias) with the epilogue of epi.mode; bias may be NULL.  -1 = shape not supported.
 int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
                                   int K, GemmEpi epi, hipStream_t s) {
-  if (N % PBN || K % PBK || K < 2 * PBK || N > 8192) return -1;
+  if (N % PBN || K % PBK || K < 2 * PBK || (bias == nullptr && N > 8192)) return -1;
   if (epi.mode == EPI_QKV && (epi.dh % 8 || epi.emb % 8)) return -1;
   const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
   static bool init = false;
