@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .metrics import perframe_average_precision
+from .metrics import perframe_average_precision_torch
 from .registry import EVAL
 
 
@@ -31,7 +31,7 @@ class Evaluate(nn.Module):
         if "THUMOS" in cfg["data_name"]:
             raise NotImplementedError("THUMOS post-processing is outside the PREGO datasets")
         self.metric = cfg["metric"]
-        self.eval_method = perframe_average_precision
+        self.eval_method = perframe_average_precision_torch      # same definition as the reference's sklearn path, on the device
         self.cfg = cfg
         self.all_class_names = json.load(open(cfg["video_list_path"]))[cfg["data_name"].split("_")[0]]["class_index"]
         self.max_frames_per_batch = int(cfg.get("eval_frames_per_batch", 4_000_000))
@@ -46,12 +46,12 @@ class Evaluate(nn.Module):
         flow = None if zero_flow else [b[1].to(device, non_blocking=True) for b in batch]
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
         for (r, f, target, vid), p, a in zip(batch, probs, args):
-            pv = p.cpu().numpy()
-            tv = target.numpy()
-            pred_scores += list(pv)
-            gt_targets += list(tv)
+            # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
+            # once at the end); the reference extends Python lists by one row object per frame (eval.py:46-49)
+            pred_scores.append(p)
+            gt_targets.append(target.to(p.device, non_blocking=True))
             if self.cfg["eval"] is not None:
-                output[vid] = {"pred": a.cpu().numpy().tolist(), "gt": np.argmax(tv, axis=1).tolist()}
+                output[vid] = {"pred": a.cpu().numpy().tolist(), "gt": torch.argmax(target, dim=1).numpy().tolist()}
         batch.clear()
 
     def eval(self, model, dataloader, logger, device):
@@ -86,28 +86,28 @@ class Evaluate(nn.Module):
             model.engine().check()
             if world > 1:
                 gathered = [None] * world if rank == 0 else None
-                dist.gather_object((per_video, [np.asarray(p) for p in pred_scores], [np.asarray(g) for g in gt_targets], output),
+                dist.gather_object((per_video, [p.cpu().numpy() for p in pred_scores], [g.cpu().numpy() for g in gt_targets], output),
                                    gathered, dst=0)
                 if rank != 0:
                     return float("nan")          # only rank 0 reports (main.py logs / checkpoints on rank 0)
                 chunks = []
                 output = {}
                 for pv, ps, gs, out in gathered:
-                    o = 0
-                    for p_idx, n in pv:
-                        chunks.append((p_idx, ps[o:o + n], gs[o:o + n]))
-                        o += n
+                    for (p_idx, n), pm, gm in zip(pv, ps, gs):       # one [n, C] matrix per video
+                        chunks.append((p_idx, torch.from_numpy(pm), torch.from_numpy(gm)))
                     output.update(out)
                 chunks.sort(key=lambda c: c[0])
-                pred_scores = [r for c in chunks for r in c[1]]
-                gt_targets = [r for c in chunks for r in c[2]]
+                pred_scores = [c[1] for c in chunks]
+                gt_targets = [c[2] for c in chunks]
             if self.cfg["eval"] is not None:
                 os.makedirs(self.output_dir, exist_ok=True)
                 with open(os.path.join(self.output_dir, "output_miniROAD.json"), "w") as file:
                     json.dump(output, file)
             t_end = time.time()
-            num_frames = len(gt_targets)
-            result = self.eval_method(pred_scores, gt_targets, self.all_class_names, self.data_processing, self.metric)
+            pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
+            gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
+            num_frames = int(gt_all.shape[0])
+            result = self.eval_method(pred_all, gt_all, self.all_class_names, self.data_processing, self.metric)
             time_taken = max(t_end - t_begin, 1e-9)
             self.last_fps = num_frames / time_taken
             logger.info(f"Processed {num_frames} frames in {time_taken:.1f} seconds ({self.last_fps:.1f} FPS)")
