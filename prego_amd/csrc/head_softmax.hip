@@ -24,9 +24,6 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
   const int l15 = lane & 15, l4 = lane >> 4;
   const int rbase = (blockIdx.x * 4 + wave) * 16 * HM;
   if (rbase >= nrows) return;
-#ifdef HEAD_DIAG
-  const unsigned long long hs0 = __builtin_amdgcn_s_memtime();
-#endif
   int arow[HM];
 #pragma unroll
   for (int m = 0; m < HM; ++m) { arow[m] = rbase + m * 16 + l15; if (arow[m] > nrows - 1) arow[m] = nrows - 1; }
@@ -63,9 +60,6 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
     s_arg[wave][lane] = ap ? (unsigned long long)(ap + t) : 0ull;
   }
 
-#ifdef HEAD_DIAG
-  const unsigned long long hs1 = __builtin_amdgcn_s_memtime();
-#endif
   f32x4 acc[HM][NTC];
 #pragma unroll
   for (int m = 0; m < HM; ++m)
@@ -73,45 +67,17 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
     for (int j = 0; j < NTC; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if constexpr (BF) {
-    // double-buffered over k (two steps per loop iteration, statically indexed buffers): the fragments of step k+1 are
-    // requested before the MFMAs of step k, so a wave keeps one step of loads in flight instead of waiting out every round trip
     const bf16_t* bp = (const bf16_t*)Wc + (size_t)l15 * HID + 8 * l4;
-    const bf16_t* ap[HM];
+    for (int k = 0; k < HID; k += 32) {
+      bf16x8 af[HM];
 #pragma unroll
-    for (int m = 0; m < HM; ++m) ap[m] = (const bf16_t*)Hrelu + (size_t)arow[m] * HID + 8 * l4;
-    bf16x8 a0[HM], a1[HM], b0[NTC], b1[NTC];
-    auto ld = [&](bf16x8 (&af)[HM], bf16x8 (&bf)[NTC], int k) {
+      for (int m = 0; m < HM; ++m) af[m] = *(const bf16x8*)((const bf16_t*)Hrelu + (size_t)arow[m] * HID + 8 * l4 + k);
 #pragma unroll
-      for (int m = 0; m < HM; ++m) af[m] = *(const bf16x8*)(ap[m] + k);
+      for (int j = 0; j < NTC; ++j) {
+        const bf16x8 bfr = *(const bf16x8*)(bp + (size_t)j * 16 * HID + k);
 #pragma unroll
-      for (int j = 0; j < NTC; ++j) bf[j] = *(const bf16x8*)(bp + (size_t)j * 16 * HID + k);
-    };
-    auto mm = [&](const bf16x8 (&af)[HM], const bf16x8 (&bf)[NTC]) {
-#pragma unroll
-      for (int j = 0; j < NTC; ++j)
-#pragma unroll
-        for (int m = 0; m < HM; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bf[j], acc[m][j], 0, 0, 0);
-    };
-    // hipcc's own waitcnt placement drains the loads just issued (vmcnt(5..0) in front of the MFMAs of the OLDER buffer), which
-    // undoes the double buffering: the waits are written by hand (loads retire in order: vmcnt(HM + NTC) = "everything but the
-    // buffer requested last") and the ready buffer is laundered through an empty asm so that the compiler adds none of its own
-    auto ready = [&](bf16x8 (&af)[HM], bf16x8 (&bf)[NTC]) {
-#pragma unroll
-      for (int m = 0; m < HM; ++m) asm volatile("" : "+v"(af[m]));
-#pragma unroll
-      for (int j = 0; j < NTC; ++j) asm volatile("" : "+v"(bf[j]));
-    };
-    ld(a0, b0, 0);
-    for (int k = 0; k < HID; k += 64) {          // HID % 64 == 0 (checked by the host: hid == 1024)
-      ld(a1, b1, k + 32);
-      __builtin_amdgcn_s_waitcnt(0x0F70 | ((HM + NTC) & 15) | ((((HM + NTC) >> 4) & 3) << 14));   // vmcnt(HM + NTC), others untouched
-      ready(a0, b0);
-      mm(a0, b0);
-      ld(a0, b0, k + 64 < HID ? k + 64 : HID - 32);      // unconditional (the last one re-reads a valid step and is ignored): a
-                                                          // conditional load makes hipcc drain everything at the loop head
-      __builtin_amdgcn_s_waitcnt(0x0F70 | ((HM + NTC) & 15) | ((((HM + NTC) >> 4) & 3) << 14));
-      ready(a1, b1);
-      mm(a1, b1);
+        for (int m = 0; m < HM; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][j], 0, 0, 0);
+      }
     }
   } else {
     const float* bp = (const float*)Wc + (size_t)l15 * HID + 4 * l4;
@@ -133,10 +99,6 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
     }
   }
 
-#ifdef HEAD_DIAG
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned long long hs2 = __builtin_amdgcn_s_memtime();
-#endif
   // lane holds, for rows r = m*16 + l4*4 + e (e = 0..3), columns c = j*16 + l15
 #pragma unroll
   for (int m = 0; m < HM; ++m)
@@ -188,9 +150,6 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
       }
     }
   }
-#ifdef HEAD_DIAG
-  if (blockIdx.x == 7 && threadIdx.x == 0) { const unsigned long long hs3 = __builtin_amdgcn_s_memtime(); printf("head diag cycles: lookup %llu, k loop %llu, epilogue %llu\n", hs1 - hs0, hs2 - hs1, hs3 - hs2); }
-#endif
 }
 
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
