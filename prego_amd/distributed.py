@@ -24,6 +24,7 @@ def init_from_env(backend: str | None = None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
