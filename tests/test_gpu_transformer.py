@@ -87,3 +87,47 @@ def test_noncausal_attention_vs_oracle_ragged_length():
     args = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
     out = attention_layer(torch.from_numpy(x).cuda(), *args, n_heads=8, mask_flag=False).cpu().numpy()
     assert np.abs(out - ref).max() < 1e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_vit_large_batch_uses_the_pingpong_epilogues_and_matches():
+    """40 windows = 5 160 token rows: above the 4 096-row switch, so the QKV-split, residual and GELU epilogues run on the 256x256
+    ping-pong kernel.  Windows 0-1 are the reference fixture's inputs (G5); every window must also agree with the same window
+    pushed through the small-batch path (128x128 kernel epilogues)."""
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    g = np.load(os.path.join(G, "g5_vit_forward.npz"))
+    cfg = _vit_cfg()
+    m = build_model(cfg, "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.vit_state_dict(cfg, 20).items()})
+    m.eval()
+    B = 40
+    rgb = torch.from_numpy(W.tsn_features((B, 128, 2048), 23, "big.rgb")).cuda()
+    flow = torch.from_numpy(W.tsn_features((B, 128, 2048), 23, "big.flow")).cuda()
+    rgb[:2] = torch.from_numpy(W.tsn_features((2, 128, 2048), 20, "g5.rgb")).cuda()
+    flow[:2] = torch.from_numpy(W.tsn_features((2, 128, 2048), 20, "g5.flow")).cuda()
+    with torch.no_grad():
+        big = m(rgb, flow)["logits"].cpu().numpy()
+        small = np.concatenate([m(rgb[i:i + 2], flow[i:i + 2])["logits"].cpu().numpy() for i in range(0, B, 2)])
+    scale = max(1.0, np.abs(g["logits"]).max())
+    assert np.abs(big[:2] - g["logits"]).max() < 1e-2 * scale
+    assert np.array_equal(big[:2].argmax(-1), g["logits"].argmax(-1))
+    assert np.abs(big - small).max() < 2e-3 * scale, np.abs(big - small).max()      # same math, different kernels / summation tiling
+
+
+def test_causal_attention_layer_large_batch_matches_per_sample():
+    """B = 5 x L = 1024 = 5 120 rows: the projections run on the ping-pong kernel (QKV epilogue); sample 0 is the G6 fixture input"""
+    from prego_amd.transformer import attention_layer
+    L = 1024
+    g = np.load(os.path.join(G, f"g6_causal_attention_L{L}.npz"))
+    sd = W.attention_layer_state_dict(2048, 20)
+    x = W.normal((5, L, 2048), 24, "big.x")
+    x[0] = W.normal((1, L, 2048), 20, f"g6.x.{L}")[0]
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    args = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
+    xt = torch.from_numpy(x).cuda()
+    out = attention_layer(xt, *args, n_heads=8, mask_flag=True).cpu().numpy()
+    scale = max(1.0, np.abs(g["out"]).max())
+    assert np.abs(out[0][g["rows"]] - g["out"]).max() < 1e-2 * scale
+    for b in (1, 4):
+        one = attention_layer(xt[b:b + 1], *args, n_heads=8, mask_flag=True)[0].cpu().numpy()
+        assert np.abs(out[b] - one).max() < 2e-3 * scale, (b, np.abs(out[b] - one).max())
