@@ -119,6 +119,10 @@ class ViTEnc(nn.Module):
         return lib, dev
 
     def forward(self, sequence_input_rgb, sequence_input_flow):
+        if self.training and torch.is_grad_enabled():
+            # the HIP path of the Transformer model is forward only; failing here beats a loss that
+            # silently has no graph
+            raise PregoError("ViTEnc: training is not implemented on the HIP path (forward / eval only); call .eval() or torch.no_grad()")
         lib, dev = self._handle()
         rgb = sequence_input_rgb.float().contiguous() if self.use_rgb else None
         flow = sequence_input_flow.float().contiguous() if self.use_flow else None
