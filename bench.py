@@ -22,9 +22,6 @@ sys.path.insert(0, ROOT)
 # multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails with hipIpcGetMemHandle: invalid argument)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-
 FLOP_PER_FRAME = 2 * (4096 * 2048 + 2048 * 3072 + 1024 * 3072 + 1024 * 86)     # 35 827 712
 GEMM_FLOP_PER_FRAME = 2 * (4096 * 2048 + 2048 * 3072)                          # the two dense projections
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
@@ -34,6 +31,11 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="assembly101", choices=["assembly101", "synth512"],
+                    help="assembly101 = BASELINE configs[1] (the metric's config); synth512 = configs[4] per-GPU share "
+                         "(512 clips x 512 frames, zero flow)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (train step, ViTEnc, causal attention, fp32 mode)")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU work): checks the N-rank launch path on a CPU box")
     ap.add_argument("--steps", type=int, default=10)      # >= 10 timed runs
     ap.add_argument("--warmup", type=int, default=3)     # ... after 3 warm-ups
     ap.add_argument("--clips", type=int, default=0, help="override clip count (debug)")
@@ -46,13 +48,56 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a CHILD
+    process and return its exit code.  This parent has not imported torch and never touches the GPU (a process that has
+    initialised HIP must not exec or fork GPU work on this pool)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without RANK in the environment: launching {args.gpus} ranks: {' '.join(cmd)}",
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
+def dry_run(args, rank, world):
+    """launch-path check without a GPU: gloo rendezvous, barrier, max-over-ranks reduction, one JSON line from rank 0"""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    print(f"[bench] rank {rank}: dist.get_world_size() = {dist.get_world_size()}", file=sys.stderr, flush=True)
+    assert dist.get_world_size() == world == args.gpus and float(t.item()) == world
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "dry_run": True}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the rank count must equal --gpus")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    global np, torch
+    import numpy as np
+    import torch
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -78,7 +123,11 @@ def main():
     if args.rows_per_chunk:
         eng.rows_per_chunk = args.rows_per_chunk
 
-    lens = assembly101_eval_lengths(seed=20 + rank)
+    synth = args.workload == "synth512"
+    if synth:       # BASELINE configs[4]: 4096 clips x 512 frames over 8 GPUs = 512 clips per GPU; the flow half is zeros and is
+        lens = [512] * 512      # never materialised, so the zero-flow fast path IS this workload
+    else:
+        lens = assembly101_eval_lengths(seed=20 + rank)
     if args.clips:
         lens = lens[: args.clips]
     lens = [max(1, int(l * args.len_scale)) for l in lens]
@@ -87,7 +136,7 @@ def main():
     gen.manual_seed(1234 + rank)
     # TSN-like non-negative features, generated on device; inputs are resident in HBM before the timed region
     rgb = [torch.randn((T, 2048), device=dev, generator=gen).clamp_(min=0) for T in lens]
-    flow = [torch.randn((T, 2048), device=dev, generator=gen).clamp_(min=0) for T in lens]
+    flow = None if synth else [torch.randn((T, 2048), device=dev, generator=gen).clamp_(min=0) for T in lens]
 
     def step(flow_arg):
         return eng.forward_ragged(rgb, flow_arg, softmax=True, want_out=True, want_argmax=True)
@@ -124,7 +173,7 @@ def main():
     value = world * frames * args.steps / dt
 
     extra = {}
-    if not args.no_zero_flow:
+    if not args.no_zero_flow and not synth:
         # the shipped Assembly101-O config zeroes the flow half (datasets/dataset.py:69); skipping its half of layer1's K is
         # exact.  Reported beside `value`, never as `value`.
         for _ in range(max(1, args.warmup)):
@@ -170,12 +219,17 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: Assembly101-O-test-split-shaped eval set, MiniROAD eval path "
-                                   "(rgb+flow fp32 [T,2048] each -> per-frame probs[86] + argmax)",
-                       "clips_per_gpu": len(lens), "frames_per_gpu": frames, "min_T": min(lens), "max_T": max(lens),
-                       "lengths": "seeded draw from the Epic-tent-O length distribution (real Assembly101-O lengths unknown)",
-                       "flow": "non-zero (full K=4096 layer1 GEMM)", "parallelism": f"clip-sharded dp{world}, no collective",
-                       "weights": "random init, seed 20"},
+            "config": ({"workload": "BASELINE configs[4] per-GPU share: synthetic 512 clips x 512 frames x 2048-d rgb (4096 clips over 8 "
+                                    "GPUs), MiniROAD eval path -> per-frame probs[86] + argmax",
+                        "clips_per_gpu": len(lens), "frames_per_gpu": frames, "min_T": min(lens), "max_T": max(lens),
+                        "flow": "zeros, not materialised (flow half of layer1's K skipped: exact)",
+                        "parallelism": f"clip-sharded dp{world}, no collective", "weights": "random init, seed 20"} if synth else
+                       {"workload": "BASELINE configs[1]: Assembly101-O-test-split-shaped eval set, MiniROAD eval path "
+                                    "(rgb+flow fp32 [T,2048] each -> per-frame probs[86] + argmax)",
+                        "clips_per_gpu": len(lens), "frames_per_gpu": frames, "min_T": min(lens), "max_T": max(lens),
+                        "lengths": "seeded draw from the Epic-tent-O length distribution (real Assembly101-O lengths unknown)",
+                        "flow": "non-zero (full K=4096 layer1 GEMM)", "parallelism": f"clip-sharded dp{world}, no collective",
+                        "weights": "random init, seed 20"}),
             # the kernel with the largest share of the timed region; every kernel's own roofline is under "rooflines"
             "roofline": dominant,
             "rooflines": {"gemm": rl_gemm, "gru_recurrence": rl_gru, "pack": rl_pack},
@@ -183,12 +237,114 @@ def main():
             "output_sane": ok,
         }
         line.update(extra)
+        if not args.no_secondary and world == 1 and not synth and args.dtype == "bf16":
+            del rgb, flow, out
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary(dev, lens, sd)
+            line["value_fp32"] = line["secondary"].get("value_fp32")
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(sd, lens, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _time_ms(fn, n=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def secondary(dev, lens, sd):
+    """Secondary paths of SURVEY section 8, measured in the same run (rank 0, N = 1; not the headline metric):
+    BASELINE configs[2] shape on one GPU (train step 16 x 128: fwd + OadLoss + BPTT + AdamW), the `Transformer` (ViTEnc)
+    forward at 256 windows of 128 frames, BASELINE configs[3]'s long-window causal AttentionLayer (B = 16, L = 1024), and the
+    headline pass with fp32 MFMA operands (the reference's own precision)."""
+    from prego_amd import weights as W
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.registry import build_criterion, build_model
+    import prego_amd.loss  # noqa: F401
+    import prego_amd.transformer  # noqa: F401
+    from prego_amd.transformer import attention_layer
+    res = {}
+    # ---- train step (a10)
+    cfg = assembly101_cfg(compute_dtype="bf16")
+    m = build_model(cfg, dev)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    crit = build_criterion(cfg, dev)
+    opt = torch.optim.AdamW([{"params": m.parameters(), "initial_lr": 1e-4}], lr=1e-4, weight_decay=0.05)
+    B, T = 16, 128
+    rgb = torch.randn(B, T, 2048, device=dev).clamp_(min=0)
+    flow = torch.randn(B, T, 2048, device=dev).clamp_(min=0)
+    tgt = torch.zeros(B, T, 86, device=dev)
+    tgt[:, :, 3] = 1
+
+    def train_step():
+        m.train()
+        loss = crit(m(rgb, flow), tgt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    ms = _time_ms(train_step)
+    m.engine().check()
+    fl = 3.0 * B * T * FLOP_PER_FRAME
+    res["train_step_ms"] = ms
+    res["train_step"] = {"shape": "B=16 x T=128 (configs/miniroad_assembly101-O.yaml), fwd + OadLoss + BPTT + AdamW, dropout 0.2, rgb+flow",
+                         "ms": ms, "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                                "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
+                                                "note": "3 x forward FLOPs over the whole step; 128 sequential BPTT steps: latency-bound"}}
+    del m, opt, crit
+    # ---- ViTEnc forward (a11, a13, a14)
+    vcfg = assembly101_cfg(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0)
+    vm = build_model(vcfg, dev)
+    vm.load_state_dict({k: torch.from_numpy(v) for k, v in W.vit_state_dict(vcfg, 20).items()})
+    vm.eval()
+    Bv = 256
+    xr = torch.randn(Bv, 128, 2048, device=dev)
+    xf = torch.randn(Bv, 128, 2048, device=dev)
+    with torch.no_grad():
+        ms = _time_ms(lambda: vm(xr, xf))
+    fl = Bv * 7.69e9
+    res["vit_windows_per_s"] = Bv / ms * 1e3
+    res["vit"] = {"shape": "256 windows x 128 frames, heads 8, 1 layer", "ms": ms,
+                  "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "SURVEY 8d: 7.69 GFLOP per window (algorithmic)"}}
+    del vm, xr, xf
+    # ---- causal AttentionLayer (a12, BASELINE configs[3])
+    sdA = W.attention_layer_state_dict(2048, 20)
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    wargs = [torch.from_numpy(sdA[n + s]).to(dev) for n in names for s in (".weight", ".bias")]
+    Bc, L = 16, 1024
+    x = torch.randn(Bc, L, 2048, device=dev)
+    ms = _time_ms(lambda: attention_layer(x, *wargs, n_heads=8, mask_flag=True))
+    fl = Bc * (2 * L * 2048 * 2048 * 4 + 4 * 8 * L * L * 256 / 2)
+    res["causal_attn_ms"] = ms
+    res["causal_attn"] = {"shape": "B=16, L=1024, d_model=2048, 8 heads (Epic-tent-O long window)", "ms": ms,
+                          "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "4 projections + causal QK^T/AV (half the square)"}}
+    del x
+    torch.cuda.empty_cache()
+    # ---- the headline pass with fp32 operands (exact-fp32 MFMA: 157 TFLOP/s peak), one warm-up + two timed passes
+    cfg32 = assembly101_cfg(compute_dtype="fp32")
+    m32 = build_model(cfg32, dev)
+    m32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m32.eval()
+    eng = m32.engine()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    rgb = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
+    flow = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
+    ms = _time_ms(lambda: eng.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True), n=2, warm=1)
+    eng.check()
+    res["value_fp32"] = sum(lens) / ms * 1e3
+    res["fp32_pass_ms"] = ms
+    return res
 
 
 def cpu_baseline(sd, lens, budget_s):

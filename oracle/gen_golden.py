@@ -312,7 +312,113 @@ def g8():
         json.dump({"shipped_equals_rerun": rerun == shipped}, f)
 
 
-GROUPS = {"g1": g1_g2_g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8}
+def _grad_summary(model, save, n=256):
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.numpy().reshape(-1)
+        idx = np.linspace(0, g.size - 1, min(n, g.size)).astype(np.int64)
+        save["norm." + k] = np.float64(np.linalg.norm(g.astype(np.float64)))
+        save["idx." + k] = idx
+        save["val." + k] = g[idx].copy()
+
+
+def g4c():
+    """Training step at the REAL shape of configs/miniroad_assembly101-O.yaml: B = 16 windows x T = 128 frames, full dims,
+    rgb + non-zero flow, dropout 0 (torch's mask stream cannot be matched): loss + per-tensor grad norms + 256 sampled
+    entries per tensor (trainer/train.py:20-23, 128 BPTT steps)."""
+    from model import build_model
+    from criterions import build_criterion
+    cfg = assembly101_cfg(dropout=0.0)
+    sd = W.miniroad_state_dict(cfg, seed=20)
+    model = _load(build_model(cfg, "cpu"), sd).train()
+    crit = build_criterion(cfg, "cpu")
+    B, T = 16, 128
+    rgb = W.tsn_features((B, T, 2048), 20, "g4c.rgb")
+    flow = W.tsn_features((B, T, 2048), 20, "g4c.flow")
+    tgt = make_targets(B, T, 86, 20, "g4c.tgt")
+    out = model(torch.from_numpy(rgb), torch.from_numpy(flow))
+    loss = crit(out, torch.from_numpy(tgt))
+    loss.backward()
+    save = {"loss": np.float64(float(loss)), "logits_last": out["logits"][:, -1, :].detach().numpy().copy()}
+    _grad_summary(model, save)
+    np.savez_compressed(os.path.join(OUT, "g4c_miniroad_train_16x128.npz"), **save)
+    print("g4c loss", float(loss))
+
+
+def g5b():
+    """ViTEnc with num_layers = 2 (every row of layer 1 reaches the logits through layer 2's attention) and the TRAINING step of
+    the `Transformer` registry entry: OadLoss on the [B,1,C] logits (criterions/loss.py:15-21), loss.backward(): loss +
+    per-tensor grad norms + sampled entries, for 1 and 2 layers, window 128, B = 2, all dropouts 0."""
+    from model import build_model
+    from criterions import build_criterion
+    B, T = 2, 128
+    rgb = W.tsn_features((B, T, 2048), 20, "g5.rgb")
+    flow = W.tsn_features((B, T, 2048), 20, "g5.flow")
+    tgt = make_targets(B, T, 86, 20, "g5b.tgt")
+    for layers in (1, 2):
+        cfg = dict(_vit_cfg(), num_layers=layers)
+        sd = W.vit_state_dict(cfg, seed=20)
+        model = _load(build_model(cfg, "cpu"), sd).eval()
+        with torch.no_grad():
+            logits = model(torch.from_numpy(rgb), torch.from_numpy(flow))["logits"].numpy()
+        model.train()
+        crit = build_criterion(cfg, "cpu")
+        out = model(torch.from_numpy(rgb), torch.from_numpy(flow))
+        loss = crit(out, torch.from_numpy(tgt))
+        loss.backward()
+        save = {"logits": logits, "loss": np.float64(float(loss))}
+        _grad_summary(model, save)
+        np.savez_compressed(os.path.join(OUT, f"g5b_vit_train_L{layers}.npz"), **save)
+        print("g5b layers", layers, "loss", float(loss), "logits", float(np.abs(logits).max()))
+
+
+def g9():
+    """Feeder (datasets/dataset.py:24-135) on a synthetic 2-video Epic-tent-O-shaped tree written to a temp dir: the window
+    list of train mode (front pad window_size-1, stride 4, np.random phase), the whole-video items of test mode, and two
+    sample items per mode.  The tree itself is regenerated from seeds by tests (prego_amd.weights), only outputs are stored."""
+    from datasets import build_data_loader  # noqa: F401  (registers)
+    from datasets.dataset_builder import DATA_LAYERS
+    tmp = tempfile.mkdtemp()
+    try:
+        lens = {"vidA": 300, "vidB": 157}
+        C = 12
+        for sub in ("target_perframe", "rgb_anet_resnet50", "rgb_as_flow/rgb_anet_resnet50"):
+            os.makedirs(os.path.join(tmp, sub))
+        for vid, T in lens.items():
+            rgb = W.tsn_features((T, 2048), 20, f"g9.rgb.{vid}")
+            tgt = np.zeros((T, C), np.float32)
+            tgt[np.arange(T), (np.arange(T) // 29) % C] = 1.0
+            np.save(os.path.join(tmp, "rgb_anet_resnet50", vid + ".npy"), rgb)
+            np.save(os.path.join(tmp, "rgb_as_flow/rgb_anet_resnet50", vid + ".npy"), rgb)
+            np.save(os.path.join(tmp, "target_perframe", vid + ".npy"), tgt)
+        vl = os.path.join(tmp, "video_list.json")
+        json.dump({"EPIC-TENT-O": {"train_session_set": ["vidA", "vidB"], "test_session_set": ["vidB", "vidA"]}}, open(vl, "w"))
+        cfg = epic_tent_cfg(root_path=tmp, video_list_path=vl)
+        save = {}
+        for mode in ("train", "test"):
+            np.random.seed(20)
+            ds = DATA_LAYERS[cfg["data_name"]](cfg, mode)
+            wins = [(it[0], int(it[1]), int(it[2])) for it in ds.inputs]
+            save[f"{mode}.vids"] = np.array([w[0] for w in wins])
+            save[f"{mode}.start"] = np.array([w[1] for w in wins], np.int64)
+            save[f"{mode}.end"] = np.array([w[2] for w in wins], np.int64)
+            for j in (0, len(ds) - 1):
+                r, f, t, vid, s_, e_ = ds[j]
+                save[f"{mode}.item{j}.rgb_sum"] = np.float64(r.double().sum().item())
+                save[f"{mode}.item{j}.rgb_rows"] = r.numpy()[[0, -1]][:, :16].copy()
+                save[f"{mode}.item{j}.flow_abs_sum"] = np.float64(f.double().abs().sum().item())
+                save[f"{mode}.item{j}.target_argmax"] = t.numpy().argmax(1).astype(np.int64)
+                save[f"{mode}.item{j}.target_rowsum"] = t.numpy().sum(1)
+                save[f"{mode}.item{j}.meta"] = np.array([str(vid), str(int(s_)), str(int(e_)), str(tuple(r.shape)), str(r.dtype), str(f.dtype), str(t.dtype)])
+            save[f"{mode}.len"] = np.int64(len(ds))
+        np.savez_compressed(os.path.join(OUT, "g9_feeder.npz"), **save)
+        print("g9 train windows", int(save["train.len"]), "test items", int(save["test.len"]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+GROUPS = {"g1": g1_g2_g3, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

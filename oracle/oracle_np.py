@@ -51,10 +51,14 @@ def layernorm(x, gamma, beta, eps=LN_EPS):
     return (x - mu) / np.sqrt(var + eps) * gamma + beta
 
 
+def _erf(x):
+    from scipy.special import erf          # vectorised; np.vectorize(math.erf) is 100x slower on [B,N,mlp] tensors
+    return erf(x)
+
+
 def gelu_erf(x):
     """nn.GELU() default = exact erf form (Transformer.py:40)."""
-    erf = np.vectorize(math.erf, otypes=[x.dtype])
-    return 0.5 * x * (1.0 + erf(x / math.sqrt(2.0)))
+    return 0.5 * x * (1.0 + _erf(x / math.sqrt(2.0)))
 
 
 def linear(x, w, b=None):
@@ -284,6 +288,103 @@ def vit_forward(sd, rgb, flow, heads, num_layers=1, dt=np.float64, causal=False,
     out = {"logits": logits}
     out.update(inter)
     return out
+
+
+def _ln_bwd(dy, x, gamma):
+    """backward of layernorm(x, gamma, beta): returns (dx, dgamma, dbeta)"""
+    mu = x.mean(axis=-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(axis=-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + LN_EPS)
+    xh = (x - mu) * rstd
+    red = tuple(range(x.ndim - 1))
+    dg = (dy * xh).sum(axis=red)
+    db = dy.sum(axis=red)
+    dxh = dy * gamma
+    dx = rstd * (dxh - dxh.mean(axis=-1, keepdims=True) - xh * (dxh * xh).mean(axis=-1, keepdims=True))
+    return dx, dg, db
+
+
+def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64, causal=False):
+    """Training step of the `Transformer` registry entry by hand: ViTEnc.forward (ViT.py:117-143, dropouts 0), OadLoss on the
+    [B,1,C] logits (loss.py:15-34: logits[:, -1] is the only row, target[:, -1] the last frame's label), and the full backward
+    through the head, the final LayerNorm (token 0 only), every pre-norm block (Transformer.py:60-77: FFN with exact-erf GELU,
+    SelfAttention of Attention.py:21-41), the learned positional table, the cls token (appended at the END, ViT.py:128) and the
+    encoding Linear.  Returns (loss, logits [B,1,C], grads keyed like the state_dict)."""
+    p = {k: np.asarray(v, dtype=dt) for k, v in sd.items() if k != "position_encoding.position_ids"}
+    X = np.asarray(rgb, dtype=dt)
+    if flow is not None:
+        X = np.concatenate([X, np.asarray(flow, dtype=dt)], axis=2)
+    B, T, _ = X.shape
+    E = p["linear_encoding.weight"].shape[0]
+    N, dh = T + 1, E // heads
+    scale = dh ** -0.5
+    x = linear(X, p["linear_encoding.weight"], p["linear_encoding.bias"])
+    x = np.concatenate([x, np.broadcast_to(p["cls_token"].reshape(1, 1, E), (B, 1, E))], axis=1)
+    x = x + p["position_encoding.pe.weight"][None, :N]
+    cache = []
+    for l in range(num_layers):
+        a_, f_ = 2 * l, 2 * l + 1
+        c = {"x_in": x}
+        xn = layernorm(x, p[f"encoder.net.{a_}.fn.norm.weight"], p[f"encoder.net.{a_}.fn.norm.bias"])
+        qkv = linear(xn, p[f"encoder.net.{a_}.fn.fn.qkv.weight"]).reshape(B, N, 3, heads, dh).transpose(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        sc = np.einsum("bhid,bhjd->bhij", q, k) * scale
+        if causal:
+            sc = np.where(np.triu(np.ones((N, N), dtype=bool), 1), -np.inf, sc)
+        att = softmax(sc)
+        o = np.einsum("bhij,bhjd->bhid", att, v).transpose(0, 2, 1, 3).reshape(B, N, E)
+        x = x + linear(o, p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.proj.bias"])
+        c.update(xn=xn, q=q, k=k, v=v, att=att, o=o, x_mid=x)
+        xn2 = layernorm(x, p[f"encoder.net.{f_}.fn.norm.weight"], p[f"encoder.net.{f_}.fn.norm.bias"])
+        u = linear(xn2, p[f"encoder.net.{f_}.fn.fn.net.0.weight"], p[f"encoder.net.{f_}.fn.fn.net.0.bias"])
+        f = gelu_erf(u)
+        x = x + linear(f, p[f"encoder.net.{f_}.fn.fn.net.3.weight"], p[f"encoder.net.{f_}.fn.fn.net.3.bias"])
+        c.update(xn2=xn2, u=u, f=f)
+        cache.append(c)
+    xf0 = layernorm(x[:, 0], p["pre_head_ln.weight"], p["pre_head_ln.bias"])
+    logits = linear(xf0, p["mlp_head.weight"], p["mlp_head.bias"])[:, None, :]
+    tgt = np.asarray(target, dtype=dt)
+    loss = oad_loss(logits, tgt)
+    dlog = oad_loss_grad(logits, tgt)[:, 0, :]
+    g = {}
+    g["mlp_head.weight"] = dlog.T @ xf0
+    g["mlp_head.bias"] = dlog.sum(axis=0)
+    d0, g["pre_head_ln.weight"], g["pre_head_ln.bias"] = _ln_bwd(dlog @ p["mlp_head.weight"], x[:, 0], p["pre_head_ln.weight"])
+    dx = np.zeros_like(x)
+    dx[:, 0] = d0
+    for l in range(num_layers - 1, -1, -1):
+        a_, f_ = 2 * l, 2 * l + 1
+        c = cache[l]
+        w2, w1 = p[f"encoder.net.{f_}.fn.fn.net.3.weight"], p[f"encoder.net.{f_}.fn.fn.net.0.weight"]
+        g[f"encoder.net.{f_}.fn.fn.net.3.weight"] = np.einsum("bne,bnm->em", dx, c["f"])
+        g[f"encoder.net.{f_}.fn.fn.net.3.bias"] = dx.sum(axis=(0, 1))
+        u = c["u"]
+        dgelu = 0.5 * (1.0 + _erf(u / math.sqrt(2.0))) + u * np.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+        du = (dx @ w2) * dgelu
+        g[f"encoder.net.{f_}.fn.fn.net.0.weight"] = np.einsum("bnm,bne->me", du, c["xn2"])
+        g[f"encoder.net.{f_}.fn.fn.net.0.bias"] = du.sum(axis=(0, 1))
+        dxa, g[f"encoder.net.{f_}.fn.norm.weight"], g[f"encoder.net.{f_}.fn.norm.bias"] = _ln_bwd(
+            du @ w1, c["x_mid"], p[f"encoder.net.{f_}.fn.norm.weight"])
+        dx = dx + dxa
+        wp, wq = p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.qkv.weight"]
+        g[f"encoder.net.{a_}.fn.fn.proj.weight"] = np.einsum("bne,bnd->ed", dx, c["o"])
+        g[f"encoder.net.{a_}.fn.fn.proj.bias"] = dx.sum(axis=(0, 1))
+        do = (dx @ wp).reshape(B, N, heads, dh).transpose(0, 2, 1, 3)
+        dv = np.einsum("bhij,bhid->bhjd", c["att"], do)
+        da = np.einsum("bhid,bhjd->bhij", do, c["v"])
+        ds = c["att"] * (da - (da * c["att"]).sum(axis=-1, keepdims=True))
+        dq = np.einsum("bhij,bhjd->bhid", ds, c["k"]) * scale
+        dk = np.einsum("bhij,bhid->bhjd", ds, c["q"]) * scale
+        dqkv = np.stack([dq, dk, dv], axis=0).transpose(1, 3, 0, 2, 4).reshape(B, N, 3 * E)
+        g[f"encoder.net.{a_}.fn.fn.qkv.weight"] = np.einsum("bnj,bne->je", dqkv, c["xn"])
+        dxa, g[f"encoder.net.{a_}.fn.norm.weight"], g[f"encoder.net.{a_}.fn.norm.bias"] = _ln_bwd(
+            dqkv @ wq, c["x_in"], p[f"encoder.net.{a_}.fn.norm.weight"])
+        dx = dx + dxa
+    g["position_encoding.pe.weight"] = dx.sum(axis=0)
+    g["cls_token"] = dx[:, N - 1].sum(axis=0).reshape(1, 1, E)
+    g["linear_encoding.weight"] = np.einsum("bte,btd->ed", dx[:, :T], X)
+    g["linear_encoding.bias"] = dx[:, :T].sum(axis=(0, 1))
+    return loss, logits, g
 
 
 # --------------------------------------------------------------------------- #

@@ -347,11 +347,8 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
 #define GL(E)                                                                                                   \
   do {                                                                                                          \
-    static bool attr_set = false;                                                                               \
-    if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); \
-      attr_set = true;                                                                                          \
-    }                                                                                                           \
+    static DeviceOnce once;                                                                                     \
+    once.run([] { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, E>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); }); \
     gemm_bf16_nt_kernel<float, E><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi); \
   } while (0)
   switch (epi.mode) {
@@ -373,11 +370,8 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
     return;
   }
   if (M >= 2048 && !no_big) {            // enough 256-row tiles to fill the chip
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GSTAGE);
-      attr_set = true;
-    }
+    static DeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GSTAGE); });
     const int ntm = (M + GBM - 1) / GBM, ntn = N / BN;
     gemm_bf16_nt_big_kernel<<<ntm * ntn, 512, 3 * GSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
     return;

@@ -132,11 +132,8 @@ void launch_gemm_bf16_experimental(int variant, const void* A, int lda, const vo
     return;
   }
   if (N % XBN) return;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE);
-    attr_set = true;
-  }
+  static DeviceOnce once;
+  once.run([] { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_256sq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XSTAGE); });
   const int ntm = (M + XBM - 1) / XBM, ntn = N / XBN;
   gemm_bf16_nt_256sq_kernel<<<ntm * ntn, 512, 2 * XSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
 }

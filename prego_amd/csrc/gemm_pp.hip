@@ -301,18 +301,20 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
   if (N % PBN || K % PBK || K < 2 * PBK || (bias == nullptr && N > 8192)) return -1;
   if (epi.mode == EPI_QKV && (epi.dh % 8 || epi.emb % 8)) return -1;
   const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
-  static bool init = false;
-  static float* zero_bias = nullptr;
-  if (!init) {
+  static DeviceOnce once;
+  static float* zero_bias[64] = {nullptr};
+  const int dev = once.run([&] {
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_GELU_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
-    (void)hipGetSymbolAddress((void**)&zero_bias, HIP_SYMBOL(g_pp_zero_bias));
-    init = true;
-  }
-  if (!bias) bias = zero_bias;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    if (d >= 0 && d < 64) (void)hipGetSymbolAddress((void**)&zero_bias[d], HIP_SYMBOL(g_pp_zero_bias));
+  });
+  if (!bias) bias = zero_bias[dev];
+  if (!bias) return -1;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
 #define PPL(E) gemm_bf16_nt_pingpong_kernel<E><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi)
   switch (epi.mode) {

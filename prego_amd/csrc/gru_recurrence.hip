@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef GRU_PRIO
+  // the recurrence is the latency-critical path of a pass: its waves win every issue arbitration against co-resident
+  // feed-forward waves (one extra wave per SIMD fits beside the 312 registers of this kernel)
+  __builtin_amdgcn_s_setprio(GRU_PRIO);
+#endif
   // ---- placement rendezvous: group := XCD when every XCD holds exactly P workgroups ------------
   constexpr int P = HID / UNITS;
   __shared__ int s_place[4];

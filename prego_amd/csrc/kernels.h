@@ -3,6 +3,23 @@
 #include <hip/hip_runtime_api.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <mutex>
+
+// One-time per-DEVICE setup at a launch site (hipFuncSetAttribute, symbol addresses): function attributes and __device__
+// symbols belong to the device that was current when they were set / resolved, so a process that drives several GPUs
+// needs them once per device, and the first calls may race between host threads.
+struct DeviceOnce {
+  std::mutex mu;
+  bool done[64] = {};
+  template <class F> int run(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) { f(); return 0; }
+    std::lock_guard<std::mutex> g(mu);
+    if (!done[dev]) { f(); done[dev] = true; }
+    return dev;
+  }
+};
 
 // host-visible copy of the slot schedule descriptor (layout identical to common.h's SlotPlan)
 #ifndef PREGO_HAVE_SLOTPLAN

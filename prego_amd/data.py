@@ -22,6 +22,10 @@ import torch.utils.data as data
 from .config import FEATURE_SIZES
 from .registry import DATA_LAYERS
 
+# datasets/dataset.py:100-107: `_init_features` removes this Assembly101-O session from `self.vids` in every mode (it is in
+# ASSEMBLY101-O's test_session_set, so the reference scores 181 test videos, not 182).  cfg['exclude_videos'] overrides.
+REFERENCE_EXCLUDED_VIDEOS = ("nusar-2021_action_both_9056-b08a_9056_user_id_2021-02-22_141934",)
+
 
 class StepRecognitionDataset(data.Dataset):
     def __init__(self, cfg, mode="train"):
@@ -36,6 +40,7 @@ class StepRecognitionDataset(data.Dataset):
         self.flow_type = cfg["flow_type"]
         self.zero_flow = cfg["flow_type"] == "flow_anet_resnet50"      # dataset.py:63-69
         vids = json.load(open(cfg["video_list_path"]))[cfg["data_name"]][mode + "_session_set"]
+        self.excluded = tuple(cfg.get("exclude_videos", REFERENCE_EXCLUDED_VIDEOS))
         self.vids, self.removed = [], 0
         self.target_all, self.rgb_inputs, self.flow_inputs = {}, {}, {}
         pad = self.window_size - 1
@@ -58,6 +63,8 @@ class StepRecognitionDataset(data.Dataset):
                 rgb = np.concatenate((np.zeros((pad, rgb.shape[1]), np.float32), rgb), 0)
                 if flow is not None:
                     flow = np.concatenate((np.zeros((pad, d_flow), np.float32), flow), 0)
+            if vid in self.excluded:       # dataset.py:100-107 (loaded, then dropped from the item list)
+                continue
             self.vids.append(vid)
             self.target_all[vid], self.rgb_inputs[vid], self.flow_inputs[vid] = target, rgb, flow
         self._zero_row = torch.zeros(1, d_flow)
@@ -100,10 +107,41 @@ def build_data_loader(cfg, mode):
     ds = DATA_LAYERS[cfg["data_name"]](cfg, mode)
     sampler = None
     if mode == "train" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        sampler = data.distributed.DistributedSampler(ds, shuffle=True, drop_last=False)
+        sampler = EpochWindowSampler(ds)
     return data.DataLoader(dataset=ds, batch_size=cfg["batch_size"] if mode == "train" else cfg["test_batch_size"],
                            shuffle=(mode == "train" and sampler is None), sampler=sampler,
                            num_workers=cfg["num_workers"], pin_memory=True)
+
+
+class EpochWindowSampler(data.Sampler):
+    """DistributedSampler for a dataset whose length changes every epoch (`_init_features()` re-draws the window phase,
+    main.py:100, so len(dataset) moves by a few windows): the permutation, the padding and the per-rank share are
+    recomputed from the CURRENT dataset length at every `__iter__`, and the epoch number seeds the shuffle
+    (`set_epoch`, called by train_one_epoch).  Every rank takes ceil(len / world) windows (the tail is padded by wrapping
+    around), so all ranks run the same number of steps."""
+
+    def __init__(self, dataset, seed: int = 0):
+        import torch.distributed as dist
+        self.dataset = dataset
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.seed = seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return (len(self.dataset) + self.world - 1) // self.world
+
+    def __iter__(self):
+        n = len(self.dataset)
+        g = torch.Generator()
+        g.manual_seed(self.seed + self.epoch)
+        order = torch.randperm(n, generator=g).tolist()
+        per = (n + self.world - 1) // self.world
+        order += order[: per * self.world - n]
+        return iter(order[self.rank: per * self.world: self.world])
 
 
 # ---- clip sharding for data-parallel inference (SURVEY.md section 8e) --------------------------------

@@ -20,11 +20,14 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # dmabuf IPC (what RCCL needs on this pool).  ROCr reads the flag at hsa_init, i.e. at the first HIP call of the process,
+    # so it is set before anything below can touch the GPU (prego_amd/__init__.py sets it at import time as well);
+    # torch.cuda.device_count() does not initialise HIP, torch.cuda.is_available() does.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if torch.cuda.device_count() > 0 else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))

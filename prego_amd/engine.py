@@ -130,14 +130,25 @@ class MiniRoadEngine:
         rgb_p = ptr_array([r.data_ptr() for r in rgb])
         flow_p = None if flow is None else ptr_array([None if f is None else f.data_ptr() for f in flow])
         out_p = arg_p = None
+        # one allocation per output kind, per-clip views into it (512 clips = 1 024 allocator calls otherwise: the host, not
+        # the GPU, then bounds a pass of short clips)
+        total = sum(lens)
         if want_out:
+            flat = torch.empty((total, ncls), dtype=torch.float32, device=self.device)
+            o, p0, ptrs = 0, flat.data_ptr(), []
             for i in range(n):
-                outs[base + i] = torch.empty((lens[i], ncls), dtype=torch.float32, device=self.device)
-            out_p = ptr_array([outs[base + i].data_ptr() for i in range(n)])
+                outs[base + i] = flat[o:o + lens[i]]
+                ptrs.append(p0 + o * ncls * 4)
+                o += lens[i]
+            out_p = ptr_array(ptrs)
         if want_argmax:
+            flat_a = torch.empty((total,), dtype=torch.int32, device=self.device)
+            o, p0, ptrs = 0, flat_a.data_ptr(), []
             for i in range(n):
-                args[base + i] = torch.empty((lens[i],), dtype=torch.int32, device=self.device)
-            arg_p = ptr_array([args[base + i].data_ptr() for i in range(n)])
+                args[base + i] = flat_a[o:o + lens[i]]
+                ptrs.append(p0 + o * 4)
+                o += lens[i]
+            arg_p = ptr_array(ptrs)
         with torch.cuda.device(self.device):
             check(self.lib.prego_miniroad_forward(
                 self.h, n, lens_arr, rgb_p, flow_p, out_p, arg_p,

@@ -25,12 +25,24 @@ def _allreduce_grads(model):
         o += n
 
 
+def _check_engine(model):
+    """A recurrence / BPTT spin timeout only sets the handle's abort word and makes the kernels return early, so the
+    logits and gradients of that step are garbage: surface it (PregoError, PREGO_ETIMEOUT) BEFORE optimizer.step().
+    `engine().check()` synchronises the stream - the reference loop syncs here anyway (`loss.item()`, train.py:26)."""
+    eng = getattr(model, "_engine", None)
+    if eng is not None:
+        eng.check()
+
+
 @TRAINER.register("OAD")
 def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, device, writer=None, scheduler=None):
     if scaler is not None:
         raise NotImplementedError("--amp: the HIP path already computes with bf16 MFMA operands and fp32 accumulation; "
                                   "fp16 autocast + GradScaler (train.py:10-18) has nothing to scale")
     epoch_loss = 0
+    sampler = getattr(trainloader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):          # data-parallel runs: a different permutation every epoch
+        sampler.set_epoch(epoch)
     for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(trainloader):
         rgb_input, flow_input, target = rgb_input.to(device), flow_input.to(device), target.to(device)
         model.train()
@@ -38,6 +50,7 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
         loss = criterion(out_dict, target)
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        _check_engine(model)
         _allreduce_grads(model)
         optimizer.step()
         epoch_loss += loss.item()

@@ -142,3 +142,108 @@ def test_evaluate_shards_videos_across_ranks_and_matches_single_process(tmp_path
             assert p.exitcode == 0
     assert res[1][1] == res[2][1]                       # identical JSON (all videos, same pred/gt)
     assert abs(res[1][0] - res[2][0]) < 1e-12           # identical mAP (same frame order on rank 0)
+
+
+class _TinyMROAD(torch.nn.Module):
+    """CPU stand-in with the MROAD call contract (forward(rgb, flow) -> {'logits'}) for the trainer test: what is under test is
+    train_one_epoch's data-parallel step (grad bucket all-reduce-mean, sampler epoch), not the arithmetic"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.l1 = torch.nn.Linear(12, 8)
+        self.gru = torch.nn.GRU(8, 6, batch_first=True)
+        self.fc = torch.nn.Linear(6, 5)
+
+    def forward(self, rgb, flow):
+        h, _ = self.gru(torch.relu(self.l1(torch.cat((rgb, flow), 2))))
+        return {"logits": self.fc(torch.relu(h))}
+
+
+def _oad_loss_torch(out, target):          # criterions/loss.py:15-34
+    lg, tg = out["logits"][:, -1, :], target[:, -1, :]
+    return torch.mean(torch.sum(-torch.nn.functional.normalize(tg) * torch.log_softmax(lg, -1), dim=1))
+
+
+def _train_batches():
+    g = torch.Generator().manual_seed(3)
+    B, T = 8, 7
+    rgb, flow = torch.randn(B, T, 6, generator=g), torch.randn(B, T, 6, generator=g)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (B, T), generator=g), 5).float()
+    return rgb, flow, tgt
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from prego_amd import distributed as D
+    from prego_amd.trainer import train_one_epoch
+    if world > 1:
+        D.init_from_env("gloo")
+    rgb, flow, tgt = _train_batches()
+    per = rgb.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)          # every rank its own windows (different data per rank)
+
+    class _Loader(list):
+        class _S:
+            epoch = None
+
+            def set_epoch(self, e):
+                self.epoch = e
+        sampler = _S()
+
+    loader = _Loader([(rgb[sl], flow[sl], tgt[sl], ("v",) * per, torch.zeros(per), torch.zeros(per))])
+    model = _TinyMROAD()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    loss = train_one_epoch(loader, model, _oad_loss_torch, opt, None, 3, "cpu")
+    assert loader.sampler.epoch == 3                  # DistributedSampler-style samplers get the epoch
+    if rank == 0:
+        q.put((float(loss), [p.detach().numpy().tolist() for p in model.parameters()]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_train_one_epoch_allreduces_grads_like_the_global_batch():
+    """two ranks with DIFFERENT local batches through TRAINER["OAD"] (-> _allreduce_grads): the parameters after the step equal
+    the single-process step over the concatenated (global) batch - the loss is a batch mean (loss.py:30-31)"""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    for a, b in zip(res[1][1], res[2][1]):
+        a, b = torch.tensor(a), torch.tensor(b)
+        assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+    assert not torch.allclose(torch.tensor(res[1][1][0]), _TinyMROAD().l1.weight)      # the step did move the weights
+
+
+def test_epoch_window_sampler_partitions_and_reshuffles():
+    from prego_amd.data import EpochWindowSampler
+
+    class _DS(list):
+        pass
+
+    class _FakeDist:
+        pass
+    import prego_amd.data as data_mod
+    ds = _DS(range(103))
+    parts = {}
+    for rank in range(4):
+        s = EpochWindowSampler.__new__(EpochWindowSampler)
+        s.dataset, s.world, s.rank, s.seed, s.epoch = ds, 4, rank, 0, 0
+        parts[rank] = list(iter(s))
+        assert len(parts[rank]) == len(s) == 26
+    flat = sorted(i for p in parts.values() for i in p)
+    assert set(flat) == set(range(103)) and len(flat) == 104           # one wrapped-around pad
+    s.set_epoch(1)
+    assert list(iter(s)) != parts[3]
+    ds.extend(range(5))                                               # _init_features() changed the window count
+    assert len(s) == 27 and len(list(iter(s))) == 27

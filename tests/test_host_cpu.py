@@ -145,3 +145,80 @@ def test_torch_average_precision_matches_sklearn_with_ties():
     for k in a["per_class_AP"]:
         assert abs(a["per_class_AP"][k] - b["per_class_AP"][k]) < 1e-12, k
     assert abs(a["mean_AP"] - b["mean_AP"]) < 1e-12 and a["num"] == b["num"]
+
+
+def test_bench_gpus_n_spawns_n_ranks_dry_run():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (one per GPU) and say n_gpus = 2; the dry run
+    rendezvouses over gloo and does no GPU work, so it runs on the CPU box."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    assert "rank 0: dist.get_world_size() = 2" in r.stderr and "rank 1: dist.get_world_size() = 2" in r.stderr
+    # a rank count that contradicts --gpus is an error, not a silent 1-GPU run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _g9_tree(tmp_path):
+    from prego_amd import weights as W
+    lens = {"vidA": 300, "vidB": 157}
+    for sub in ("target_perframe", "rgb_anet_resnet50"):
+        os.makedirs(os.path.join(tmp_path, sub))
+    for vid, T in lens.items():
+        tgt = np.zeros((T, 12), np.float32)
+        tgt[np.arange(T), (np.arange(T) // 29) % 12] = 1.0
+        np.save(os.path.join(tmp_path, "rgb_anet_resnet50", vid + ".npy"), W.tsn_features((T, 2048), 20, f"g9.rgb.{vid}"))
+        np.save(os.path.join(tmp_path, "target_perframe", vid + ".npy"), tgt)
+    vl = os.path.join(tmp_path, "video_list.json")
+    json.dump({"EPIC-TENT-O": {"train_session_set": ["vidA", "vidB"], "test_session_set": ["vidB", "vidA"]}}, open(vl, "w"))
+    return vl
+
+
+def test_feeder_matches_reference_dataset_fixture(tmp_path):
+    """G9: the reference's THUMOSDataset (datasets/dataset.py:24-135) on the same synthetic 2-video tree: identical window list
+    in train mode (np.random phase, seed 20), identical whole-video items in test mode, identical sample items."""
+    from prego_amd.config import epic_tent_cfg
+    from prego_amd.data import StepRecognitionDataset
+    g = np.load(os.path.join(G, "g9_feeder.npz"))
+    vl = _g9_tree(str(tmp_path))
+    cfg = epic_tent_cfg(root_path=str(tmp_path), video_list_path=vl)
+    for mode in ("train", "test"):
+        np.random.seed(20)
+        ds = StepRecognitionDataset(cfg, mode)
+        assert len(ds) == int(g[f"{mode}.len"])
+        assert [w[0] for w in ds.inputs] == list(g[f"{mode}.vids"])
+        assert [w[1] for w in ds.inputs] == list(g[f"{mode}.start"]) and [w[2] for w in ds.inputs] == list(g[f"{mode}.end"])
+        for j in (0, len(ds) - 1):
+            r, f, t, vid, s_, e_ = ds[j]
+            meta = list(g[f"{mode}.item{j}.meta"])
+            assert [str(vid), str(int(s_)), str(int(e_)), str(tuple(r.shape)), str(r.dtype), str(f.dtype), str(t.dtype)] == meta
+            assert abs(float(r.double().sum()) - float(g[f"{mode}.item{j}.rgb_sum"])) < 1e-6
+            assert np.array_equal(r.numpy()[[0, -1]][:, :16], g[f"{mode}.item{j}.rgb_rows"])
+            assert float(f.double().abs().sum()) == float(g[f"{mode}.item{j}.flow_abs_sum"]) == 0.0
+            assert np.array_equal(t.numpy().argmax(1), g[f"{mode}.item{j}.target_argmax"])
+            assert np.array_equal(t.numpy().sum(1), g[f"{mode}.item{j}.target_rowsum"])
+
+
+def test_feeder_drops_the_video_the_reference_drops(tmp_path):
+    """datasets/dataset.py:100-107 removes one Assembly101-O session from every split: 181 test videos, not 182."""
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.data import REFERENCE_EXCLUDED_VIDEOS, StepRecognitionDataset
+    bad = REFERENCE_EXCLUDED_VIDEOS[0]
+    vids = ["v0", bad, "v1"]
+    for sub in ("target_perframe", "rgb_anet_resnet50"):
+        os.makedirs(os.path.join(tmp_path, sub))
+    for v in vids:
+        np.save(os.path.join(tmp_path, "rgb_anet_resnet50", v + ".npy"), np.ones((20, 2048), np.float32))
+        np.save(os.path.join(tmp_path, "target_perframe", v + ".npy"), np.eye(86, dtype=np.float32)[np.arange(20) % 86])
+    vl = os.path.join(tmp_path, "vl.json")
+    json.dump({"ASSEMBLY101-O": {"train_session_set": vids, "test_session_set": vids}}, open(vl, "w"))
+    ds = StepRecognitionDataset(assembly101_cfg(root_path=str(tmp_path), video_list_path=vl), "test")
+    assert ds.vids == ["v0", "v1"] and [w[0] for w in ds.inputs] == ["v0", "v1"]
+    ds = StepRecognitionDataset(assembly101_cfg(root_path=str(tmp_path), video_list_path=vl, exclude_videos=()), "test")
+    assert ds.vids == vids

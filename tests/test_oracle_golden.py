@@ -186,3 +186,42 @@ def test_torch_port_matches_golden():
     out = port.forward(rgb, torch.zeros_like(rgb))[0].numpy()
     assert np.abs(out - g["probs"]).max() < 1e-6
     assert np.array_equal(out.argmax(1), g["argmax"])
+
+
+def test_g4c_train_16x128_real_shape():
+    """the oracle's hand-written BPTT at the real training shape (16 windows x 128 frames) against the reference"""
+    g = _ld("g4c_miniroad_train_16x128.npz")
+    cfg = assembly101_cfg(dropout=0.0)
+    sd = W.miniroad_state_dict(cfg, 20)
+    rgb = W.tsn_features((16, 128, 2048), 20, "g4c.rgb")
+    flow = W.tsn_features((16, 128, 2048), 20, "g4c.flow")
+    tgt = _targets(16, 128, 86, 20, "g4c.tgt")
+    loss, grads = O.miniroad_loss_and_grads(sd, rgb, flow, tgt)
+    assert abs(loss - float(g["loss"])) < 5e-6
+    for k in sd:
+        gg = grads[k].reshape(-1)
+        assert abs(np.linalg.norm(gg) - float(g["norm." + k])) < 2e-4 * float(g["norm." + k]) + 1e-9, k
+        ref = g["val." + k]
+        assert np.abs(gg[g["idx." + k]] - ref).max() < 1e-7 + 2e-3 * np.abs(ref).max(), k
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_g5b_vit_training_step(layers):
+    """ViTEnc forward (1 and 2 layers) + OadLoss + full backward by hand against the reference's autograd"""
+    g = _ld(f"g5b_vit_train_L{layers}.npz")
+    cfg = dict(_vit_cfg(), num_layers=layers)
+    sd = W.vit_state_dict(cfg, 20)
+    rgb = W.tsn_features((2, 128, 2048), 20, "g5.rgb")
+    flow = W.tsn_features((2, 128, 2048), 20, "g5.flow")
+    tgt = _targets(2, 128, 86, 20, "g5b.tgt")
+    loss, logits, grads = O.vit_loss_and_grads(sd, rgb, flow, tgt, heads=8, num_layers=layers)
+    assert np.abs(logits - g["logits"]).max() < 3e-5
+    assert abs(loss - float(g["loss"])) < 5e-6
+    keys = [k[5:] for k in g.files if k.startswith("norm.")]
+    assert set(keys) == set(k for k in sd if k != "position_encoding.position_ids")
+    for k in keys:
+        gg = grads[k].reshape(-1)
+        ref_norm = float(g["norm." + k])
+        assert abs(np.linalg.norm(gg) - ref_norm) < 5e-4 * ref_norm + 1e-9, (k, np.linalg.norm(gg), ref_norm)
+        ref = g["val." + k]
+        assert np.abs(gg[g["idx." + k]] - ref).max() < 1e-7 + 5e-3 * np.abs(ref).max(), k
