@@ -153,6 +153,20 @@ size_t prego_vit_workspace_bytes(const prego_vit* h, int batch);
 int prego_vit_forward(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
                       void* workspace, size_t workspace_bytes, prego_stream_t stream);
 
+/* Training of the "Transformer" registry entry: trainer/train.py:20-24 (fwd, loss, backward) over ViTEnc (ViT.py:117-143,
+ * Transformer.py:5-82, Attention.py:21-41).  forward_train is ViTEnc.forward in training mode with every dropout rate 0
+ * (cfg['dropout'] == cfg['attn_dropout_rate'] == 0; non-zero rates are rejected by the host module) and keeps the activations
+ * the backward needs in `workspace` (caller-owned, prego_vit_train_workspace_bytes, untouched between the two calls).
+ * backward: dlogits device fp32 [batch, n_classes] = dLoss/dlogits (OadLoss: prego_oad_loss on the [batch,1,C] logits);
+ * grads: host array of n_tensors device fp32 tensors in prego_vit_set_weights' order and shapes, OVERWRITTEN.  All sums over
+ * rows / windows run in a fixed order (bit-reproducible); the attention backward recomputes the probabilities from Q, K and the
+ * forward's log-sum-exp (no [B,h,N,N] tensor) and uses no atomics.  flags bit 0: causal attention (as in forward). */
+size_t prego_vit_train_workspace_bytes(const prego_vit* h, int batch);
+int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
+                            void* workspace, size_t workspace_bytes, prego_stream_t stream);
+int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
+                       void* workspace, size_t workspace_bytes, prego_stream_t stream);
+
 /* AttentionLayer(FullAttention(mask_flag=causal)) of attn.py:139-170,35-57,10-18 as a stateless op (BASELINE config 4:
  * long-window causal attention).  x, out: device fp32 [batch, len, d_model]; projection weights [d_model, d_model] and
  * biases [d_model] in nn.Linear layout.  scores = softmax(mask(q k^T) / sqrt(d_model/heads)); never materialised. */
@@ -171,6 +185,12 @@ int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
 int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,
                           prego_stream_t stream);
+
+/* Debug / unit test only: the attention backward kernels alone.  qs (= q * dh^-0.5), k, v: device bf16 [batch, heads, len, dh];
+ * o, dout: device bf16 [batch, len, heads*dh]; lse: device fp32 [batch, heads, len] log-sum-exp of the scaled scores;
+ * dqkv: device bf16 [batch*len, 3*heads*dh] (dq | dk | dv, dq wrt the unscaled q).  Synchronises the stream. */
+int prego_debug_attention_bwd(int batch, int len, int heads, int dh, int causal, const void* qs, const void* k, const void* v,
+                              const void* o, const void* dout, const float* lse, void* dqkv, prego_stream_t stream);
 
 #ifdef __cplusplus
 }

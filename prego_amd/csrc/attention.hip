@@ -16,7 +16,7 @@
 template <int DH>
 __global__ __launch_bounds__(256) void flash_attention_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
-    int N, int Npad, int heads, int causal) {
+    int N, int Npad, int heads, int causal, float* __restrict__ lse /*nullable: [B,h,N] log-sum-exp of the scaled scores (training)*/) {
   constexpr int KS = DH / 32;            // k-steps of QK^T
   constexpr int DT = DH / 16;            // output column tiles
   constexpr int KLD = DH + 8;            // LDS row pitch of the K tile (elements): 16-byte skew per row
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(
     const int qr = q0 + wave * 16 + l4 * 4 + e;
     if (qr < N) {
       const float inv = 1.0f / l_run[e];
+      if (lse != nullptr && l15 == 0) lse[(size_t)bh * N + qr] = m_run[e] + logf(l_run[e]);
       bf16_t* orow = out + ((size_t)b * N + qr) * heads * DH + hd * DH;
 #pragma unroll
       for (int d = 0; d < DT; ++d) orow[d * 16 + l15] = f2bf(o[d][e] * inv);
@@ -145,15 +146,16 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(
 }
 
 int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
-                           int dh, int causal, hipStream_t s) {
+                           int dh, int causal, hipStream_t s, float* lse) {
   if (Npad % AK) return -1;
   dim3 grid((N + AQ - 1) / AQ, B * heads);
 #define FA(D)                                                                                                   \
   do {                                                                                                          \
     const size_t lds = ((size_t)AK * (D + 8) + (size_t)D * (AK + 8) + 4 * 16 * (AK + 8)) * 2;                   \
-    (void)hipFuncSetAttribute((const void*)flash_attention_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    static DeviceOnce once;                                                                                     \
+    once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
     flash_attention_kernel<D><<<grid, 256, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)out, N, \
-                                                     Npad, heads, causal);                                      \
+                                                     Npad, heads, causal, lse);                                 \
   } while (0)
   if (dh == 256) FA(256);
   else if (dh == 128) FA(128);

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             float* xr = (float*)C + (size_t)m * ldc + n;
             *xr = *xr + v;
           } else if constexpr (EPI == EPI_GELU_BF16) {                // FFN-1: bf16(gelu(v))
+            if (epi.pre_f32) epi.pre_f32[(size_t)m * ldc + n] = v;   // training: keep the pre-activation for gelu'
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gelu_erf_(v));
           } else if constexpr (EPI == EPI_STORE_BF16) {
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             const size_t bh = (size_t)b * epi.heads + hd;
             if (which == 0) ((bf16_t*)epi.q)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v * epi.q_scale);
             else if (which == 1) ((bf16_t*)epi.k)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
-            else ((bf16_t*)epi.vt)[(bh * epi.dh + d) * epi.n_pad + t] = f2bf(v);
+            else {
+              ((bf16_t*)epi.vt)[(bh * epi.dh + d) * epi.n_pad + t] = f2bf(v);
+              if (epi.vn) ((bf16_t*)epi.vn)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
+            }
           }
         }
       }

@@ -240,6 +240,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
                         v1[0] + bv[y][1].x, v1[1] + bv[y][1].y, v1[2] + bv[y][1].z, v1[3] + bv[y][1].w};
           if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_GELU_BF16) {
             if constexpr (EPI == EPI_GELU_BF16) {
+              if (epi.pre_f32) {                                         // training: keep the pre-activation for gelu'
+                *(float4*)(epi.pre_f32 + (size_t)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4*)(epi.pre_f32 + (size_t)m * ldc + n + 4) = make_float4(o[4], o[5], o[6], o[7]);
+              }
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = gelu_erf_(o[e]);
             }
@@ -267,6 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) ((bf16_t*)epi.vt)[(bh * epi.dh + d + e) * epi.n_pad + t] = f2bf(o[e]);
+              if (epi.vn) {                                              // training: V by rows as well
+                uint4 pk;
+                pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+                *(uint4*)((bf16_t*)epi.vn + (bh * epi.n_tok + t) * epi.dh + d) = pk;
+              }
             }
           } else {
             *(float4*)(C + (size_t)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);

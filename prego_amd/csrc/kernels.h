@@ -79,6 +79,8 @@ struct GemmEpi {
   void* q; void* k; void* vt;  // EPI_QKV destinations
   int n_tok, n_pad, heads, dh, emb;
   float q_scale;               // softmax scale folded into Q
+  void* vn;                    // EPI_QKV, training: V also in [B,h,N,dh] layout (attention backward reads it by rows); nullable
+  float* pre_f32;              // EPI_GELU_BF16, training: the pre-activation W1 x + b1 in fp32 (gelu'), leading dim = ldc; nullable
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
@@ -128,12 +130,23 @@ void launch_gru_bwd_step(bool bf16, int t, int na, int na_next, int row_t, int r
 void launch_relu_mask(const float* dHrelu, const float* Hraw, size_t n, float* out, hipStream_t s);
 void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_max, int nrows, int H, void* out,
                         hipStream_t s);
+// relu = 0: plain LayerNorm backward (Transformer path); accumulate = 1: dY += result (residual stream)
 int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
-                       int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s);
+                       int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s,
+                       int relu = 1, int accumulate = 0);
 
 // Transformer path (attention.hip, vit.hip)
 int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
-                           int dh, int causal, hipStream_t s);
+                           int dh, int causal, hipStream_t s, float* lse = nullptr);
+// attention backward (attention_bwd.hip): dqkv [B*N, 3*heads*dh] bf16; delta: scratch fp32 [B*heads*N]
+int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                         float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s);
+// ViTEnc training glue (vit_train.hip)
+void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s);
+void launch_vit_head_bwd(const float* x, const float* dlogits, int B, int N, int E, int C, const float* lnw, const float* lnb,
+                         const float* hw, float* dx, float* scratch /*[3][B][E]*/, float* g_lnw, float* g_lnb, float* g_hw,
+                         float* g_hb, hipStream_t s);
+void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s);
 void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s);
 void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,

@@ -220,7 +220,7 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
     const float* __restrict__ dE, const float* __restrict__ Y, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, int nrows, int E, float drop_p,
-    unsigned long long seed, int row0_abs, float* __restrict__ dY, float* __restrict__ part) {
+    unsigned long long seed, int row0_abs, float* __restrict__ dY, float* __restrict__ part, int relu, int accumulate) {
   __shared__ float sg[4][4096 / 1];   // per-wave dgamma contributions are reduced through LDS below (E <= 4096)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = E / 256;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
       for (int k = 0; k < 4; ++k) {
         const float x = (yy[k] - mu) * rstd;
         const float pre = x * gg[k] + bb[k];
-        float d = (live && pre > 0.f) ? dd[k] : 0.f;                      // ReLU
+        float d = (live && (!relu || pre > 0.f)) ? dd[k] : 0.f;           // ReLU (MiniROAD layer1) / none (Transformer)
         if (thresh) d = dropout_keep_(seed, (size_t)(row0_abs + r) * E + c + k, thresh) ? d * keep_scale : 0.f;
         xo[k] = x; dgo[k] = d * x; dbo[k] = d; dxo[k] = d * gg[k];
         s1 += dxo[k]; s2 += dxo[k] * x;
@@ -265,6 +265,10 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
       float4 o;
       o.x = rstd * (dxh[i].x - m1 - xh[i].x * m2); o.y = rstd * (dxh[i].y - m1 - xh[i].y * m2);
       o.z = rstd * (dxh[i].z - m1 - xh[i].z * m2); o.w = rstd * (dxh[i].w - m1 - xh[i].w * m2);
+      if (accumulate) {                                                  // residual stream: dx += (branch gradient)
+        const float4 p = *(const float4*)(dY + (size_t)r * E + c);
+        o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+      }
       *(float4*)(dY + (size_t)r * E + c) = o;
     }
   // block partials of dgamma (pass 0) and dbeta (pass 1): fixed order wave 0..3
@@ -336,10 +340,11 @@ void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_m
 }
 // part must hold ceil(nrows/4) * 2 * E floats; returns the number of row blocks
 int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
-                       int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s) {
+                       int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s,
+                       int relu, int accumulate) {
   const int nb = (nrows + 3) / 4;
   if (nb <= 0) return 0;
-  if (E <= 2048) ln_relu_bwd_rows_kernel<8><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part);
-  else ln_relu_bwd_rows_kernel<16><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part);
+  if (E <= 2048) ln_relu_bwd_rows_kernel<8><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate);
+  else ln_relu_bwd_rows_kernel<16><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate);
   return nb;
 }

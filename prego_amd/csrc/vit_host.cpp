@@ -3,6 +3,7 @@
 #include "../../include/prego_amd.h"
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -159,6 +160,191 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   for (const auto& l : h->L)
     if (encoder_block(h, l, (float*)(ws + w.x), ws, w, B, N, (flags & 1) ? 1 : 0, s)) return prego_fail_(PREGO_EINVAL, "encoder block launch failed");
   launch_vit_head((const float*)(ws + w.x), B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ================================================================================================
+// training: forward that keeps activations + backward (trainer/train.py:20-24 over ViT.py:117-143)
+// ================================================================================================
+struct VitLayerKeep { size_t x_in, st1, xn1, q, k, vn, vt, lse, ao, x_mid, st2, xn2, u, f; };
+struct VitTrainWs {
+  size_t xb, enc, x;                     // inputs as bf16, encoding GEMM output, residual stream (final value after forward)
+  std::vector<VitLayerKeep> L;
+  // backward scratch
+  size_t dx, dxb, tmp, du, dub, dO, dqkv, delta, T1, T2, WT, part, head, denc, vec;
+  size_t total;
+  int npad, Mp, MTp;
+};
+static VitTrainWs vit_train_ws(const prego_vit* h, int B) {
+  const size_t E = h->emb, T = h->window, N = T + 1, din = h->d_rgb + h->d_flow, mlp = h->mlp, M = (size_t)B * N;
+  VitTrainWs w{};
+  w.npad = (int)align_up(N, 64);
+  w.Mp = (int)align_up(M, 64);
+  w.MTp = (int)align_up((size_t)B * T, 64);
+  size_t off = 0;
+  auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  w.xb = put((size_t)B * T * din * 2); w.enc = put((size_t)B * T * E * 4); w.x = put(M * E * 4);
+  w.L.resize(h->layers);
+  for (auto& l : w.L) {
+    l.x_in = put(M * E * 4); l.st1 = put(M * 8); l.xn1 = put(M * E * 2);
+    l.q = put(M * E * 2); l.k = put(M * E * 2); l.vn = put(M * E * 2); l.vt = put((size_t)B * E * w.npad * 2);
+    l.lse = put((size_t)B * h->heads * N * 4); l.ao = put(M * E * 2);
+    l.x_mid = put(M * E * 4); l.st2 = put(M * 8); l.xn2 = put(M * E * 2);
+    l.u = put(M * mlp * 4); l.f = put(M * mlp * 2);
+  }
+  const size_t wide = std::max<size_t>(std::max<size_t>(3 * E, mlp), din);
+  w.dx = put(M * E * 4); w.dxb = put(M * E * 2); w.tmp = put(M * std::max<size_t>(E, mlp) * 4);
+  w.du = put(M * mlp * 4); w.dub = put(M * mlp * 2); w.dO = put(M * E * 2); w.dqkv = put(M * 3 * E * 2);
+  w.delta = put((size_t)B * h->heads * N * 4);
+  w.T1 = put(wide * (size_t)w.Mp * 2); w.T2 = put(wide * (size_t)w.Mp * 2);
+  w.WT = put(3 * E * E * 2);
+  w.part = put(std::max<size_t>(((size_t)M / 64 + 2) * std::max<size_t>(mlp, E), ((size_t)M / 4 + 2) * 2 * E) * 4);
+  w.head = put((size_t)3 * B * E * 4); w.denc = put((size_t)B * T * E * 4); w.vec = put(4 * std::max<size_t>(E, mlp) * 4);
+  w.total = off;
+  return w;
+}
+extern "C" size_t prego_vit_train_workspace_bytes(const prego_vit* h, int batch) {
+  return (h && batch > 0) ? vit_train_ws(h, batch).total : 0;
+}
+
+extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
+                                       void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
+  if (batch <= 0) return prego_fail_(PREGO_EINVAL, "batch %d", batch);
+  if (h->d_rgb > 0 && !rgb) return prego_fail_(PREGO_EINVAL, "missing input");
+  const VitTrainWs w = vit_train_ws(h, batch);
+  if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int B = batch, T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow, M = B * N, dh = E / h->heads;
+  const int causal = (flags & 1) ? 1 : 0;
+  float* x = (float*)(ws + w.x);
+  launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
+  launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);
+  launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, x, s);
+  for (int li = 0; li < h->layers; ++li) {
+    const VitLayer& l = h->L[li];
+    const VitLayerKeep& k = w.L[li];
+    HIPCHK(hipMemcpyAsync(ws + k.x_in, x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s));
+    launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + k.xn1, (float*)(ws + k.st1), 0.f, 0, 0, s, 0);
+    GemmEpi e{};
+    e.mode = EPI_QKV; e.q = ws + k.q; e.k = ws + k.k; e.vt = ws + k.vt; e.vn = ws + k.vn; e.n_tok = N; e.n_pad = w.npad;
+    e.heads = h->heads; e.dh = dh; e.emb = E; e.q_scale = 1.0f / sqrtf((float)dh);
+    HIPCHK(hipMemsetAsync(ws + k.vt, 0, (size_t)B * E * w.npad * 2, s));
+    launch_gemm_bf16_nt_epi(ws + k.xn1, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
+    if (launch_flash_attention(ws + k.q, ws + k.k, ws + k.vt, ws + k.ao, B, N, w.npad, h->heads, dh, causal, s, (float*)(ws + k.lse)))
+      return prego_fail_(PREGO_EINVAL, "attention launch failed");
+    GemmEpi r{}; r.mode = EPI_RESIDUAL;
+    launch_gemm_bf16_nt_epi(ws + k.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);
+    HIPCHK(hipMemcpyAsync(ws + k.x_mid, x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s));
+    launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + k.xn2, (float*)(ws + k.st2), 0.f, 0, 0, s, 0);
+    GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + k.f; g.pre_f32 = (float*)(ws + k.u);
+    launch_gemm_bf16_nt_epi(ws + k.xn2, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);
+    launch_gemm_bf16_nt_epi(ws + k.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);
+  }
+  launch_vit_head(x, B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// C[Mo, No] = A^T . B over the rows: A_rows [R, Mo], B_rows [R, No] (fp32 or bf16) -> transposes + NT GEMM (the reduction
+// dimension of every weight gradient is the row index)
+static void wgrad(const void* a_rows, bool a_bf16, int Mo, const void* b_rows, bool b_bf16, int No, int R, int Rp, char* T1, char* T2,
+                  float* out, hipStream_t s) {
+  launch_transpose_convert(a_bf16, true, a_rows, R, Mo, Mo, T1, Rp, s);
+  launch_transpose_convert(b_bf16, true, b_rows, R, No, No, T2, Rp, s);
+  launch_gemm_bf16_nt(T1, Rp, T2, Rp, nullptr, out, No, Mo, No, Rp, s);
+}
+
+extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
+                                  void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!h || !dlogits || !grads || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d gradient tensors, got %d", prego_vit_num_tensors(h), n_tensors);
+  for (int i = 0; i < n_tensors; ++i) if (!grads[i]) return prego_fail_(PREGO_EINVAL, "gradient tensor %d is NULL", i);
+  const VitTrainWs w = vit_train_ws(h, batch);
+  if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int B = batch, T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow, M = B * N, dh = E / h->heads, mlp = h->mlp;
+  const int causal = (flags & 1) ? 1 : 0;
+  const int Mp = w.Mp;
+  float* dx = (float*)(ws + w.dx);
+  float* tmp = (float*)(ws + w.tmp);
+  float* part = (float*)(ws + w.part);
+  float* vec = (float*)(ws + w.vec);
+  char* T1 = ws + w.T1; char* T2 = ws + w.T2; char* WT = ws + w.WT;
+  // gradient tensors in state_dict order (prego_vit_set_weights)
+  float* g_enc_w = grads[0]; float* g_enc_b = grads[1]; float* g_cls = grads[2]; float* g_pe = grads[3];
+  float* const* gl = grads + 4;
+  float* const* gt = grads + 4 + 11 * h->layers;          // pre_head_ln.weight/bias, mlp_head.weight/bias
+
+  // ---- head + final LayerNorm (token 0 only, ViT.py:134-138)
+  HIPCHK(hipMemsetAsync(dx, 0, (size_t)M * E * 4, s));
+  launch_vit_head_bwd((const float*)(ws + w.x), dlogits, B, N, E, h->ncls, h->lnf_w, h->lnf_b, h->head_w, dx, (float*)(ws + w.head),
+                      gt[0], gt[1], gt[2], gt[3], s);
+
+  for (int li = h->layers - 1; li >= 0; --li) {
+    const VitLayer& l = h->L[li];
+    const VitLayerKeep& k = w.L[li];
+    float* const* g = gl + 11 * li;      // ln1 w,b | qkv w | proj w,b | ln2 w,b | ff1 w,b | ff2 w,b
+    // ---- FFN: x += W2 gelu(W1 LN2(x) + b1) + b2   (Transformer.py:35-47)
+    launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
+    launch_colsum(dx, M, E, part, g[10], s);                                                 // d b2
+    wgrad(dx, false, E, ws + k.f, true, mlp, M, Mp, T1, T2, g[9], s);                        // d W2 [E, mlp]
+    launch_transpose_convert(true, true, l.ff2_w, E, mlp, mlp, WT, E, s);                    // W2^T [mlp][E]
+    launch_gemm_bf16_nt(ws + w.dxb, E, WT, E, nullptr, tmp, mlp, M, mlp, E, s);              // d f = dx . W2
+    launch_gelu_bwd(tmp, (const float*)(ws + k.u), (size_t)M * mlp, (float*)(ws + w.du), ws + w.dub, s);
+    launch_colsum((const float*)(ws + w.du), M, mlp, part, g[8], s);                         // d b1
+    wgrad(ws + w.du, false, mlp, ws + k.xn2, true, E, M, Mp, T1, T2, g[7], s);               // d W1 [mlp, E]
+    launch_transpose_convert(true, true, l.ff1_w, mlp, E, E, WT, mlp, s);                    // W1^T [E][mlp]
+    launch_gemm_bf16_nt(ws + w.dub, mlp, WT, mlp, nullptr, tmp, E, M, E, mlp, s);            // d LN2 out = du . W1
+    int nb = launch_ln_relu_bwd(tmp, (const float*)(ws + k.x_mid), (const float*)(ws + k.st2), l.ln2_w, l.ln2_b, M, E, 0.f, 0, 0, dx,
+                                part, s, 0, 1);                                              // dx += LN2 backward
+    launch_colsum_stage2(part, nb, 2 * E, vec, s);
+    HIPCHK(hipMemcpyAsync(g[5], vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g[6], vec + E, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+    // ---- attention: x += proj(attn(LN1(x)))   (Attention.py:21-41)
+    launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
+    launch_colsum(dx, M, E, part, g[4], s);                                                  // d proj bias
+    wgrad(dx, false, E, ws + k.ao, true, E, M, Mp, T1, T2, g[3], s);                         // d Wproj [E, E]
+    launch_transpose_convert(true, true, l.proj_w, E, E, E, WT, E, s);                       // Wp^T
+    {
+      GemmEpi eb{}; eb.mode = EPI_STORE_BF16; eb.out_b = ws + w.dO;
+      launch_gemm_bf16_nt_epi(ws + w.dxb, E, WT, E, nullptr, nullptr, E, M, E, E, eb, s);    // d o = dx . Wp (bf16, [B,N,h*dh])
+    }
+    if (launch_attention_bwd(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, ws + w.dO, (const float*)(ws + k.lse), (float*)(ws + w.delta),
+                             ws + w.dqkv, B, N, h->heads, dh, causal, 1.0f / sqrtf((float)dh), s))
+      return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
+    wgrad(ws + w.dqkv, true, 3 * E, ws + k.xn1, true, E, M, Mp, T1, T2, g[2], s);            // d Wqkv [3E, E]
+    launch_transpose_convert(true, true, l.qkv_w, 3 * E, E, E, WT, 3 * E, s);                // Wqkv^T [E][3E]
+    launch_gemm_bf16_nt(ws + w.dqkv, 3 * E, WT, 3 * E, nullptr, tmp, E, M, E, 3 * E, s);     // d LN1 out
+    nb = launch_ln_relu_bwd(tmp, (const float*)(ws + k.x_in), (const float*)(ws + k.st1), l.ln1_w, l.ln1_b, M, E, 0.f, 0, 0, dx, part,
+                            s, 0, 1);                                                        // dx += LN1 backward
+    launch_colsum_stage2(part, nb, 2 * E, vec, s);
+    HIPCHK(hipMemcpyAsync(g[0], vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g[1], vec + E, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // ---- tokens: positional table, cls token, encoding Linear (ViT.py:125-129)
+  float* denc = (float*)(ws + w.denc);
+  launch_vit_tokens_bwd(dx, B, T, E, denc, g_pe, g_cls, s);
+  launch_colsum(denc, B * T, E, part, g_enc_b, s);
+  wgrad(denc, false, E, ws + w.xb, true, din, B * T, w.MTp, T1, T2, g_enc_w, s);             // d W_enc [E, din]
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// debug / unit test: the attention backward kernels alone (tests/test_gpu_vit_train.py)
+extern "C" int prego_debug_attention_bwd(int batch, int len, int heads, int dh, int causal, const void* qs, const void* k, const void* v,
+                                         const void* o, const void* dout, const float* lse, void* dqkv, prego_stream_t stream) {
+  if (!qs || !k || !v || !o || !dout || !lse || !dqkv || batch <= 0 || len <= 0 || heads <= 0) return prego_fail_(PREGO_EINVAL, "debug attention bwd: bad arguments");
+  float* delta = nullptr;
+  HIPCHK(hipMalloc((void**)&delta, (size_t)batch * heads * len * 4));
+  const int rc = launch_attention_bwd(qs, k, v, o, dout, lse, delta, dqkv, batch, len, heads, dh, causal, 1.0f / sqrtf((float)dh), (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(delta);
+  if (rc) return prego_fail_(PREGO_EINVAL, "debug attention bwd: unsupported head dim %d", dh);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

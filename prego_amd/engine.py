@@ -228,6 +228,12 @@ def oad_loss(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True,
     """OadLoss on the device (criterions/loss.py:15-34) for uniform [B,T,C] tensors.
     Returns (loss scalar tensor, dlogits [B,T,C] or None)."""
     lib = _lib.load()
+    if target.shape[1] != logits.shape[1]:
+        # `Transformer` emits ONE logit row per window ([B,1,C], ViT.py:140) while the target keeps every frame ([B,T,C]):
+        # loss.py:18-19 takes logits[:, -1] and target[:, -1], so only the last rows meet
+        if logits.shape[1] != 1:
+            raise PregoError(f"oad_loss: logits {tuple(logits.shape)} vs target {tuple(target.shape)}")
+        target = target[:, -1:, :]
     B, T, Cn = logits.shape
     logits = logits.to(torch.float32).contiguous()
     target = target.to(torch.float32).contiguous()

@@ -1,8 +1,10 @@
 """`Transformer` (ViTEnc) behind the reference's plug-in API (model/transformer_models/ViT.py:25-143) and the causal
 `AttentionLayer(FullAttention)` op of attn.py as a function.  Same constructor keys (`patch_dim`, `num_heads`,
 `attn_dropout_rate` on top of the yaml), same `forward(rgb, flow) -> {'logits': [B,1,C]}` (raw logits in both modes),
-same state_dict keys/shapes, so reference checkpoints load.  Forward only in this round
-(inference); bf16 MFMA operands, fp32 residual stream / LayerNorm / softmax."""
+same state_dict keys/shapes, so reference checkpoints load.  bf16 MFMA operands, fp32 residual
+stream / LayerNorm / softmax.  Training (trainer/train.py:20-24) runs through `prego_vit_forward_train` / `prego_vit_backward`
+behind a torch.autograd.Function; the dropout rates of the reference module must be 0 there (cfg['dropout'],
+cfg['attn_dropout_rate']): the HIP training path has no dropout masks yet and says so instead of silently skipping them."""
 from __future__ import annotations
 
 import ctypes as C
@@ -92,6 +94,8 @@ class ViTEnc(nn.Module):
         self.encoder.net = nn.Sequential(*layers)
         self.pre_head_ln = nn.LayerNorm(E)                                                      # ViT.py:79
         self.mlp_head = nn.Linear(E, self.out_dim)                                              # ViT.py:90
+        self.dropout_rate = float(cfg.get("dropout", 0.0))           # ViT.py:38
+        self.attn_dropout_rate = float(cfg.get("attn_dropout_rate", 0.0))   # ViT.py:47
         self.causal = bool(cfg.get("causal_attention", False))     # extension, see DESIGN.md
         self._h = None
         self._ver = None
@@ -118,12 +122,7 @@ class ViTEnc(nn.Module):
             self._keep, self._ver = ts, ver
         return lib, dev
 
-    def forward(self, sequence_input_rgb, sequence_input_flow):
-        if self.training and torch.is_grad_enabled():
-            # the HIP path of the Transformer model is forward only; failing here beats a loss that
-            # silently has no graph
-            raise PregoError("ViTEnc: training is not implemented on the HIP path (forward / eval only); call .eval() or torch.no_grad()")
-        lib, dev = self._handle()
+    def _inputs(self, sequence_input_rgb, sequence_input_flow):
         rgb = sequence_input_rgb.float().contiguous() if self.use_rgb else None
         flow = sequence_input_flow.float().contiguous() if self.use_flow else None
         B, T = (rgb if rgb is not None else flow).shape[:2]
@@ -131,6 +130,18 @@ class ViTEnc(nn.Module):
             raise PregoError(f"ViTEnc needs T == window_size ({self.img_dim}), got {T} (learned positional table, PositionalEncoding.py:25-41)")
         if rgb is None:
             raise PregoError("--no_rgb is not supported by the HIP path yet")
+        return rgb, flow, B
+
+    def forward(self, sequence_input_rgb, sequence_input_flow):
+        if self.training and torch.is_grad_enabled():
+            if self.dropout_rate != 0 or self.attn_dropout_rate != 0:
+                raise PregoError("ViTEnc training on the HIP path needs cfg['dropout'] == cfg['attn_dropout_rate'] == 0 "
+                                 f"(got {self.dropout_rate}, {self.attn_dropout_rate}): dropout masks are not implemented there")
+            names = _tensor_order(self.num_layers)
+            sd = dict(self.named_parameters())
+            return {"logits": _ViTTrainFn.apply(self, sequence_input_rgb, sequence_input_flow, *[sd[k] for k in names]).unsqueeze(1)}
+        lib, dev = self._handle()
+        rgb, flow, B = self._inputs(sequence_input_rgb, sequence_input_flow)
         need = lib.prego_vit_workspace_bytes(self._h, B)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -147,6 +158,39 @@ class ViTEnc(nn.Module):
                 _lib.load().prego_vit_destroy(self._h)
         except Exception:
             pass
+
+
+class _ViTTrainFn(torch.autograd.Function):
+    """trainer/train.py:20-24 for model: 'Transformer': autograd only carries the tensors between the two C-ABI calls"""
+
+    @staticmethod
+    def forward(ctx, model, rgb_in, flow_in, *params):
+        lib, dev = model._handle()
+        rgb, flow, B = model._inputs(rgb_in, flow_in)
+        need = lib.prego_vit_train_workspace_bytes(model._h, B)
+        if getattr(model, "_ws_train", None) is None or model._ws_train.numel() < need:
+            model._ws_train = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, model.out_dim), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.prego_vit_forward_train(model._h, B, C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
+                                              C.c_void_p(out.data_ptr()), 1 if model.causal else 0,
+                                              C.c_void_p(model._ws_train.data_ptr()), model._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))
+        ctx.model, ctx.B, ctx.keep = model, B, (rgb, flow)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, B = ctx.model, ctx.B
+        lib = _lib.load()
+        dev = dout.device
+        dout = dout.float().contiguous()
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        with torch.cuda.device(dev):
+            check(lib.prego_vit_backward(model._h, B, C.c_void_p(dout.data_ptr()), ptr_array([g.data_ptr() for g in grads]), len(grads),
+                                         1 if model.causal else 0, C.c_void_p(model._ws_train.data_ptr()), model._ws_train.numel(),
+                                         C.c_void_p(_stream_ptr(dev))))
+        return (None, None, None) + tuple(grads)
 
 
 def attention_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True):
