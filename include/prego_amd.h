@@ -12,7 +12,9 @@
  *  - functions return 0 on success, a negative PREGO_E* code otherwise; prego_last_error() gives the text.
  *  - calls only enqueue work on the caller's stream; nothing synchronises except prego_miniroad_check().
  *  - the caller owns inputs, outputs and the workspace; they must stay valid until the stream reaches the
- *    end of the call.  The handle owns converted weight copies and small plan tables.
+ *    end of the call.  The handle owns converted weight copies, the plan tables (pre-sized at create for clips of up to
+ *    131 072 frames: forward() allocates nothing below that) and a pinned staging buffer for the per-call pointer tables
+ *    (host pointer arrays passed to a call may be freed as soon as the call returns).
  *  - one handle per (device, stream); different handles are independent and re-entrant.
  */
 #ifndef PREGO_AMD_H
@@ -48,7 +50,7 @@ typedef void* prego_stream_t;
 typedef struct prego_miniroad prego_miniroad;
 
 int prego_abi_version(void);
-const char* prego_last_error(void);
+const char* prego_last_error(void);     /* most recent error text of the calling thread (any handle, or handle-free calls) */
 
 /* ---- MiniROAD (MROAD, registry name "MiniROAD"): step_recognition/model/rnn/rnn.py:18-71 ---------------- */
 
@@ -58,6 +60,8 @@ const char* prego_last_error(void);
 int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
                           int compute_dtype);
 void prego_miniroad_destroy(prego_miniroad* h);
+/* text of the last error raised by an entry point of THIS handle (handles are independent: one per (device, stream)) */
+const char* prego_miniroad_last_error(const prego_miniroad* h);
 
 /* load_state_dict (main.py:48): device fp32 tensors with the reference's state_dict shapes
  *   layer1.0.weight [emb, d_rgb+d_flow]  layer1.0.bias [emb]   layer1.1.weight/bias [emb]   (rnn.py:39-44)
@@ -127,6 +131,26 @@ int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens,
                             float* g_w_hh, float* g_b_ih, float* g_b_hh, float* g_fc_w, float* g_fc_b,
                             void* fwd_workspace, size_t fwd_workspace_bytes, void* bwd_workspace,
                             size_t bwd_workspace_bytes, prego_stream_t stream);
+
+/* utils/aggregate.py:55-72 on the device: the per-frame argmax of ONE video (device int32 [n_frames], as prego_miniroad_forward
+ * writes it) is cut into consecutive windows of `window` frames (the reference uses 200; the last one may be shorter) and every
+ * window votes for its most frequent class, the lowest class id winning a tie (np.argmax(np.bincount(.))).
+ * votes: device int32 [ceil(n_frames / window)].  n_classes <= 128.  The de-duplication / change lists of aggregate.py:75-78
+ * then run over one value per window instead of one per frame. */
+int prego_window_vote(const int32_t* argmax, int64_t n_frames, int window, int n_classes, int32_t* votes, prego_stream_t stream);
+
+/* torch.optim.AdamW as main.py:62-67 builds it (amsgrad off, maximize off), fused over a tensor list in one launch:
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * params/grads/exp_avg/exp_avg_sq: host arrays of n_tensors device fp32 pointers; numel: host array; step is 1-based. */
+int prego_adamw_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, prego_stream_t stream);
+/* The same step for MiniROAD's ten tensors (prego_miniroad_set_weights' order, reference state_dict shapes) that ALSO rewrites the
+ * handle's converted operand copies from the updated values in the same pass: the training loop (train.py:24 optimizer.step())
+ * needs no prego_miniroad_set_weights after it. */
+int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, prego_stream_t stream);
 
 /* ---- "Transformer" (ViTEnc): step_recognition/model/transformer_models/ViT.py:25-143 ------------------------------ */
 typedef struct prego_vit prego_vit;

@@ -19,11 +19,11 @@ E_TIMEOUT = -4
 # every symbol include/prego_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "prego_abi_version", "prego_last_error",
-    "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_set_weights",
+    "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_last_error", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
     "prego_miniroad_debug_stamps", "prego_miniroad_set_dropout", "prego_oad_loss",
-    "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward",
+    "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
     "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
@@ -56,6 +56,8 @@ def load() -> C.CDLL:
     lib.prego_miniroad_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
     lib.prego_miniroad_destroy.argtypes = [vp]
     lib.prego_miniroad_destroy.restype = None
+    lib.prego_miniroad_last_error.argtypes = [vp]
+    lib.prego_miniroad_last_error.restype = C.c_char_p
     lib.prego_miniroad_set_weights.argtypes = [vp] + [vp] * 10 + [vp]
     lib.prego_miniroad_max_clips.argtypes = [vp]
     lib.prego_miniroad_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32), i64, i32]
@@ -74,6 +76,10 @@ def load() -> C.CDLL:
     lib.prego_miniroad_backward_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32)]
     lib.prego_miniroad_backward_workspace_bytes.restype = sz
     lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]
+    lib.prego_window_vote.argtypes = [vp, i64, i32, i32, vp, vp]
+    f32 = C.c_float
+    lib.prego_adamw_step.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i64, f32, f32, f32, f32, f32, vp]
+    lib.prego_miniroad_adamw_step.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, f32, f32, f32, f32, f32, vp]
     lib.prego_vit_create.argtypes = [C.POINTER(vp)] + [i32] * 8
     lib.prego_vit_destroy.argtypes = [vp]
     lib.prego_vit_destroy.restype = None

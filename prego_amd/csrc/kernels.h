@@ -135,6 +135,14 @@ int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, cons
                        int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s,
                        int relu = 1, int accumulate = 0);
 
+// post-processing (postproc.hip)
+int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, int* bad, hipStream_t s);
+
+// fused multi-tensor AdamW (optim.hip)
+int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,
+                 float wd, hipStream_t s);
+
 // Transformer path (attention.hip, vit.hip)
 int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
                            int dh, int causal, hipStream_t s, float* lse = nullptr);

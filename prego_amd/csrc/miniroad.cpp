@@ -15,6 +15,11 @@
 #include <vector>
 
 static thread_local std::string g_err;
+// the handle whose entry point is running on this thread (set by HandleScope): errors are recorded in it as well, so that
+// prego_miniroad_last_error(h) of one handle is never overwritten by another handle's failure
+struct prego_miniroad;
+static thread_local prego_miniroad* g_cur = nullptr;
+static void note_handle_error(const char* msg);
 static int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -22,6 +27,7 @@ static int fail(int code, const char* fmt, ...) {
   vsnprintf(buf, sizeof buf, fmt, ap);
   va_end(ap);
   g_err = buf;
+  note_handle_error(buf);
   return code;
 }
 // shared with vit.cpp
@@ -86,6 +92,12 @@ struct prego_miniroad {
   size_t cap_t = 0, cap_c = 0;
   // per-call pointer tables (device)
   void** d_ptrs = nullptr;      // [4][max_clips]
+  // pinned host staging for the per-call tables (pointer table, plan arrays): the async H2D copies read it after the call
+  // returns, so it is handle-owned and fenced by an event (never a stack or pageable buffer)
+  char* pin = nullptr; size_t pin_bytes = 0; hipEvent_t pin_ev = nullptr; bool pin_busy = false;
+  bool plan_dirty = false;      // host plan arrays changed, device copies pending
+  bool no_local = false;        // PREGO_GRU_NO_LOCAL (read once at create): skip the XCD-local hand-off fast path
+  std::string err;              // last error of THIS handle (prego_miniroad_last_error)
   // timing
   bool timing = false;
   std::vector<EventPair> ev_pool;
@@ -93,6 +105,13 @@ struct prego_miniroad {
   size_t ev_used = 0;
   double gemm_flop = 0, pack_bytes = 0;
 };
+
+static void note_handle_error(const char* msg) { if (g_cur) g_cur->err = msg; }
+struct HandleScope {
+  explicit HandleScope(prego_miniroad* h) { g_cur = h; }
+  ~HandleScope() { g_cur = nullptr; }
+};
+extern "C" const char* prego_miniroad_last_error(const prego_miniroad* h) { return h ? h->err.c_str() : "handle is NULL"; }
 
 static int max_slots_of(const prego_miniroad* h) { return h->G * 16 * gru_max_tiles(); }
 #define PREGO_MAX_CLIPS 8192     // clips per call (continuous batching packs them into <= max_slots slots)
@@ -135,6 +154,17 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   A((void**)&h->h_state, (size_t)max_slots_of(h) * H * 4);
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
+  // plan tables pre-sized here so that forward() allocates nothing: 131 072 steps (a 72-minute clip at 30 frames/s; the longest
+  // Epic-tent-O video has 31 114 frames) and max_clips clips; only a longer clip than that makes forward() grow them
+  h->cap_t = (size_t)131072 + 1;
+  h->cap_c = (size_t)max_clips_of(h) + 64;
+  A((void**)&h->d_rowoff, h->cap_t * 4); A((void**)&h->d_nact, h->cap_t * 4);
+  A((void**)&h->d_sorted, h->cap_c * 4); A((void**)&h->d_seg_off, (h->cap_c + 1) * 4);
+  A((void**)&h->d_seg_clip, h->cap_c * 4); A((void**)&h->d_seg_start, h->cap_c * 4);
+  h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + 1024;
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
+  h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
@@ -153,6 +183,8 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
                   h->d_seg_start, h->d_ptrs};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+  if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
+  if (h->pin) (void)hipHostFree(h->pin);
   delete h;
 }
 
@@ -162,6 +194,7 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
                                           const float* ln_w, const float* ln_b, const float* w_ih, const float* w_hh,
                                           const float* b_ih, const float* b_hh, const float* fc_w, const float* fc_b,
                                           prego_stream_t stream) {
+  HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!layer1_w || !layer1_b || !ln_w || !ln_b || !w_ih || !w_hh || !b_ih || !b_hh || !fc_w || !fc_b)
     return fail(PREGO_EINVAL, "set_weights: NULL tensor");
@@ -189,7 +222,7 @@ static const double kStepCost[5] = {0.0, 2.4, 4.4, 6.4, 8.4};
 // Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
 // backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
 // minimises the estimated recurrence time: sequential steps = max(longest clip, frames / slots).
-static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single, hipStream_t s) {
+static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single) {
   if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin()) && h->plan_want_single == want_single)
     return PREGO_OK;
   long long total = 0;
@@ -267,26 +300,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   for (int t = smax; t >= 1; --t) { alive += cnt[t]; h->h_nact[t - 1] = alive; }
   h->h_rowoff.assign((size_t)smax + 1, 0);
   for (int t = 0; t < smax; ++t) h->h_rowoff[t + 1] = h->h_rowoff[t] + h->h_nact[t];
-  if ((size_t)smax + 1 > h->cap_t) {
-    if (h->d_rowoff) (void)hipFree(h->d_rowoff);
-    if (h->d_nact) (void)hipFree(h->d_nact);
-    h->cap_t = (size_t)smax + 1 + 1024;
-    HIPCHK(hipMalloc((void**)&h->d_rowoff, h->cap_t * 4));
-    HIPCHK(hipMalloc((void**)&h->d_nact, h->cap_t * 4));
-  }
-  if ((size_t)n + 1 > h->cap_c) {
-    for (int** p : {&h->d_sorted, &h->d_seg_off, &h->d_seg_clip, &h->d_seg_start}) if (*p) { (void)hipFree(*p); *p = nullptr; }
-    h->cap_c = (size_t)n + 64;
-    HIPCHK(hipMalloc((void**)&h->d_sorted, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_off, (h->cap_c + 1) * 4));
-    HIPCHK(hipMalloc((void**)&h->d_seg_clip, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_start, h->cap_c * 4));
-  }
-  // pageable-source async copies: the runtime stages the host data before returning
-  HIPCHK(hipMemcpyAsync(h->d_rowoff, h->h_rowoff.data(), ((size_t)smax + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_nact, h->h_nact.data(), (size_t)smax * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_sorted, h->h_sorted.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_seg_off, h->h_seg_off.data(), (size_t)(S + 1) * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_seg_clip, h->h_seg_clip.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipMemcpyAsync(h->d_seg_start, h->h_seg_start.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+  h->plan_dirty = true;              // device copies are staged by the caller (stage_tables)
   h->t_max = smax;
   h->n_slots = S;
   h->plan_single = single;
@@ -300,6 +314,52 @@ static SlotPlan device_plan(const prego_miniroad* h) {
   p.rowoff = h->d_rowoff; p.nact = h->d_nact; p.seg_off = h->d_seg_off; p.seg_clip = h->d_seg_clip; p.seg_start = h->d_seg_start;
   p.s_max = h->t_max; p.n_slots = h->n_slots;
   return p;
+}
+
+// Stage the per-call pointer table (and, when the plan changed, the plan arrays) through the handle's pinned buffer.
+// `tab4` = 4 * max_clips pointers.  The previous call's copies are fenced by pin_ev before the buffer is rewritten.
+static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_count, hipStream_t s) {
+  if (h->pin_busy) { HIPCHK(hipEventSynchronize(h->pin_ev)); h->pin_busy = false; }
+  const size_t smax = (size_t)h->t_max, S = (size_t)h->n_slots, n = h->h_seg_clip.size();
+  if (h->plan_dirty && (smax + 1 > h->cap_t || n + 1 > h->cap_c)) {
+    // a clip longer than the tables reserved at create (or more clips): grow once, outside the steady state
+    HIPCHK(hipStreamSynchronize(s));
+    if (smax + 1 > h->cap_t) {
+      (void)hipFree(h->d_rowoff); (void)hipFree(h->d_nact);
+      h->cap_t = smax + 1 + 4096;
+      HIPCHK(hipMalloc((void**)&h->d_rowoff, h->cap_t * 4)); HIPCHK(hipMalloc((void**)&h->d_nact, h->cap_t * 4));
+    }
+    if (n + 1 > h->cap_c) {
+      for (int** p : {&h->d_sorted, &h->d_seg_off, &h->d_seg_clip, &h->d_seg_start}) { (void)hipFree(*p); *p = nullptr; }
+      h->cap_c = n + 64;
+      HIPCHK(hipMalloc((void**)&h->d_sorted, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_off, (h->cap_c + 1) * 4));
+      HIPCHK(hipMalloc((void**)&h->d_seg_clip, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_start, h->cap_c * 4));
+    }
+    (void)hipHostFree(h->pin);
+    h->pin = nullptr;
+    h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + 1024;
+    HIPCHK(hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault));
+  }
+  char* p = h->pin;
+  auto put = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    std::memcpy(p, src, bytes);
+    const hipError_t e = hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, s);
+    p += (bytes + 15) / 16 * 16;
+    return e;
+  };
+  HIPCHK(put(h->d_ptrs, tab4, tab_count * sizeof(void*)));
+  if (h->plan_dirty) {
+    HIPCHK(put(h->d_rowoff, h->h_rowoff.data(), (smax + 1) * 4));
+    HIPCHK(put(h->d_nact, h->h_nact.data(), smax * 4));
+    HIPCHK(put(h->d_sorted, h->h_sorted.data(), S * 4));
+    HIPCHK(put(h->d_seg_off, h->h_seg_off.data(), (S + 1) * 4));
+    HIPCHK(put(h->d_seg_clip, h->h_seg_clip.data(), n * 4));
+    HIPCHK(put(h->d_seg_start, h->h_seg_start.data(), n * 4));
+    h->plan_dirty = false;
+  }
+  HIPCHK(hipEventRecord(h->pin_ev, s));
+  h->pin_busy = true;
+  return PREGO_OK;
 }
 
 struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, total; };
@@ -361,6 +421,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                                       const float* const* flow, float* const* out, int32_t* const* argmax,
                                       const float* h0, float* h_last, int flags, void* workspace,
                                       size_t workspace_bytes, prego_stream_t stream) {
+  HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "forward before set_weights");
   if (n_clips <= 0 || !lens) return fail(PREGO_EINVAL, "no clips");
@@ -369,7 +430,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (!workspace) return fail(PREGO_EINVAL, "workspace is NULL");
   hipStream_t s = (hipStream_t)stream;
   const bool want_single = h0 != nullptr || h_last != nullptr || (flags & PREGO_FWD_KEEP) != 0;
-  int rc = build_plan(h, n_clips, lens, want_single, s);
+  int rc = build_plan(h, n_clips, lens, want_single);
   if (rc) return rc;
   const SlotPlan plan = device_plan(h);
   const int n_slots = h->n_slots;
@@ -386,7 +447,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     tab[2 * MC + i] = out ? out[i] : nullptr;
     tab[3 * MC + i] = argmax ? argmax[i] : nullptr;
   }
-  HIPCHK(hipMemcpyAsync(h->d_ptrs, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  rc = stage_tables(h, tab.data(), tab.size(), s);
+  if (rc) return rc;
   const float* const* d_rgb_ptrs = h->d_rgb > 0 ? (const float* const*)(h->d_ptrs + 0 * MC) : nullptr;
   const float* const* d_flow_ptrs = any_flow ? (const float* const*)(h->d_ptrs + 1 * MC) : nullptr;
   float* const* d_out_ptrs = out ? (float* const*)(h->d_ptrs + 2 * MC) : nullptr;
@@ -470,7 +532,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
-    ga.sync = (getenv("PREGO_GRU_NO_LOCAL") == nullptr) ? h->flags : nullptr;   // flags[0..15] double as the rendezvous words
+    ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
     ev = ev_begin(h, 1, s);
     if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
     ev_end(ev, s);
@@ -488,6 +550,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
 }
 
 extern "C" int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream) {
+  HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   unsigned ab = 0;
@@ -511,6 +574,7 @@ extern "C" int prego_miniroad_timing_enable(prego_miniroad* h, int enable) {
 extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flop,
                                           double* gru_ms, int64_t* gru_launches, double* pack_ms,
                                           int64_t* pack_launches, double* pack_bytes) {
+  HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   double ms[3] = {0, 0, 0};
   int64_t n[3] = {0, 0, 0};
@@ -549,6 +613,7 @@ extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long
 // training: dropout control, loss, backward
 // ================================================================================================
 extern "C" int prego_miniroad_set_dropout(prego_miniroad* h, float p, uint64_t seed) {
+  HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!(p >= 0.f && p < 1.f)) return fail(PREGO_EINVAL, "dropout p = %f", (double)p);
   h->drop_p = p;
@@ -634,6 +699,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
                                        float* g_w_hh, float* g_b_ih, float* g_b_hh, float* g_fc_w, float* g_fc_b,
                                        void* fwd_workspace, size_t fwd_bytes, void* bwd_workspace, size_t bwd_bytes,
                                        prego_stream_t stream) {
+  HandleScope scope_(h);
   if (!h || !lens || !dlogits || !fwd_workspace || !bwd_workspace) return fail(PREGO_EINVAL, "backward: NULL argument");
   if (!g_layer1_w || !g_layer1_b || !g_ln_w || !g_ln_b || !g_w_ih || !g_w_hh || !g_b_ih || !g_b_hh || !g_fc_w || !g_fc_b)
     return fail(PREGO_EINVAL, "backward: NULL gradient tensor");
@@ -669,7 +735,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   const int MC = max_clips_of(h);
   std::vector<const void*> tab((size_t)MC, nullptr);
   for (int i = 0; i < n_clips; ++i) { if (!dlogits[i]) return fail(PREGO_EINVAL, "dlogits[%d] is NULL", i); tab[i] = dlogits[i]; }
-  HIPCHK(hipMemcpyAsync(h->d_ptrs, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  { const int rc = stage_tables(h, tab.data(), tab.size(), s); if (rc) return rc; }
   const float* const* d_dl = (const float* const*)h->d_ptrs;
 
   // ---- head: logits = relu(h) Wc^T + bc  (rnn.py:62-64)
@@ -703,7 +769,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
       ba.dGI = (float*)(bw + L.dGI); ba.dGH = (float*)(bw + L.dGH); ba.dGIop = bw + L.dGIop; ba.dGHop = bw + L.dGHop;
       ba.hx = bw + L.bhx; ba.sync = (unsigned*)(bw + L.bsync); ba.abort_word = h->abort_word;
       ba.rowoff = h->d_rowoff; ba.nact = h->d_nact; ba.t_max = h->t_max; ba.n_clips = h->n_slots; ba.G = h->G;
-      ba.force_sc1 = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
+      ba.force_sc1 = h->no_local ? 1 : 0;
       persistent = launch_gru_bptt(bf, H, nct, ba, s) == 0;
     }
   }
@@ -746,6 +812,68 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   launch_transpose_convert(bf, bf, X, R, kx, kx, bw + L.T2, Rp, s);
   if (kx < din) HIPCHK(hipMemsetAsync(g_layer1_w, 0, (size_t)E * din * 4, s));          // zero-flow columns: zero gradient
   gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_layer1_w, din, E, kx, Rp, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ================================================================================================
+// post-processing: utils/aggregate.py:55-72 (the 200-frame majority vote) on the device
+// ================================================================================================
+extern "C" int prego_window_vote(const int32_t* argmax, int64_t n_frames, int window, int n_classes, int32_t* votes,
+                                 prego_stream_t stream) {
+  if (!argmax || !votes) return fail(PREGO_EINVAL, "window_vote: NULL argument");
+  if (launch_window_vote(argmax, n_frames, window, n_classes, votes, nullptr, (hipStream_t)stream))
+    return fail(PREGO_EINVAL, "window_vote: n_frames %lld, window %d, n_classes %d (1..128)", (long long)n_frames, window, n_classes);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ================================================================================================
+// optimizer: torch.optim.AdamW of main.py:62-67 on the ABI
+// ================================================================================================
+extern "C" int prego_adamw_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                                float* const* exp_avg_sq, const int64_t* numel, int64_t step, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, prego_stream_t stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return fail(PREGO_EINVAL, "adamw: NULL argument");
+  std::vector<long long> n(numel, numel + std::max(n_tensors, 0));
+  if (launch_adamw(n_tensors, params, grads, exp_avg, exp_avg_sq, nullptr, n.data(), false, step, lr, beta1, beta2, eps, weight_decay,
+                   (hipStream_t)stream))
+    return fail(PREGO_EINVAL, "adamw: bad tensor list (n = %d, step = %lld)", n_tensors, (long long)step);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// The same step for the ten MiniROAD tensors (prego_miniroad_set_weights' order) that ALSO refreshes the handle's operand copies
+// (bf16 / fp32 weights, padded classifier, folded GRU biases) in the same pass: no set_weights call after the step.
+extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params, const float* const* grads, float* const* exp_avg,
+                                         float* const* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return fail(PREGO_EINVAL, "adamw: NULL argument");
+  if (!h->have_weights) return fail(PREGO_EINVAL, "adamw step before set_weights");
+  hipStream_t s = (hipStream_t)stream;
+  const long long din = h->d_rgb + h->d_flow, E = h->emb, H = h->hid, C = h->ncls;
+  // set_weights order: layer1.0.weight, layer1.0.bias, layer1.1.weight, layer1.1.bias, w_ih, w_hh, b_ih, b_hh, fc.weight, fc.bias
+  const long long numel[10] = {E * din, E, E, E, 3 * H * E, 3 * H * H, 3 * H, 3 * H, C * H, C};
+  // operand-typed copies (weights) first, fp32 copies (biases, LayerNorm) second: two launches, one element type each
+  float* pw[4] = {params[0], params[4], params[5], params[8]};
+  const float* gw[4] = {grads[0], grads[4], grads[5], grads[8]};
+  float* mw[4] = {exp_avg[0], exp_avg[4], exp_avg[5], exp_avg[8]};
+  float* vw[4] = {exp_avg_sq[0], exp_avg_sq[4], exp_avg_sq[5], exp_avg_sq[8]};
+  void* cw[4] = {h->w1, h->w_ih, h->w_hh, h->w_c};            // w_c: rows >= n_classes stay zero (same linear index below them)
+  const long long nw[4] = {numel[0], numel[4], numel[5], numel[8]};
+  float* pb[6] = {params[1], params[2], params[3], params[6], params[7], params[9]};
+  const float* gb[6] = {grads[1], grads[2], grads[3], grads[6], grads[7], grads[9]};
+  float* mb[6] = {exp_avg[1], exp_avg[2], exp_avg[3], exp_avg[6], exp_avg[7], exp_avg[9]};
+  float* vb[6] = {exp_avg_sq[1], exp_avg_sq[2], exp_avg_sq[3], exp_avg_sq[6], exp_avg_sq[7], exp_avg_sq[9]};
+  void* cb[6] = {h->b1, h->ln_g, h->ln_b, nullptr, nullptr, h->b_c};
+  const long long nb[6] = {numel[1], numel[2], numel[3], numel[6], numel[7], numel[9]};
+  for (int i = 0; i < 10; ++i) if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return fail(PREGO_EINVAL, "adamw: tensor %d is NULL", i);
+  if (launch_adamw(4, pw, gw, mw, vw, cw, nw, h->bf16, step, lr, beta1, beta2, eps, weight_decay, s) ||
+      launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s))
+    return fail(PREGO_EINVAL, "adamw: bad step %lld", (long long)step);
+  launch_add_vec(params[6], params[7], h->bias2, (int)(3 * H), (int)(2 * H), s);      // r,z rows: b_ih + b_hh ; n rows: b_ih
+  HIPCHK(hipMemcpyAsync(h->b_hn, params[7] + 2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

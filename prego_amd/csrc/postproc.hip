@@ -1,0 +1,54 @@
+// Post-processing of the per-frame predictions on the device:
+//   window_vote   utils/aggregate.py:55-72 - non-overlapping windows of `window` (200) frames, each replaced by its most frequent
+//                 class (np.argmax(np.bincount(...)): the LOWEST class id wins a tie); the int32 per-frame argmax the head kernel
+//                 wrote never leaves HBM, only one int32 per window does.
+// One wave per window: a segmented histogram in LDS (integer atomics: exact and order-independent), then a 64-lane argmax over
+// (count, -class).
+#include "common.h"
+#include "kernels.h"
+
+#define VOTE_MAX_CLASSES 128
+
+__global__ __launch_bounds__(256) void window_vote_kernel(const int* __restrict__ pred, long long n_frames, int window, int n_classes,
+                                                          int* __restrict__ votes, int* __restrict__ bad /*nullable: set to 1 on an id out of range*/) {
+  __shared__ int hist[4][VOTE_MAX_CLASSES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long n_win = (n_frames + window - 1) / window;
+  for (long long w0 = (long long)blockIdx.x * 4; w0 < n_win; w0 += (long long)gridDim.x * 4) {   // block-uniform trip count
+    const long long w = w0 + wave;
+    hist[wave][lane] = 0; hist[wave][lane + 64] = 0;
+    __syncthreads();
+    if (w < n_win) {
+      const long long s = w * window;
+      const long long e = s + window < n_frames ? s + window : n_frames;
+      for (long long i = s + lane; i < e; i += 64) {
+        const int c = pred[i];
+        if (c >= 0 && c < n_classes) atomicAdd(&hist[wave][c], 1);
+        else if (bad) *bad = 1;
+      }
+    }
+    __syncthreads();
+    if (w < n_win) {
+      // best = max count, ties -> lowest class id (np.argmax takes the first maximum)
+      int c0 = hist[wave][lane], c1 = hist[wave][lane + 64];
+      int best_cnt = c0, best_id = lane;
+      if (c1 > best_cnt) { best_cnt = c1; best_id = lane + 64; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int oc = __shfl_xor(best_cnt, off, 64), oi = __shfl_xor(best_id, off, 64);
+        if (oc > best_cnt || (oc == best_cnt && oi < best_id)) { best_cnt = oc; best_id = oi; }
+      }
+      if (lane == 0) votes[w] = best_id;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, int* bad, hipStream_t s) {
+  if (n_frames <= 0 || window <= 0 || n_classes <= 0 || n_classes > VOTE_MAX_CLASSES) return -1;
+  const long long n_win = (n_frames + window - 1) / window;
+  long long blocks = (n_win + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  window_vote_kernel<<<(int)blocks, 256, 0, s>>>(pred, n_frames, window, n_classes, votes, bad);
+  return 0;
+}

@@ -37,13 +37,30 @@ class Evaluate(nn.Module):
         self.max_frames_per_batch = int(cfg.get("eval_frames_per_batch", 4_000_000))
         self.output_dir = cfg.get("eval_output_dir", "output_miniRoad")
         self.last_fps = None
+        self._copy_stream = None             # side stream for the H2D feature copies (double buffering against the compute stream)
 
     def _flush(self, model, batch, pred_scores, gt_targets, output, device):
         if not batch:
             return
         zero_flow = bool(getattr(model, "assume_zero_flow", False))
-        rgb = [b[0].to(device, non_blocking=True) for b in batch]
-        flow = None if zero_flow else [b[1].to(device, non_blocking=True) for b in batch]
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            # H2D on a side stream: the copies of this batch run while the previous batch is still computing (the loader's
+            # pin_memory=True makes them true async DMA); the compute stream waits on one event per batch
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(self._copy_stream):
+                rgb = [b[0].to(dev, non_blocking=True) for b in batch]
+                flow = None if zero_flow else [b[1].to(dev, non_blocking=True) for b in batch]
+                ready = torch.cuda.Event()
+                ready.record(self._copy_stream)
+            cur.wait_event(ready)
+            for t in rgb + (flow or []):
+                t.record_stream(cur)         # allocated on the copy stream, consumed on the compute stream
+        else:
+            rgb = [b[0].to(device) for b in batch]
+            flow = None if zero_flow else [b[1].to(device) for b in batch]
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
         for (r, f, target, vid), p, a in zip(batch, probs, args):
             # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
@@ -52,11 +69,13 @@ class Evaluate(nn.Module):
             gt_targets.append(target.to(p.device, non_blocking=True))
             if self.cfg["eval"] is not None:
                 output[vid] = {"pred": a.cpu().numpy().tolist(), "gt": torch.argmax(target, dim=1).numpy().tolist()}
+                self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
         batch.clear()
 
     def eval(self, model, dataloader, logger, device):
         model.eval()
         output = {}
+        self.last_device_argmax = {}
         max_clips = model.engine().max_clips
         # data-parallel eval: videos are independent, so under torch.distributed rank r takes every world-th video of
         # the loader's order (no data-path collective); rank 0 gathers the per-video results once at the end

@@ -90,8 +90,12 @@ def main(argv=None):
     trainloader = build_data_loader(cfg, mode="train")
     criterion = build_criterion(cfg, device)
     train_one_epoch = build_trainer(cfg)
-    optim = torch.optim.AdamW if cfg["optimizer"] == "AdamW" else torch.optim.Adam
-    optimizer = optim([{"params": net.parameters(), "initial_lr": cfg["lr"]}], lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    if cfg["optimizer"] == "AdamW":          # main.py:62-67, arithmetic on the HIP path (one fused launch, csrc/optim.hip)
+        from .optim import FusedAdamW
+        optimizer = FusedAdamW([{"params": list(net.parameters()), "initial_lr": cfg["lr"]}], lr=cfg["lr"],
+                               weight_decay=cfg["weight_decay"], model=net)
+    else:
+        optimizer = torch.optim.Adam([{"params": net.parameters(), "initial_lr": cfg["lr"]}], lr=cfg["lr"], weight_decay=cfg["weight_decay"])
     best_mAP, best_epoch = 0, 0
     for epoch in range(1, cfg["num_epoch"] + 1):
         epoch_loss = train_one_epoch(trainloader, net, criterion, optimizer, None, epoch, device, None, scheduler=None)

@@ -1,0 +1,83 @@
+"""`FusedAdamW`: torch.optim.AdamW as step_recognition/main.py:62-67 builds it (same constructor arguments, same `state`
+entries - 'step', 'exp_avg', 'exp_avg_sq' - so optimizer state dicts interchange), with the arithmetic in ONE fused HIP launch
+over all tensors (csrc/optim.hip) instead of torch's per-op kernels.  For a `MiniROAD` model the step also rewrites the engine's
+bf16 / fp32 operand copies of the weights from the updated values in the same pass, so the training loop never re-ingests the
+17.9 M parameters (`prego_miniroad_set_weights`) after `optimizer.step()`."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import PregoError, check, ptr_array
+from .engine import _PARAM_ORDER, _stream_ptr
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._model = model if model is not None and hasattr(model, "engine") and hasattr(model, "gru") else None
+
+    def _state(self, p):
+        st = self.state[p]
+        if not st:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise PregoError("FusedAdamW: parameters must be contiguous fp32 CUDA tensors (the HIP path has no CPU fallback)")
+            states = [self._state(p) for p in ps]
+            steps = {int(st["step"].item()) for st in states}
+            if len(steps) != 1:
+                raise PregoError("FusedAdamW: parameters of one group must share the step count")
+            step = steps.pop() + 1
+            for st in states:
+                st["step"] += 1
+            grads = [p.grad.contiguous() for p in ps]
+            dev = ps[0].device
+            b1, b2 = group["betas"]
+            hyper = (step, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]))
+            m = self._model
+            fused_model = False
+            if m is not None:
+                named = dict(m.named_parameters())
+                want = [named[k] for k in _PARAM_ORDER]
+                fused_model = len(ps) == len(want) and {id(p) for p in ps} == {id(p) for p in want}
+                if fused_model:             # the C ABI takes the ten tensors in prego_miniroad_set_weights' order
+                    ps = want
+                    states = [self.state[p] for p in ps]
+                    grads = [p.grad.contiguous() for p in ps]
+            with torch.cuda.device(dev):
+                if fused_model:
+                    eng = m.engine()        # weights already ingested (versions unchanged since the forward)
+                    check(lib.prego_miniroad_adamw_step(
+                        eng.h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
+                        ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
+                        *hyper, C.c_void_p(_stream_ptr(dev))))
+                    # the engine's operand copies are now those of the NEW values; parameter versions did not move, so
+                    # model.engine() will not re-ingest them
+                else:
+                    numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
+                    check(lib.prego_adamw_step(
+                        len(ps), ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
+                        ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
+                        numel, *hyper, C.c_void_p(_stream_ptr(dev))))
+                    torch._C._increment_version(ps)      # raw-pointer update: tell autograd / the weight caches the values moved
+        return loss

@@ -130,7 +130,7 @@ def test_g4c_train_step_16x128(dtype):
     loss.backward()
     model.engine().check()
     ltol = 2e-2 if dtype == "bf16" else 2e-4
-    assert abs(float(loss) - float(g["loss"])) < ltol, (float(loss), float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < ltol, (float(loss.detach()), float(g["loss"]))
     lerr = np.abs(out["logits"][:, -1, :].detach().cpu().numpy() - g["logits_last"]).max()
     assert lerr < (3e-2 if dtype == "bf16" else 1e-3), lerr
     # fp32 operands: 0.5 % of every tensor's norm.  bf16 operands (dGH and the wgrad operands are rounded to bf16 at each of the
