@@ -27,7 +27,9 @@ SYMBOLS = [
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
     "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
-    "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd",
+    "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
+    "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
+    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd",
 ]
 
 
@@ -95,6 +97,13 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_workspace_bytes.argtypes = [i32, i32, i32]
     lib.prego_attention_layer_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward.argtypes = [i32] * 5 + [vp] * 10 + [vp, sz, vp]
+    lib.prego_attention_layer_create.argtypes = [C.POINTER(vp), i32, i32]
+    lib.prego_attention_layer_destroy.argtypes = [vp]
+    lib.prego_attention_layer_destroy.restype = None
+    lib.prego_attention_layer_set_weights.argtypes = [vp] + [vp] * 8 + [vp]
+    lib.prego_attention_layer_handle_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.prego_attention_layer_handle_workspace_bytes.restype = sz
+    lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.prego_debug_attention_bwd.argtypes = [i32] * 5 + [vp] * 7 + [vp]
     lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:          # fail loudly at load time if the library is stale

@@ -1,166 +1,206 @@
 // Flash-style multi-head attention for the "Transformer" path (ViTEnc) and for the causal AttentionLayer:
 //   SelfAttention.forward   model/transformer_models/Attention.py:21-41   softmax(q k^T * dh^-0.5) v, no mask
 //   FullAttention.forward   model/transformer_models/attn.py:35-57        masked_fill(triu(1), -inf) then softmax(scale * s)
-// The reference materialises the [B,h,L,L] score tensor (33.6 MB per window at L = 1025); here scores never leave
-// registers: per workgroup 64 queries (4 waves x 16 rows), K and V^T tiles of 64 keys staged in LDS, S = Q K^T on
-// MFMA 16x16x32 bf16, online softmax with the row reduce done by 16-lane shuffles over the accumulator layout
-// (col = lane&15, row = (lane>>4)*4 + reg), P re-laid out through a per-wave LDS tile, O += P V on MFMA.
-// Causal: key tiles beyond the diagonal are skipped.  The softmax scale is folded into Q by the QKV GEMM epilogue.
-// Layouts (bf16): Q, K [B, h, N, DH]; V^T [B, h, DH, Npad] (Npad multiple of 64, pad zeroed); out [B, N, h*DH].
+// The reference materialises the [B,h,L,L] score tensor (33.6 MB per window at L = 1025); here scores never leave registers.
+// The softmax scale is folded into Q by the QKV GEMM epilogue.  Causal: key tiles beyond the diagonal are skipped and the
+// heaviest query blocks are dispatched first.
 #include "common.h"
 #include "kernels.h"
 
-#define AQ 64      // queries per workgroup
 #define AK 64      // keys per tile
 
-template <int DH>
-__global__ __launch_bounds__(256) void flash_attention_kernel(
-    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ Vt, bf16_t* __restrict__ out,
-    int N, int Npad, int heads, int causal, float* __restrict__ lse /*nullable: [B,h,N] log-sum-exp of the scaled scores (training)*/) {
-  constexpr int KS = DH / 32;            // k-steps of QK^T
-  constexpr int DT = DH / 16;            // output column tiles
-  constexpr int KLD = DH + 8;            // LDS row pitch of the K tile (elements): 16-byte skew per row
-  constexpr int VLD = AK + 8;            // LDS row pitch of the V^T tile and of P
+// ------------------------------------------------------------------------------------------------------
+// "Query on the lane" (swapped QK^T, cdna_hip_programming.md T12 / Attention backward): S^T = K_tile Q^T has the keys in
+// the accumulator registers and the query on the lane, so
+//   * the softmax statistics of a query are per-LANE scalars (the reduce over keys is 16 in-register values + two shuffles),
+//   * P^T is ALREADY the B operand of O^T += V_tile^T P^T (two 16-row accumulator tiles = the 8 k-elements of a lane, in the
+//     order {4g..4g+3, 16+4g..16+4g+3}): no LDS round trip for P,
+//   * V stays ROW-major [key][d] and is read transposed by ds_read_b64_tr_b16 in that k order: no V^T tensor at all,
+//   * the output leaves as 8-byte stores of four consecutive head-dim elements.
+// A wave owns QG groups of 16 queries (QG = 2: 128 queries per workgroup): every K / V fragment read from LDS feeds QG MFMAs,
+// which halves the LDS bytes per FLOP (dh = 256 is otherwise LDS-bound: each wave re-reads the whole 64 KB tile pair).
+// K and V tiles of 64 keys are double-buffered in LDS: tile kt+1 travels global -> registers while tile kt is multiplied and
+// lands in the other buffer behind ONE barrier per tile.
+// Layouts (bf16): Q [B,h,Nq,DH] (pre-scaled), K, V [B,h,N,DH]; out [B,Nq,h*DH]; lse fp32 [B,h,Nq] (nullable).
+// Query i sits at sequence position i (causal: keys <= i).
+// ------------------------------------------------------------------------------------------------------
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+template <int DH, int QG>
+__global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* __restrict__ out,
+    int Nq, int N, int heads, int causal, float* __restrict__ lse) {
+  constexpr int KS = DH / 32, DT = DH / 16;
+  constexpr int CPR = DH / 8;                         // 16-byte chunks per row
+  constexpr int SW = CPR < 16 ? CPR : 16;             // XOR swizzle period: chunk position = chunk ^ (row & (SW - 1))
+  constexpr int RPI = 64 / CPR;                       // rows per LDS-DMA wave-instruction (1 KiB)
+  constexpr int NI = AK / RPI / 4;                    // DMA instructions per wave, tile and tensor
+  constexpr int TILE = AK * DH;                       // elements of one tile image (unpadded rows: the swizzle spreads the banks)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t* sK = (bf16_t*)smem;                         // [AK][KLD]
-  bf16_t* sV = sK + AK * KLD;                         // [DH][VLD]
-  bf16_t* sP = sV + DH * VLD;                         // [4 waves][16][VLD]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * AQ;
-  const bf16_t* Qb = Q + (size_t)bh * N * DH;
+  bf16_t* sK = (bf16_t*)smem;                         // [2][AK][DH]
+  bf16_t* sV = sK + 2 * TILE;                         // [2][AK][DH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  // causal: the heaviest query blocks (most key tiles) are dispatched first
+  const int qb = causal ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int q0 = qb * (64 * QG);
+  const bf16_t* Qb = Q + (size_t)bh * Nq * DH;
   const bf16_t* Kb = K + (size_t)bh * N * DH;
-  const bf16_t* Vb = Vt + (size_t)bh * DH * Npad;
+  const bf16_t* Vb = V + (size_t)bh * N * DH;
 
-  // Q fragments (A operand: row = query, k = d)
-  int qrow = q0 + wave * 16 + l15;
-  const int qrow_ld = qrow < N ? qrow : N - 1;
-  bf16x8 qf[KS];
+  int own[QG];
+  bf16x8 qf[QG][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qb + (size_t)qrow_ld * DH + ks * 32 + 8 * l4);
+  for (int u = 0; u < QG; ++u) {
+    own[u] = q0 + (wave * QG + u) * 16 + l15;
+    const int ld = own[u] < Nq ? own[u] : Nq - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[u][ks] = *(const bf16x8*)(Qb + (size_t)ld * DH + ks * 32 + 8 * g);
+  }
+  f32x4 o[QG][DT];
+  float m_run[QG], l_run[QG];
+#pragma unroll
+  for (int u = 0; u < QG; ++u) {
+    m_run[u] = -INFINITY; l_run[u] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) o[u][d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int q_hi = (q0 + 64 * QG - 1 < Nq - 1) ? q0 + 64 * QG - 1 : Nq - 1;
+  const int n_tiles = causal ? ((q_hi < N - 1 ? q_hi : N - 1) / AK + 1) : (N + AK - 1) / AK;
 
-  f32x4 o[DT];
+  // HBM -> LDS by 16-byte LDS-DMA, no staging registers: lane -> (row of the instruction, chunk position); the SOURCE chunk is
+  // the swizzled one, so the image is lane-linear (what the DMA writes) and the reads apply the same XOR
+  const int d_row = lane / CPR, d_pos = lane % CPR;
+  auto dma = [&](int buf, int kt) {
 #pragma unroll
-  for (int d = 0; d < DT; ++d) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run[4], l_run[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { m_run[e] = -INFINITY; l_run[e] = 0.f; }
-
-  const int q_hi = (q0 + AQ - 1 < N - 1) ? q0 + AQ - 1 : N - 1;            // last query of this block
-  const int n_tiles = causal ? (q_hi / AK + 1) : (N + AK - 1) / AK;
+    for (int i = 0; i < NI; ++i) {
+      const int r0 = (wave * NI + i) * RPI;                                  // wave-uniform first row of this instruction
+      const int r = r0 + d_row;
+      int kr = kt * AK + r; if (kr > N - 1) kr = N - 1;                      // clamped; masked below
+      const size_t src = (size_t)kr * DH + ((d_pos ^ (r & (SW - 1))) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + src),
+                                       (__attribute__((address_space(3))) void*)(sK + buf * TILE + r0 * DH), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + src),
+                                       (__attribute__((address_space(3))) void*)(sV + buf * TILE + r0 * DH), 16, 0, 0);
+    }
+  };
+  dma(0, 0);
+  __syncthreads();                                                           // vmcnt(0) + barrier: tile 0 landed
+  const int qp = l15 >> 2, pp = l15 & 3;
   for (int kt = 0; kt < n_tiles; ++kt) {
-    const int k0 = kt * AK;
-    __syncthreads();                                  // previous tile fully consumed
-    // stage K tile: AK rows x DH elements (rows >= N clamped; masked below)
-    for (int c = tid; c < AK * (DH / 8); c += 256) {
-      const int r = c / (DH / 8), ch = c % (DH / 8);
-      int kr = k0 + r; if (kr > N - 1) kr = N - 1;
-      *(uint4*)(sK + r * KLD + ch * 8) = *(const uint4*)(Kb + (size_t)kr * DH + ch * 8);
-    }
-    // stage V^T tile: DH rows x AK keys (in bounds: Npad is a multiple of AK)
-    for (int c = tid; c < DH * (AK / 8); c += 256) {
-      const int r = c / (AK / 8), ch = c % (AK / 8);
-      *(uint4*)(sV + r * VLD + ch * 8) = *(const uint4*)(Vb + (size_t)r * Npad + k0 + ch * 8);
-    }
-    __syncthreads();
-
-    // S = Q K^T  (4 key tiles of 16)
-    f32x4 s[4];
+    const int buf = kt & 1, k0 = kt * AK;
+    if (kt + 1 < n_tiles) dma(buf ^ 1, kt + 1);                              // lands under this tile's MFMAs
+    const bf16_t* cK = sK + buf * TILE;
+    const bf16_t* cV = sV + buf * TILE;
+    // S^T = K_tile . Q^T: rows = key (16 t + 4 g + e), column = query (lane & 15); one K fragment feeds QG MFMAs
+    f32x4 st[QG][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) s[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < QG; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 kf = *(const bf16x8*)(sK + (j * 16 + l15) * KLD + ks * 32 + 8 * l4);
-        s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[j], 0, 0, 0);
-      }
-    // mask + online softmax; this lane: rows qr = q0 + wave*16 + l4*4 + e, key columns k0 + j*16 + l15
-    float alpha[4];
+      for (int t = 0; t < 4; ++t) {
+        const int row = t * 16 + l15;
+        const bf16x8 kf = *(const bf16x8*)(cK + row * DH + (((ks * 4 + g) ^ (row & (SW - 1))) << 3));
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int qr = q0 + wave * 16 + l4 * 4 + e;
+        for (int u = 0; u < QG; ++u) st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][t], 0, 0, 0);
+      }
+    // online softmax, per lane = per query
+    bf16x8 pf[QG][2];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int key = k0 + j * 16 + l15;
-        const bool dead = key >= N || (causal && key > qr);
-        const float v = dead ? -INFINITY : s[j][e];
-        s[j][e] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      const float m_new = fmaxf(m_run[e], mx);
-      const float msafe = (m_new == -INFINITY) ? 0.f : m_new;     // fully masked so far (rows >= N only)
-      alpha[e] = __expf(m_run[e] - msafe);
+        for (int e = 0; e < 4; ++e) {
+          const int key = k0 + t * 16 + 4 * g + e;
+          const bool dead = key >= N || (causal && key > own[u]);
+          const float v = dead ? -INFINITY : st[u][t][e];
+          st[u][t][e] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);
+      const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __expf(m_run[u] - msafe);
       float rs = 0.f;
+      unsigned pw[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float p = __expf(s[j][e] - msafe);
-        s[j][e] = p;
-        rs += p;
+      for (int t = 0; t < 4; ++t) {
+        float p[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p[e] = __expf(st[u][t][e] - msafe); rs += p[e]; }
+        pw[t >> 1][2 * (t & 1)] = pack_bf16x2(p[0], p[1]);
+        pw[t >> 1][2 * (t & 1) + 1] = pack_bf16x2(p[2], p[3]);
+      }
+      rs += __shfl_xor(rs, 16, 64);
+      rs += __shfl_xor(rs, 32, 64);
+      l_run[u] = l_run[u] * alpha + rs;
+      m_run[u] = m_new;
+      if (__any(alpha != 1.0f)) {                                            // the running maximum moved for some query of the wave
+#pragma unroll
+        for (int d = 0; d < DT; ++d) { o[u][d][0] *= alpha; o[u][d][1] *= alpha; o[u][d][2] *= alpha; o[u][d][3] *= alpha; }
       }
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) rs += __shfl_xor(rs, off, 64);
-      l_run[e] = l_run[e] * alpha[e] + rs;
-      m_run[e] = m_new;
+      for (int s2 = 0; s2 < 2; ++s2) pf[u][s2] = __builtin_bit_cast(bf16x8, (u32x4){pw[s2][0], pw[s2][1], pw[s2][2], pw[s2][3]});
     }
+    // O^T += V_tile^T . P^T: A = V read transposed (rows d = 16 dt + lane & 15, k = keys {32 s + 4 g + 0..3, 32 s + 16 + 4 g + 0..3});
+    // the lane that supplies the address of block row q', columns 4 p .. 4 p + 3 is lane 4 q' + p of its 16-lane group
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[d][e] *= alpha[e];
-    // P -> LDS as [query row][key], bf16 (re-layout from accumulator form to A-operand form)
-    bf16_t* pw = sP + wave * 16 * VLD;
+      for (int dt = 0; dt < DT; ++dt) {
+        const int ra = 32 * s2 + 4 * g + qp, rb = ra + 16;                   // rb & (SW-1) == ra & (SW-1)
+        const int cc = (((2 * dt + (pp >> 1)) ^ (ra & (SW - 1))) << 3) + 4 * (pp & 1);
+        typedef __attribute__((address_space(3))) v4s_t* lds_v4s;
+        const v4s_t ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + ra * DH + cc));
+        const v4s_t tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + rb * DH + cc));
+        const bf16x8 vf = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < QG; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
+      }
+    __syncthreads();                                   // vmcnt(0) + barrier: next tile landed, everyone done reading this one
+  }
+  // epilogue: out[b, q, head*DH + d] = O^T[d][q] / l ; d = 16 dt + 4 g + e -> one 8-byte store per dt
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pw[(l4 * 4 + e) * VLD + j * 16 + l15] = f2bf(s[j][e]);
-    __syncthreads();
-    // O += P V : A = P (row = query, k = key), B = V^T tile (col = d, k = key)
+  for (int u = 0; u < QG; ++u)
+    if (own[u] < Nq) {
+      const float inv = 1.0f / l_run[u];
+      if (lse != nullptr && g == 0) lse[(size_t)bh * Nq + own[u]] = m_run[u] + logf(l_run[u]);
+      bf16_t* orow = out + ((size_t)b * Nq + own[u]) * heads * DH + (size_t)hd * DH;
 #pragma unroll
-    for (int ks = 0; ks < AK / 32; ++ks) {
-      const bf16x8 pf = *(const bf16x8*)(pw + l15 * VLD + ks * 32 + 8 * l4);
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const bf16x8 vf = *(const bf16x8*)(sV + (d * 16 + l15) * VLD + ks * 32 + 8 * l4);
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[d], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) {
+        uint2 w;
+        w.x = pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv);
+        w.y = pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv);
+        *(uint2*)(orow + dt * 16 + 4 * g) = w;
       }
     }
-  }
-  // epilogue: out[b, q, head*DH + d] = O / l
-  const int b = bh / heads, hd = bh % heads;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int qr = q0 + wave * 16 + l4 * 4 + e;
-    if (qr < N) {
-      const float inv = 1.0f / l_run[e];
-      if (lse != nullptr && l15 == 0) lse[(size_t)bh * N + qr] = m_run[e] + logf(l_run[e]);
-      bf16_t* orow = out + ((size_t)b * N + qr) * heads * DH + hd * DH;
-#pragma unroll
-      for (int d = 0; d < DT; ++d) orow[d * 16 + l15] = f2bf(o[d][e] * inv);
-    }
-  }
 }
 
-int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
-                           int dh, int causal, hipStream_t s, float* lse) {
-  if (Npad % AK) return -1;
-  dim3 grid((N + AQ - 1) / AQ, B * heads);
-#define FA(D)                                                                                                   \
-  do {                                                                                                          \
-    const size_t lds = ((size_t)AK * (D + 8) + (size_t)D * (AK + 8) + 4 * 16 * (AK + 8)) * 2;                   \
-    static DeviceOnce once;                                                                                     \
-    once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-    flash_attention_kernel<D><<<grid, 256, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, (bf16_t*)out, N, \
-                                                     Npad, heads, causal, lse);                                 \
+// V row-major [B,h,N,dh]; Nq queries per (batch, head) at positions 0..Nq-1 (Nq == N for self-attention; Nq = 1: only token 0,
+// the last encoder layer of ViTEnc whose output is read at token 0 only, ViT.py:136)
+int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
+                              int causal, hipStream_t s, float* lse) {
+  const int qg = Nq > 192 ? 2 : 1;                   // 129-token windows: 3 x 64 query slots instead of 2 x 128
+  dim3 grid((Nq + 64 * qg - 1) / (64 * qg), B * heads);
+#define FA2(D, G)                                                                                                \
+  do {                                                                                                           \
+    const size_t lds = (size_t)4 * AK * D * 2;                                                                   \
+    static DeviceOnce once;                                                                                      \
+    once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_v2_kernel<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+    flash_attention_v2_kernel<D, G><<<grid, 256, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, Nq, N, \
+                                                           heads, causal, lse);                                  \
   } while (0)
-  if (dh == 256) FA(256);
-  else if (dh == 128) FA(128);
-  else if (dh == 64) FA(64);
+  if (dh == 256) { if (qg == 2) FA2(256, 2); else FA2(256, 1); }
+  else if (dh == 128) { if (qg == 2) FA2(128, 2); else FA2(128, 1); }
+  else if (dh == 64) { if (qg == 2) FA2(64, 2); else FA2(64, 1); }
   else return -1;
-#undef FA
+#undef FA2
   return 0;
 }

@@ -129,16 +129,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gelu_erf_(v));
           } else if constexpr (EPI == EPI_STORE_BF16) {
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
-          } else {                                               // EPI_QKV: split into Q, K [B,h,Ntok,dh] and V^T [B,h,dh,Npad]
+          } else {                                               // EPI_QKV: split into Q, K, V [B,h,Ntok,dh]
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
-            const int which = n / epi.emb, r = n - which * epi.emb;
+            const int blk = n / epi.emb, r = n - blk * epi.emb, which = blk + epi.which0;
             const int hd = r / epi.dh, d = r - hd * epi.dh;
             const size_t bh = (size_t)b * epi.heads + hd;
             if (which == 0) ((bf16_t*)epi.q)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v * epi.q_scale);
             else if (which == 1) ((bf16_t*)epi.k)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
             else {
-              ((bf16_t*)epi.vt)[(bh * epi.dh + d) * epi.n_pad + t] = f2bf(v);
-              if (epi.vn) ((bf16_t*)epi.vn)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
+              ((bf16_t*)epi.vn)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
             }
           }
         }

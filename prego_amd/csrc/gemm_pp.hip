@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
             xr[1] = make_float4(r1.x + o[4], r1.y + o[5], r1.z + o[6], r1.w + o[7]);
           } else if constexpr (EPI == EPI_QKV) {                        // 8 consecutive columns = one head, one of q / k / v
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
-            const int which = n / epi.emb, r = n - which * epi.emb;
+            const int blk = n / epi.emb, r = n - blk * epi.emb, which = blk + epi.which0;
             const int hd = r / epi.dh, d = r - hd * epi.dh;
             const size_t bh = (size_t)b * epi.heads + hd;
             if (which < 2) {
@@ -269,13 +269,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
               bf16_t* dst = which == 0 ? (bf16_t*)epi.q : (bf16_t*)epi.k;
               *(uint4*)(dst + (bh * epi.n_tok + t) * epi.dh + d) = pk;
             } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) ((bf16_t*)epi.vt)[(bh * epi.dh + d + e) * epi.n_pad + t] = f2bf(o[e]);
-              if (epi.vn) {                                              // training: V by rows as well
-                uint4 pk;
-                pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
-                *(uint4*)((bf16_t*)epi.vn + (bh * epi.n_tok + t) * epi.dh + d) = pk;
-              }
+              uint4 pk;                                                  // V by rows [B,h,n_tok,dh]: one 16-byte store
+              pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+              *(uint4*)((bf16_t*)epi.vn + (bh * epi.n_tok + t) * epi.dh + d) = pk;
             }
           } else {
             *(float4*)(C + (size_t)m * ldc + n) = make_float4(o[0], o[1], o[2], o[3]);

@@ -76,17 +76,18 @@ enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU_BF16 = 2, EPI_STORE_BF16 = 3, E
 struct GemmEpi {
   int mode;
   void* out_b;                 // bf16 output (EPI_GELU_BF16 / EPI_STORE_BF16), leading dim = ldc
-  void* q; void* k; void* vt;  // EPI_QKV destinations
-  int n_tok, n_pad, heads, dh, emb;
+  void* q; void* k;            // EPI_QKV destinations [B,h,n_tok,dh]
+  int n_tok, heads, dh, emb;
   float q_scale;               // softmax scale folded into Q
-  void* vn;                    // EPI_QKV, training: V also in [B,h,N,dh] layout (attention backward reads it by rows); nullable
+  void* vn;                    // EPI_QKV: V [B,h,n_tok,dh] (row-major; the attention kernels read it transposed from LDS)
+  int which0;                  // EPI_QKV: index of the first output block (0 = q|k|v; 1 = the GEMM computes k|v only)
   float* pre_f32;              // EPI_GELU_BF16, training: the pre-activation W1 x + b1 in fp32 (gelu'), leading dim = ldc; nullable
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
 
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s);
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0);
 void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
                     bool in_bf16 = false);
@@ -144,8 +145,9 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
                  float wd, hipStream_t s);
 
 // Transformer path (attention.hip, vit.hip)
-int launch_flash_attention(const void* Q, const void* K, const void* Vt, void* out, int B, int N, int Npad, int heads,
-                           int dh, int causal, hipStream_t s, float* lse = nullptr);
+// attention forward (attention.hip): query on the lane, V row-major [B,h,N,dh], Nq queries against N keys
+int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
+                              int causal, hipStream_t s, float* lse = nullptr);
 // attention backward (attention_bwd.hip): dqkv [B*N, 3*heads*dh] bf16; delta: scratch fp32 [B*heads*N]
 int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s);

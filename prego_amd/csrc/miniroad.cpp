@@ -97,6 +97,11 @@ struct prego_miniroad {
   char* pin = nullptr; size_t pin_bytes = 0; hipEvent_t pin_ev = nullptr; bool pin_busy = false;
   bool plan_dirty = false;      // host plan arrays changed, device copies pending
   bool no_local = false;        // PREGO_GRU_NO_LOCAL (read once at create): skip the XCD-local hand-off fast path
+  // feature streaming of chunk c+1 under the recurrence of chunk c: the pack kernel (22 registers, no LDS) fits beside a
+  // recurrence workgroup on every CU, so it runs on a handle-owned side stream, forked from and joined to the caller's stream
+  // by events (the caller still sees one in-order stream)
+  hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool pack_prefetch = true;
+  int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
   // timing
   bool timing = false;
@@ -165,6 +170,11 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
   h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
+  h->pack_prefetch = getenv("PREGO_NO_PACK_PREFETCH") == nullptr;
+  if (const char* pg = getenv("PREGO_PACK_PREFETCH_GRID")) h->prefetch_grid = atoi(pg);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
@@ -185,6 +195,9 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
   if (h->pin) (void)hipHostFree(h->pin);
+  if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -501,20 +514,33 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const int slots = (n_slots + h->G - 1) / h->G;
   const int nct = (slots + 15) / 16;          // live 16-clip tiles per group (kernels: 1, 2, 4, 8)
 
+  // chunk [t0, t1): the largest t1 with rowoff[t1] - rowoff[t0] <= cap_rows
+  auto chunk_end = [&](int t0_) {
+    const int base_ = h->h_rowoff[t0_];
+    int t1_ = (int)(std::upper_bound(h->h_rowoff.begin() + t0_, h->h_rowoff.end(), base_ + (int)std::min<long long>(cap_rows, total_rows)) -
+                    h->h_rowoff.begin()) - 1;
+    if (t1_ <= t0_) t1_ = t0_ + 1;
+    if (t1_ > h->t_max) t1_ = h->t_max;
+    return t1_;
+  };
+  auto pack_chunk = [&](int t0_, int t1_, hipStream_t st) {
+    const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
+    EventPair* evp = ev_begin(h, 2, st);
+    launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
+                     st == s ? 0 : h->prefetch_grid);
+    ev_end(evp, st);
+    if (h->timing) h->pack_bytes += (double)rows_ * (kx * 4.0 + rb.x);
+  };
+  const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
+  bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
   int t0 = 0;
   while (t0 < h->t_max) {
-    // largest t1 with rowoff[t1] - rowoff[t0] <= cap_rows
     const int base = h->h_rowoff[t0];
-    int t1 = (int)(std::upper_bound(h->h_rowoff.begin() + t0, h->h_rowoff.end(), base + (int)std::min<long long>(cap_rows, total_rows)) -
-                   h->h_rowoff.begin()) - 1;
-    if (t1 <= t0) t1 = t0 + 1;
-    if (t1 > h->t_max) t1 = h->t_max;
+    const int t1 = chunk_end(t0);
     const int rows = h->h_rowoff[t1] - base;
-
-    EventPair* ev = ev_begin(h, 2, s);
-    launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base, rows, h->d_rgb, with_flow ? h->d_flow : 0, X, s);
-    ev_end(ev, s);
-    if (h->timing) h->pack_bytes += (double)rows * (kx * 4.0 + rb.x);
+    EventPair* ev;
+    if (!packed) pack_chunk(t0, t1, s);
+    packed = false;
 
     ev = ev_begin(h, 0, s);
     proj(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx);
@@ -533,6 +559,15 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
+    if (prefetch && t1 < h->t_max) {
+      // X is dead once the layer1 GEMM of this chunk has run: stream the next chunk's features into it while the recurrence
+      // (latency-bound, one wave per SIMD) holds the CUs
+      HIPCHK(hipEventRecord(h->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      pack_chunk(t1, chunk_end(t1), h->side);
+      HIPCHK(hipEventRecord(h->ev_join, h->side));
+      packed = true;
+    }
     ev = ev_begin(h, 1, s);
     if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
     ev_end(ev, s);
@@ -542,6 +577,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                               (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s))
         return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
     }
+    if (packed) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     t0 = t1;
   }
   if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);

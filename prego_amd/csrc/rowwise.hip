@@ -139,10 +139,13 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
 // ------------------------------------------------------------------------------------------
 // host launchers (called from miniroad.cpp)
 // ------------------------------------------------------------------------------------------
+// grid_limit > 0: at most that many workgroups (each walks rows at a stride): a THROTTLED stream for the copy that runs beside
+// the latency-bound recurrence (fewer loads in flight per CU = less queueing in front of the recurrence's gather)
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s) {
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit) {
   if (nrows <= 0) return;
   int grid = nrows < 65536 ? nrows : 65536;
+  if (grid_limit > 0 && grid > grid_limit) grid = grid_limit;
   if (bf16)
     pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X);
   else

@@ -108,16 +108,18 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
   return PREGO_OK;
 }
 
-struct VitWs { size_t xb, enc, x, xn, q, k, vt, ao, f, total; int npad; };
+struct VitWs { size_t xb, enc, x, xn, q, k, vn, ao, f, x0, q0, ao0, xn0, f0, total; };
 static VitWs vit_ws(const prego_vit* h, int B) {
   const size_t E = h->emb, T = h->window, N = T + 1, din = h->d_rgb + h->d_flow;
   VitWs w{};
-  w.npad = (int)align_up(N, 64);
   size_t off = 0;
   auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   w.xb = put((size_t)B * T * din * 2); w.enc = put((size_t)B * T * E * 4); w.x = put((size_t)B * N * E * 4);
   w.xn = put((size_t)B * N * E * 2); w.q = put((size_t)B * N * E * 2); w.k = put((size_t)B * N * E * 2);
-  w.vt = put((size_t)B * E * w.npad * 2); w.ao = put((size_t)B * N * E * 2); w.f = put((size_t)B * N * h->mlp * 2);
+  w.vn = put((size_t)B * N * E * 2); w.ao = put((size_t)B * N * E * 2); w.f = put((size_t)B * N * h->mlp * 2);
+  // last block, token 0 only (ViT.py:136 reads x[:, 0]): one row per window
+  w.x0 = put((size_t)B * E * 4); w.q0 = put((size_t)B * E * 2); w.ao0 = put((size_t)B * E * 2); w.xn0 = put((size_t)B * E * 2);
+  w.f0 = put((size_t)B * h->mlp * 2);
   w.total = off;
   return w;
 }
@@ -129,17 +131,43 @@ static int encoder_block(const prego_vit* h, const VitLayer& l, float* x, char* 
   const int E = h->emb, M = B * N, dh = E / h->heads;
   launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
   GemmEpi e{};
-  e.mode = EPI_QKV; e.q = ws + w.q; e.k = ws + w.k; e.vt = ws + w.vt; e.n_tok = N; e.n_pad = w.npad; e.heads = h->heads;
+  e.mode = EPI_QKV; e.q = ws + w.q; e.k = ws + w.k; e.vn = ws + w.vn; e.n_tok = N; e.heads = h->heads;
   e.dh = dh; e.emb = E; e.q_scale = 1.0f / sqrtf((float)dh);                      // Attention.py:14 (dh^-0.5)
-  if (hipMemsetAsync(ws + w.vt, 0, (size_t)B * E * w.npad * 2, s) != hipSuccess) return -1;   // V^T pad must be finite
   launch_gemm_bf16_nt_epi(ws + w.xn, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
-  if (launch_flash_attention(ws + w.q, ws + w.k, ws + w.vt, ws + w.ao, B, N, w.npad, h->heads, dh, causal, s)) return -1;
+  if (launch_flash_attention_v2(ws + w.q, ws + w.k, ws + w.vn, ws + w.ao, B, N, N, h->heads, dh, causal, s)) return -1;
   GemmEpi r{}; r.mode = EPI_RESIDUAL;
   launch_gemm_bf16_nt_epi(ws + w.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);          // x += proj(attn)
   launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
   GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f;
   launch_gemm_bf16_nt_epi(ws + w.xn, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);   // gelu(W1 x + b1)
   launch_gemm_bf16_nt_epi(ws + w.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);     // x += W2 . + b2
+  return 0;
+}
+
+// The LAST encoder block when only token 0 of its output is read (ViT.py:136 `x[:, 0]`, then pre_head_ln and mlp_head): keys and
+// values are needed for every token, but the query, the attention output, the projection, the residual stream and the whole FFN
+// only for token 0 of each window - B rows instead of B*N.  Exact (the skipped rows never reach the logits); with num_layers = 1
+// it removes 44 % of a window's FLOPs.  Leaves the block's token-0 output in x0 [B, E].
+static int encoder_block_token0(const prego_vit* h, const VitLayer& l, const float* x, char* ws, const VitWs& w, int B, int N,
+                                int causal, hipStream_t s) {
+  const int E = h->emb, M = B * N, dh = E / h->heads;
+  launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
+  GemmEpi e{};
+  e.mode = EPI_QKV; e.q = ws + w.q0; e.k = ws + w.k; e.vn = ws + w.vn; e.n_tok = N; e.heads = h->heads; e.dh = dh; e.emb = E;
+  e.q_scale = 1.0f / sqrtf((float)dh);
+  e.which0 = 1;                                                                                // k | v for every token
+  launch_gemm_bf16_nt_epi(ws + w.xn, E, (const char*)l.qkv_w + (size_t)E * E * 2, E, nullptr, nullptr, 0, M, 2 * E, E, e, s);
+  e.which0 = 0; e.n_tok = 1;                                                                   // q for token 0: rows b * N of xn
+  launch_gemm_bf16_nt_epi(ws + w.xn, N * E, l.qkv_w, E, nullptr, nullptr, 0, B, E, E, e, s);
+  if (launch_flash_attention_v2(ws + w.q0, ws + w.k, ws + w.vn, ws + w.ao0, B, 1, N, h->heads, dh, causal, s)) return -1;
+  float* x0 = (float*)(ws + w.x0);
+  if (hipMemcpy2DAsync(x0, (size_t)E * 4, x, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  GemmEpi r{}; r.mode = EPI_RESIDUAL;
+  launch_gemm_bf16_nt_epi(ws + w.ao0, E, l.proj_w, E, l.proj_b, x0, E, B, E, E, r, s);
+  launch_ln_relu(true, x0, l.ln2_w, l.ln2_b, B, E, 1e-5f, ws + w.xn0, nullptr, 0.f, 0, 0, s, 0);
+  GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f0;
+  launch_gemm_bf16_nt_epi(ws + w.xn0, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, B, h->mlp, E, g, s);
+  launch_gemm_bf16_nt_epi(ws + w.f0, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x0, E, B, E, h->mlp, r, s);
   return 0;
 }
 
@@ -154,12 +182,19 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const int B = batch, T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow;
+  const int causal = (flags & 1) ? 1 : 0;
+  const bool all_rows = (flags & 2) != 0;             // bit 1 (debug / A-B): run the last block on every token as well
   launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
   launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);   // ViT.py:125
   launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);              // ViT.py:126-129
-  for (const auto& l : h->L)
-    if (encoder_block(h, l, (float*)(ws + w.x), ws, w, B, N, (flags & 1) ? 1 : 0, s)) return prego_fail_(PREGO_EINVAL, "encoder block launch failed");
-  launch_vit_head((const float*)(ws + w.x), B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
+  for (int li = 0; li < h->layers; ++li) {
+    const bool last = li + 1 == h->layers && !all_rows;
+    const int rc = last ? encoder_block_token0(h, h->L[li], (const float*)(ws + w.x), ws, w, B, N, causal, s)
+                        : encoder_block(h, h->L[li], (float*)(ws + w.x), ws, w, B, N, causal, s);
+    if (rc) return prego_fail_(PREGO_EINVAL, "encoder block launch failed");
+  }
+  if (all_rows) launch_vit_head((const float*)(ws + w.x), B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
+  else launch_vit_head((const float*)(ws + w.x0), B, 1, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
@@ -167,7 +202,7 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
 // ================================================================================================
 // training: forward that keeps activations + backward (trainer/train.py:20-24 over ViT.py:117-143)
 // ================================================================================================
-struct VitLayerKeep { size_t x_in, st1, xn1, q, k, vn, vt, lse, ao, x_mid, st2, xn2, u, f; };
+struct VitLayerKeep { size_t x_in, st1, xn1, q, k, vn, lse, ao, x_mid, st2, xn2, u, f; };
 struct VitTrainWs {
   size_t xb, enc, x;                     // inputs as bf16, encoding GEMM output, residual stream (final value after forward)
   std::vector<VitLayerKeep> L;
@@ -188,7 +223,7 @@ static VitTrainWs vit_train_ws(const prego_vit* h, int B) {
   w.L.resize(h->layers);
   for (auto& l : w.L) {
     l.x_in = put(M * E * 4); l.st1 = put(M * 8); l.xn1 = put(M * E * 2);
-    l.q = put(M * E * 2); l.k = put(M * E * 2); l.vn = put(M * E * 2); l.vt = put((size_t)B * E * w.npad * 2);
+    l.q = put(M * E * 2); l.k = put(M * E * 2); l.vn = put(M * E * 2);
     l.lse = put((size_t)B * h->heads * N * 4); l.ao = put(M * E * 2);
     l.x_mid = put(M * E * 4); l.st2 = put(M * 8); l.xn2 = put(M * E * 2);
     l.u = put(M * mlp * 4); l.f = put(M * mlp * 2);
@@ -230,11 +265,10 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
     HIPCHK(hipMemcpyAsync(ws + k.x_in, x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s));
     launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + k.xn1, (float*)(ws + k.st1), 0.f, 0, 0, s, 0);
     GemmEpi e{};
-    e.mode = EPI_QKV; e.q = ws + k.q; e.k = ws + k.k; e.vt = ws + k.vt; e.vn = ws + k.vn; e.n_tok = N; e.n_pad = w.npad;
+    e.mode = EPI_QKV; e.q = ws + k.q; e.k = ws + k.k; e.vn = ws + k.vn; e.n_tok = N;
     e.heads = h->heads; e.dh = dh; e.emb = E; e.q_scale = 1.0f / sqrtf((float)dh);
-    HIPCHK(hipMemsetAsync(ws + k.vt, 0, (size_t)B * E * w.npad * 2, s));
     launch_gemm_bf16_nt_epi(ws + k.xn1, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
-    if (launch_flash_attention(ws + k.q, ws + k.k, ws + k.vt, ws + k.ao, B, N, w.npad, h->heads, dh, causal, s, (float*)(ws + k.lse)))
+    if (launch_flash_attention_v2(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, B, N, N, h->heads, dh, causal, s, (float*)(ws + k.lse)))
       return prego_fail_(PREGO_EINVAL, "attention launch failed");
     GemmEpi r{}; r.mode = EPI_RESIDUAL;
     launch_gemm_bf16_nt_epi(ws + k.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);
@@ -349,11 +383,95 @@ extern "C" int prego_debug_attention_bwd(int batch, int len, int heads, int dh, 
   return PREGO_OK;
 }
 
-// ---- AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170,35-57: stateless op -------------------------------
+// ---- AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170,35-57 ---------------------------------------------
+// the attention arithmetic shared by the stateless op and the handle: wqkv bf16 [3D][D] (rows q | k | v), bqkv fp32 [3D],
+// wob bf16 [D][D]; act = 5 activation buffers of M*D bf16 (x, q, k, v, attention output)
+static int attention_layer_run(int batch, int len, int d_model, int heads, int causal, const float* x, const void* wqkv,
+                               const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s) {
+  const size_t M = (size_t)batch * len, D = d_model, step = align_up(M * D * 2, 256);
+  const int dh = d_model / heads;
+  char* xb = act; char* q = act + step; char* k = act + 2 * step; char* vn = act + 3 * step; char* ao = act + 4 * step;
+  launch_cat_convert(x, nullptr, (int)M, d_model, 0, xb, s);
+  GemmEpi e{};
+  e.mode = EPI_QKV; e.q = q; e.k = k; e.vn = vn; e.n_tok = len; e.heads = heads; e.dh = dh; e.emb = d_model;
+  e.q_scale = 1.0f / sqrtf((float)dh);                                   // attn.py:44 scale = 1/sqrt(E)
+  launch_gemm_bf16_nt_epi(xb, d_model, wqkv, d_model, bqkv, nullptr, 0, (int)M, 3 * d_model, d_model, e, s);
+  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s)) return -1;
+  launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s);
+  return 0;
+}
+static int attention_layer_check(int d_model, int heads) {
+  if (d_model % 128 || heads <= 0 || d_model % heads) return prego_fail_(PREGO_EINVAL, "d_model %d / heads %d", d_model, heads);
+  const int dh = d_model / heads;
+  if (dh != 64 && dh != 128 && dh != 256) return prego_fail_(PREGO_EINVAL, "head dim %d: supported 64, 128, 256", dh);
+  return 0;
+}
+
+// handle form: the four projection weights are converted to bf16 ONCE (set_weights), not on every call
+struct prego_attn_layer {
+  int d_model, heads;
+  void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr;
+  bool have_weights = false;
+};
+extern "C" int prego_attention_layer_create(prego_attn_layer** out, int d_model, int heads) {
+  if (!out) return prego_fail_(PREGO_EINVAL, "out is NULL");
+  *out = nullptr;
+  if (attention_layer_check(d_model, heads)) return PREGO_EINVAL;
+  prego_attn_layer* h = new prego_attn_layer();
+  h->d_model = d_model; h->heads = heads;
+  const size_t D = d_model;
+  hipError_t e = hipMalloc(&h->wqkv, 3 * D * D * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->bqkv, 3 * D * 4);
+  if (e == hipSuccess) e = hipMalloc(&h->wo, D * D * 2);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->bo, D * 4);
+  if (e != hipSuccess) { prego_attention_layer_destroy(h); return prego_fail_(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  *out = h;
+  return PREGO_OK;
+}
+extern "C" void prego_attention_layer_destroy(prego_attn_layer* h) {
+  if (!h) return;
+  for (void* p : {h->wqkv, (void*)h->bqkv, h->wo, (void*)h->bo}) if (p) (void)hipFree(p);
+  delete h;
+}
+extern "C" int prego_attention_layer_set_weights(prego_attn_layer* h, const float* wq, const float* bq, const float* wk,
+                                                 const float* bk, const float* wv, const float* bv, const float* wo,
+                                                 const float* bo, prego_stream_t stream) {
+  if (!h || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int d = h->d_model;
+  const size_t D = d;
+  launch_pad_convert(true, wq, d, d, d, h->wqkv, d, d, s);
+  launch_pad_convert(true, wk, d, d, d, (char*)h->wqkv + D * D * 2, d, d, s);
+  launch_pad_convert(true, wv, d, d, d, (char*)h->wqkv + 2 * D * D * 2, d, d, s);
+  launch_pad_convert(true, wo, d, d, d, h->wo, d, d, s);
+  HIPCHK(hipMemcpyAsync(h->bqkv, bq, D * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpyAsync(h->bo, bo, D * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipGetLastError());
+  h->have_weights = true;
+  return PREGO_OK;
+}
+extern "C" size_t prego_attention_layer_handle_workspace_bytes(const prego_attn_layer* h, int batch, int len) {
+  return h ? 5 * align_up((size_t)batch * len * h->d_model * 2, 256) : 0;
+}
+extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
+                                                    void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!h || !x || !out || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
+  if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
+  if (workspace_bytes < prego_attention_layer_handle_workspace_bytes(h, batch, len)) return prego_fail_(PREGO_EWORKSPACE, "workspace too small");
+  if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, (char*)workspace,
+                          (hipStream_t)stream))
+    return prego_fail_(PREGO_EINVAL, "attention launch failed");
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// stateless op (weights passed per call and converted into the workspace first)
 extern "C" size_t prego_attention_layer_workspace_bytes(int batch, int len, int d_model) {
-  const size_t M = (size_t)batch * len, D = d_model, npad = align_up((size_t)len, 64);
-  return align_up(3 * D * D * 2, 256) + align_up(3 * D * 4, 256) + align_up(D * D * 2, 256) + 4 * align_up(M * D * 2, 256) +
-         align_up((size_t)batch * D * npad * 2, 256);
+  const size_t M = (size_t)batch * len, D = d_model;
+  return align_up(3 * D * D * 2, 256) + align_up(3 * D * 4, 256) + align_up(D * D * 2, 256) + 5 * align_up(M * D * 2, 256);
 }
 
 extern "C" int prego_attention_layer_forward(int batch, int len, int d_model, int heads, int causal, const float* x,
@@ -361,17 +479,13 @@ extern "C" int prego_attention_layer_forward(int batch, int len, int d_model, in
                                              const float* wv, const float* bv, const float* wo, const float* bo, float* out,
                                              void* workspace, size_t workspace_bytes, prego_stream_t stream) {
   if (!x || !wq || !bq || !wk || !bk || !wv || !bv || !wo || !bo || !out || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
-  if (d_model % 128 || heads <= 0 || d_model % heads) return prego_fail_(PREGO_EINVAL, "d_model %d / heads %d", d_model, heads);
-  const int dh = d_model / heads;
-  if (dh != 64 && dh != 128 && dh != 256) return prego_fail_(PREGO_EINVAL, "head dim %d: supported 64, 128, 256", dh);
+  if (attention_layer_check(d_model, heads)) return PREGO_EINVAL;
   if (workspace_bytes < prego_attention_layer_workspace_bytes(batch, len, d_model)) return prego_fail_(PREGO_EWORKSPACE, "workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const size_t M = (size_t)batch * len, D = d_model, npad = align_up((size_t)len, 64);
+  const size_t D = d_model;
   char* p = (char*)workspace;
   auto carve = [&](size_t bytes) { char* q = p; p += align_up(bytes, 256); return q; };
   char* wqkv = carve(3 * D * D * 2); float* bqkv = (float*)carve(3 * D * 4); char* wob = carve(D * D * 2);
-  char* xb = carve(M * D * 2); char* q = carve(M * D * 2); char* k = carve(M * D * 2); char* ao = carve(M * D * 2);
-  char* vt = carve((size_t)batch * D * npad * 2);
   launch_pad_convert(true, wq, d_model, d_model, d_model, wqkv, d_model, d_model, s);
   launch_pad_convert(true, wk, d_model, d_model, d_model, wqkv + D * D * 2, d_model, d_model, s);
   launch_pad_convert(true, wv, d_model, d_model, d_model, wqkv + 2 * D * D * 2, d_model, d_model, s);
@@ -379,14 +493,7 @@ extern "C" int prego_attention_layer_forward(int batch, int len, int d_model, in
   HIPCHK(hipMemcpyAsync(bqkv, bq, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice, s));
-  launch_cat_convert(x, nullptr, (int)M, d_model, 0, xb, s);
-  HIPCHK(hipMemsetAsync(vt, 0, (size_t)batch * D * npad * 2, s));
-  GemmEpi e{};
-  e.mode = EPI_QKV; e.q = q; e.k = k; e.vt = vt; e.n_tok = len; e.n_pad = (int)npad; e.heads = heads; e.dh = dh; e.emb = d_model;
-  e.q_scale = 1.0f / sqrtf((float)dh);                                   // attn.py:44 scale = 1/sqrt(E)
-  launch_gemm_bf16_nt_epi(xb, d_model, wqkv, d_model, bqkv, nullptr, 0, (int)M, 3 * d_model, d_model, e, s);
-  if (launch_flash_attention(q, k, vt, ao, batch, len, (int)npad, heads, dh, causal ? 1 : 0, s)) return prego_fail_(PREGO_EINVAL, "attention launch failed");
-  launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s);
+  if (attention_layer_run(batch, len, d_model, heads, causal, x, wqkv, bqkv, wob, bo, out, p, s)) return prego_fail_(PREGO_EINVAL, "attention launch failed");
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
