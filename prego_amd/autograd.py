@@ -25,12 +25,10 @@ class _MiniRoadTrainFn(torch.autograd.Function):
 
 
 def miniroad_train_forward(model, rgb_input, flow_input):
-    if not model.use_rgb:
-        raise NotImplementedError("--no_rgb training")
     named = dict(model.named_parameters())
     params = [named[k] for k in _PARAM_ORDER]
-    flow = flow_input if (model.use_flow and not model.assume_zero_flow) else None
-    return _MiniRoadTrainFn.apply(model, rgb_input, flow, *params)
+    flow = flow_input if (model.use_flow and (not model.assume_zero_flow or not model.use_rgb)) else None
+    return _MiniRoadTrainFn.apply(model, rgb_input if model.use_rgb else None, flow, *params)
 
 
 class _OadLossFn(torch.autograd.Function):

@@ -470,6 +470,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   // workspace carve
   const bool with_flow = any_flow;
   const int kx = h->d_rgb + (with_flow ? h->d_flow : 0);      // K of the layer1 GEMM actually multiplied
+  if (kx == 0) return fail(PREGO_EINVAL, "a model without rgb features (--no_rgb) needs the flow tensors");
   const int din = h->d_rgb + h->d_flow;
   const RowBytes rb = row_bytes(h, with_flow, flags);
   const int total_rows = h->h_rowoff[h->t_max];

@@ -248,7 +248,7 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
   if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0) return prego_fail_(PREGO_EINVAL, "batch %d", batch);
-  if (h->d_rgb > 0 && !rgb) return prego_fail_(PREGO_EINVAL, "missing input");
+  if ((h->d_rgb > 0 && !rgb) || (h->d_rgb == 0 && !flow)) return prego_fail_(PREGO_EINVAL, "missing input");
   const VitTrainWs w = vit_train_ws(h, batch);
   if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
   hipStream_t s = (hipStream_t)stream;

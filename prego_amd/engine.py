@@ -90,19 +90,24 @@ class MiniRoadEngine:
         """rgb[i]: fp32 cuda [T_i, d_rgb] contiguous; flow[i] likewise or None (= zeros).
         Returns (outs list of [T_i, C] or None, argmax list of int32 [T_i] or None, h_last or None)."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
-        n = len(rgb)
+        if d_rgb == 0:                  # --no_rgb (rnn.py:23-29,54-57): the model's only input is the flow stream
+            if flow is None or any(f is None for f in flow):
+                raise PregoError("a --no_rgb model needs a flow tensor for every clip")
+            rgb = None
+        src_list = rgb if rgb is not None else flow
+        n = len(src_list)
         if n == 0:                      # empty clip list: nothing to do (the reference's loader simply yields nothing)
             return ([] if want_out else None), ([] if want_argmax else None), (torch.empty((0, hid), device=self.device) if want_h_last else None)
         outs = [None] * n
         args = [None] * n
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
-        lens = [int(r.shape[0]) for r in rgb]
+        lens = [int(r.shape[0]) for r in src_list]
         single = h0 is not None or want_h_last
         for idx in plan_passes(lens, self.max_clips, single, 512 if self.compute_dtype == "bf16" else 256):
             sub_h0 = None if h0 is None else h0[idx].contiguous()
             sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
             sub_out, sub_arg = [None] * len(idx), [None] * len(idx)
-            self._forward_pass([rgb[i] for i in idx], None if flow is None else [flow[i] for i in idx], softmax,
+            self._forward_pass(None if rgb is None else [rgb[i] for i in idx], None if flow is None else [flow[i] for i in idx], softmax,
                                want_out, want_argmax, sub_h0, sub_hl, sub_out, sub_arg, 0)
             for k, i in enumerate(idx):
                 outs[i], args[i] = sub_out[k], sub_arg[k]
@@ -112,11 +117,12 @@ class MiniRoadEngine:
 
     def _forward_pass(self, rgb, flow, softmax, want_out, want_argmax, h0, h_last, outs, args, base):
         d_rgb, d_flow, emb, hid, ncls = self.dims
-        n = len(rgb)
+        n = len(rgb) if rgb is not None else len(flow)
         lens = []
-        for i, r in enumerate(rgb):
-            if r.dtype != torch.float32 or not r.is_cuda or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != d_rgb:
-                raise PregoError(f"rgb[{i}] must be a contiguous fp32 cuda tensor [T, {d_rgb}], got {tuple(r.shape)} {r.dtype}")
+        for i, r in enumerate(rgb if rgb is not None else flow):
+            want = d_rgb if rgb is not None else d_flow
+            if r.dtype != torch.float32 or not r.is_cuda or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != want:
+                raise PregoError(f"{'rgb' if rgb is not None else 'flow'}[{i}] must be a contiguous fp32 cuda tensor [T, {want}], got {tuple(r.shape)} {r.dtype}")
             lens.append(r.shape[0])
         if flow is not None:
             for i, f in enumerate(flow):
@@ -127,7 +133,7 @@ class MiniRoadEngine:
         lens_arr = (C.c_int32 * n)(*lens)
         flags = _lib.FWD_SOFTMAX if softmax else 0
         ws = self._workspace(n, lens_arr, flags)
-        rgb_p = ptr_array([r.data_ptr() for r in rgb])
+        rgb_p = None if rgb is None else ptr_array([r.data_ptr() for r in rgb])
         flow_p = None if flow is None else ptr_array([None if f is None else f.data_ptr() for f in flow])
         out_p = arg_p = None
         # one allocation per output kind, per-clip views into it (512 clips = 1 024 allocator calls otherwise: the host, not
@@ -163,10 +169,13 @@ class MiniRoadEngine:
     def forward_train(self, rgb: torch.Tensor, flow: Optional[torch.Tensor]) -> torch.Tensor:
         """training-mode forward of a uniform batch [B,T,D]: raw logits [B,T,C]; keeps activations for backward()."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
-        B, T = rgb.shape[0], rgb.shape[1]
+        if d_rgb == 0:
+            rgb = None
+        src = rgb if rgb is not None else flow
+        B, T = src.shape[0], src.shape[1]
         if B > self.max_clips:
             raise PregoError(f"training batch {B} > {self.max_clips} clips per call")
-        rgb = rgb.contiguous()
+        rgb = None if rgb is None else rgb.contiguous()
         flow = None if flow is None else flow.contiguous()
         lens_arr = (C.c_int32 * B)(*([T] * B))
         flags = _lib.FWD_KEEP
@@ -175,7 +184,7 @@ class MiniRoadEngine:
             self._ws_train = torch.empty(need, dtype=torch.uint8, device=self.device)
         out = torch.empty((B, T, ncls), dtype=torch.float32, device=self.device)
         esz = 4
-        rgb_p = ptr_array([rgb.data_ptr() + b * T * d_rgb * esz for b in range(B)])
+        rgb_p = None if rgb is None else ptr_array([rgb.data_ptr() + b * T * d_rgb * esz for b in range(B)])
         flow_p = None if flow is None else ptr_array([flow.data_ptr() + b * T * d_flow * esz for b in range(B)])
         out_p = ptr_array([out.data_ptr() + b * T * ncls * esz for b in range(B)])
         with torch.cuda.device(self.device):

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """CLI mirror of step_recognition/main.py (flags, yaml (+) argparse merge, seed 20, eval branch, train branch, best-mAP
 checkpointing) on the MI355X path.  Differences on purpose: the device is `cuda:$LOCAL_RANK` (the reference hard-codes
-"cuda:1", main.py:33), TensorBoard and the never-stepped lr scheduler are not wired, `--amp` is rejected (the HIP path
-already computes with bf16 operands), and `torchrun` launches give clip-sharded data-parallel training.
+"cuda:1", main.py:33), TensorBoard and the never-stepped lr scheduler are not wired, `--amp` keeps the reference's GradScaler
+protocol (train.py:10-18) around a path whose MFMA operands are bf16 either way, and `torchrun` launches give clip-sharded
+data-parallel training.
 
     python -m prego_amd.main --config step_recognition/configs/miniroad_assembly101-O.yaml --eval ckpt.pth
 """
@@ -62,8 +63,6 @@ def main(argv=None):
     args = parser.parse_args(argv)
     cfg = yaml.load(open(args.config), Loader=yaml.FullLoader)
     cfg.update(vars(args))                                           # main.py:28-30
-    if args.amp:
-        raise SystemExit("--amp is not needed: the HIP path computes with bf16 MFMA operands and fp32 accumulation")
 
     from . import distributed as D
     from .data import build_data_loader
@@ -96,9 +95,10 @@ def main(argv=None):
                                weight_decay=cfg["weight_decay"], model=net)
     else:
         optimizer = torch.optim.Adam([{"params": net.parameters(), "initial_lr": cfg["lr"]}], lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    scaler = torch.amp.GradScaler("cuda") if args.amp else None          # main.py:75
     best_mAP, best_epoch = 0, 0
     for epoch in range(1, cfg["num_epoch"] + 1):
-        epoch_loss = train_one_epoch(trainloader, net, criterion, optimizer, None, epoch, device, None, scheduler=None)
+        epoch_loss = train_one_epoch(trainloader, net, criterion, optimizer, scaler, epoch, device, None, scheduler=None)
         trainloader.dataset._init_features()
         mAP = evaluate_fn(net, testloader, logger, device)
         if rank == 0 and mAP > best_mAP:

@@ -73,12 +73,10 @@ class MROAD(nn.Module):
         src = rgb_input if self.use_rgb else flow_input
         B, T = src.shape[0], src.shape[1]
         rgb = [rgb_input[b].contiguous() for b in range(B)] if self.use_rgb else None
-        if self.use_flow and not self.assume_zero_flow:
-            flow = [flow_input[b].contiguous() for b in range(B)]
+        if self.use_flow and (not self.assume_zero_flow or not self.use_rgb):
+            flow = [flow_input[b].contiguous() for b in range(B)]       # --no_rgb: flow is the model's only input (rnn.py:54-57)
         else:
             flow = None
-        if not self.use_rgb:
-            raise PregoError("--no_rgb (flow-only) models are not supported by the HIP path yet")
         outs, _, _ = eng.forward_ragged(rgb, flow, softmax=True)
         return {"logits": torch.stack(outs, 0)}
 

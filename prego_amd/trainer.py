@@ -36,9 +36,6 @@ def _check_engine(model):
 
 @TRAINER.register("OAD")
 def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, device, writer=None, scheduler=None):
-    if scaler is not None:
-        raise NotImplementedError("--amp: the HIP path already computes with bf16 MFMA operands and fp32 accumulation; "
-                                  "fp16 autocast + GradScaler (train.py:10-18) has nothing to scale")
     epoch_loss = 0
     sampler = getattr(trainloader, "sampler", None)
     if hasattr(sampler, "set_epoch"):          # data-parallel runs: a different permutation every epoch
@@ -46,13 +43,27 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
     for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(trainloader):
         rgb_input, flow_input, target = rgb_input.to(device), flow_input.to(device), target.to(device)
         model.train()
-        out_dict = model(rgb_input, flow_input)
-        loss = criterion(out_dict, target)
-        optimizer.zero_grad(set_to_none=True)
-        loss.backward()
-        _check_engine(model)
-        _allreduce_grads(model)
-        optimizer.step()
+        if scaler is not None:
+            # --amp (train.py:10-18): the reference's loss-scaling protocol runs unchanged - scaled loss, scaled gradients through
+            # the HIP backward (fp32 accumulation; the MFMA operands are bf16 whatever autocast says: there is no fp16 path on
+            # this hardware route, and bf16's exponent range makes the scale harmless), unscale + inf check + step by GradScaler
+            with torch.autocast(device_type="cuda", enabled=torch.cuda.is_available()):
+                out_dict = model(rgb_input, flow_input)
+                loss = criterion(out_dict, target)
+            optimizer.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            _check_engine(model)
+            _allreduce_grads(model)
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            out_dict = model(rgb_input, flow_input)
+            loss = criterion(out_dict, target)
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            _check_engine(model)
+            _allreduce_grads(model)
+            optimizer.step()
         epoch_loss += loss.item()
         if writer is not None:
             writer.add_scalar("Train Loss", loss.item(), it + epoch * len(trainloader))

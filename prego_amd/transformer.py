@@ -128,8 +128,6 @@ class ViTEnc(nn.Module):
         B, T = (rgb if rgb is not None else flow).shape[:2]
         if T != self.img_dim:
             raise PregoError(f"ViTEnc needs T == window_size ({self.img_dim}), got {T} (learned positional table, PositionalEncoding.py:25-41)")
-        if rgb is None:
-            raise PregoError("--no_rgb is not supported by the HIP path yet")
         return rgb, flow, B
 
     def forward(self, sequence_input_rgb, sequence_input_flow):
@@ -147,7 +145,7 @@ class ViTEnc(nn.Module):
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((B, self.out_dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            check(lib.prego_vit_forward(self._h, B, C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
+            check(lib.prego_vit_forward(self._h, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
                                         C.c_void_p(out.data_ptr()), (1 if self.causal else 0) | (2 if getattr(self, "debug_all_rows", False) else 0),
                                         C.c_void_p(self._ws.data_ptr()),
                                         self._ws.numel(), C.c_void_p(_stream_ptr(dev))))
@@ -173,7 +171,7 @@ class _ViTTrainFn(torch.autograd.Function):
             model._ws_train = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((B, model.out_dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            check(lib.prego_vit_forward_train(model._h, B, C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
+            check(lib.prego_vit_forward_train(model._h, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
                                               C.c_void_p(out.data_ptr()), 1 if model.causal else 0,
                                               C.c_void_p(model._ws_train.data_ptr()), model._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))
         ctx.model, ctx.B, ctx.keep = model, B, (rgb, flow)

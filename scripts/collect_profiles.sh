@@ -6,10 +6,10 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-zero-flow > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-zero-flow --no-secondary > $OUT/trace.log 2>&1
 tail -1 $OUT/trace.log | cut -c1-400
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-zero-flow --clips 64 --len-scale 0.25 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-zero-flow --clips 64 --len-scale 0.25 > $OUT/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-zero-flow --no-secondary --clips 64 --len-scale 0.25 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-zero-flow --no-secondary --clips 64 --len-scale 0.25 > $OUT/pmc_write.log 2>&1
 find $OUT -name "*.csv" | head -20
 # keep the merge small: the kernel traces are large
 find $OUT -name "*kernel_trace.csv" -size +20M -delete

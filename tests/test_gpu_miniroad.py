@@ -218,3 +218,37 @@ def test_continuous_batching_matches_per_clip_results(dtype):
         assert np.array_equal(args[i].cpu().numpy(), outs[i].cpu().numpy().argmax(1))
     eng.rows_per_chunk = 65536
     eng._ws = None
+
+
+@pytest.mark.parametrize("which", ["no_rgb", "no_flow"])
+def test_single_stream_models_no_rgb_no_flow(which):
+    """--no_rgb / --no_flow (main.py:23-24, rnn.py:23-29,54-57): input_dim = one feature stream; eval and one training step"""
+    from prego_amd.registry import build_criterion
+    import prego_amd.loss  # noqa: F401
+    cfg = epic_tent_cfg(**{which: True}, dropout=0.0)
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    assert sd["layer1.0.weight"].shape == (2048, 2048)
+    m = _model(cfg, sd, "fp32")
+    B, T = 3, 21
+    feat = W.tsn_features((B, T, 2048), 31, f"single.{which}")
+    dummy = torch.zeros(B, T, 0, device="cuda")
+    x = torch.from_numpy(feat).cuda()
+    rgb, flow = (dummy, x) if which == "no_rgb" else (x, dummy)
+    with torch.no_grad():
+        out = m(rgb, flow)["logits"].cpu().numpy()
+    m.engine().check()
+    ref = O.miniroad_forward(sd, feat, None)["logits"]
+    assert np.abs(out - ref).max() < 1e-3
+    # training step (fp32 operands): loss and gradients against the oracle's BPTT
+    tgt = np.zeros((B, T, 12), np.float32)
+    tgt[np.arange(B)[:, None], np.arange(T)[None, :], (np.arange(T)[None, :] + np.arange(B)[:, None]) % 12] = 1.0
+    crit = build_criterion(cfg, "cuda:0")
+    m.train()
+    loss = crit(m(rgb, flow), torch.from_numpy(tgt).cuda())
+    loss.backward()
+    m.engine().check()
+    ref_loss, ref_g = O.miniroad_loss_and_grads(sd, feat, None, tgt)
+    assert abs(float(loss.detach()) - ref_loss) < 1e-4
+    for k, p in m.named_parameters():
+        g = p.grad.cpu().numpy()
+        assert np.abs(g - ref_g[k]).max() < 2e-3 * max(np.abs(ref_g[k]).max(), 1e-6) + 1e-7, k

@@ -273,3 +273,30 @@ def test_fused_adamw_refreshes_engine_weights(dtype):
         # two kernels' m / sqrt(v) into a fraction of lr (1e-3 here); the bulk must agree to fp32 rounding
         assert np.abs(a - b).max() < 2.5e-3 and np.abs(a - b).mean() < 2e-7, (k, np.abs(a - b).max(), np.abs(a - b).mean())
     assert np.abs(res["fused"][1] - res["torch"][1]).max() < (2e-3 if dtype == "bf16" else 2e-4)
+
+
+def test_amp_flag_runs_the_reference_gradscaler_protocol():
+    """--amp (train.py:10-18): scaled loss -> scaled gradients through the HIP backward -> GradScaler unscale / inf check / step;
+    the parameters after the step equal the unscaled step (the scale is a power of two: exact in fp32)."""
+    from prego_amd.optim import FusedAdamW
+    from prego_amd.registry import build_trainer
+    import prego_amd.trainer  # noqa: F401
+    cfg = assembly101_cfg(dropout=0.0, compute_dtype="fp32")
+    sd = W.miniroad_state_dict(cfg, 20)
+    rgb = torch.from_numpy(W.tsn_features((2, 8, 2048), 20, "g4b.rgb"))
+    flow = torch.from_numpy(W.tsn_features((2, 8, 2048), 20, "g4b.flow"))
+    tgt = torch.from_numpy(_targets(2, 8, 86, 20, "g4b.tgt"))
+    loader = [(rgb, flow, tgt, ("a", "b"), torch.zeros(2), torch.zeros(2))]
+    train = build_trainer(dict(cfg, task="OAD"))
+    res = {}
+    for amp in (False, True):
+        model, crit = _build(cfg, sd)
+        opt = FusedAdamW([{"params": list(model.parameters())}], lr=1e-3, weight_decay=0.05, model=model)
+        scaler = torch.amp.GradScaler("cuda") if amp else None
+        loss = train(loader, model, crit, opt, scaler, 1, "cuda:0")
+        res[amp] = (loss, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()})
+        if amp:
+            assert scaler.get_scale() == 65536.0          # no inf / nan was found: the scale did not back off
+    assert abs(res[True][0] - res[False][0]) < 1e-6
+    for k in res[True][1]:
+        assert np.abs(res[True][1][k] - res[False][1][k]).max() < 2e-6, k

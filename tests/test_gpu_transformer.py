@@ -177,3 +177,20 @@ def test_attention_layer_stateless_op_equals_handle():
     assert torch.equal(a, out)
     ref = O.causal_attention_layer(x.cpu().numpy().astype(np.float64), *[t.cpu().numpy().astype(np.float64) for t in ws], heads=H)
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-2
+
+
+def test_vit_no_rgb_flow_only():
+    """--no_rgb on the Transformer entry (ViT.py:118-123): the encoding Linear sees the flow stream only"""
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    cfg = _vit_cfg(no_rgb=True)
+    sd = W.vit_state_dict(cfg, 20)
+    assert sd["linear_encoding.weight"].shape == (2048, 2048)
+    m = build_model(cfg, "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    x = W.tsn_features((2, 128, 2048), 20, "vit.norgb")
+    with torch.no_grad():
+        got = m(torch.zeros(2, 128, 0, device="cuda"), torch.from_numpy(x).cuda())["logits"].cpu().numpy()
+    ref = O.vit_forward(sd, x, None, heads=8)["logits"]
+    assert np.abs(got - ref).max() < 1e-2
