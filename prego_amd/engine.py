@@ -206,7 +206,15 @@ class MiniRoadEngine:
                   "layer1.1.bias": (emb,), "gru.weight_ih_l0": (3 * hid, emb), "gru.weight_hh_l0": (3 * hid, hid),
                   "gru.bias_ih_l0": (3 * hid,), "gru.bias_hh_l0": (3 * hid,), "f_classification.0.weight": (ncls, hid),
                   "f_classification.0.bias": (ncls,)}
-        grads = {k: torch.empty(shapes[k], dtype=torch.float32, device=self.device) for k in _PARAM_ORDER}
+        # one flat fp32 bucket (17.9 M elements = 71.7 MB), the ten gradients are views into it: data-parallel training
+        # all-reduces the bucket in place (no gather / scatter copies around the collective)
+        sizes = [int(torch.Size(shapes[k]).numel()) for k in _PARAM_ORDER]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64            # 256-byte aligned views
+        self._grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        grads = {k: self._grad_flat[o:o + n].view(shapes[k]) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}
         dl_p = ptr_array([dlogits.data_ptr() + b * T * ncls * 4 for b in range(B)])
         with torch.cuda.device(self.device):
             check(self.lib.prego_miniroad_backward(

@@ -72,6 +72,31 @@ def average_precision_torch(y_true, y_score):
     return float(((recall - prev) * precision).sum())
 
 
+def average_precision_columns_torch(y_true, y_score):
+    """sklearn.metrics.average_precision_score for EVERY class at once: y_true (bool) and y_score [frames, classes] on any
+    device -> float64 [classes] (NaN where a class has no positive).  One stable sort along the frame axis, cumulative sums and
+    a running maximum: no per-class Python loop and a single host transfer for the whole metric.  Thresholds are the ends of
+    runs of equal scores (ties share one threshold), exactly as sklearn's precision_recall_curve builds them."""
+    import torch
+    s, idx = torch.sort(y_score.to(torch.float64), dim=0, descending=True, stable=True)
+    y = torch.gather(y_true.to(torch.float64), 0, idx)
+    n = y.shape[0]
+    tps = torch.cumsum(y, 0)
+    last = torch.ones_like(y, dtype=torch.bool)
+    if n > 1:
+        last[:-1] = s[:-1] != s[1:]
+    cnt = torch.arange(1, n + 1, device=y.device, dtype=torch.float64)[:, None]
+    total = tps[-1:].clamp(min=1e-300)
+    recall = tps / total
+    precision = tps / cnt
+    zero = torch.zeros((), dtype=torch.float64, device=y.device)
+    r_last = torch.where(last, recall, zero)
+    prev = torch.cummax(r_last, 0).values                      # recall at the most recent threshold at or before i (recall is monotone)
+    prev = torch.cat([torch.zeros_like(prev[:1]), prev[:-1]], 0)
+    ap = torch.where(last, (recall - prev) * precision, zero).sum(0)
+    return torch.where(tps[-1] > 0, ap, torch.full_like(ap, float("nan")))
+
+
 def perframe_average_precision_torch(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
     """`perframe_average_precision` on torch tensors [frames, classes] (prediction: scores, ground_truth: one/multi-hot)."""
     import torch
@@ -80,12 +105,14 @@ def perframe_average_precision_torch(prediction, ground_truth, class_names, post
     result = OrderedDict()
     result["per_class_AP"] = OrderedDict()
     result["num"] = OrderedDict()
-    present = (ground_truth != 0).any(0).cpu().numpy()
+    truth = ground_truth != 0
+    # everything the report needs in ONE device -> host transfer: AP, positives and score mass per class
+    stats = torch.stack([average_precision_columns_torch(truth, prediction), truth.sum(0).to(torch.float64),
+                         prediction.to(torch.float64).sum(0), ground_truth.to(torch.float64).sum(0)]).cpu().numpy()
     for idx, class_name in enumerate(class_names):
-        if idx != 0 and present[idx]:
-            gt = ground_truth[:, idx]
-            ap = average_precision_torch(gt != 0, prediction[:, idx])
+        if idx != 0 and stats[1, idx] > 0:                        # class 0 is skipped as "background" (utils/metrics.py:48)
+            ap = float(stats[0, idx])
             result["per_class_AP"][class_name] = ap
-            result["num"][class_name] = (f"[true: {int(gt.sum())}, pred:{int(prediction[:, idx].sum())}, AP:{ap * 100:.1f}]")
+            result["num"][class_name] = (f"[true: {int(stats[3, idx])}, pred:{int(stats[2, idx])}, AP:{ap * 100:.1f}]")
     result["mean_AP"] = np.mean(list(result["per_class_AP"].values()))
     return result

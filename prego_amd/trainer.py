@@ -16,7 +16,12 @@ def _allreduce_grads(model):
     if world == 1:
         return
     ps = [p for p in model.parameters() if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])        # one bucket: 17.9 M fp32 = 71.7 MB
+    eng = getattr(model, "_engine", None)
+    flat = getattr(eng, "_grad_flat", None) if eng is not None else None
+    if flat is not None and all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in ps):
+        allreduce_mean_(flat, world)        # the HIP backward wrote every gradient into one bucket: reduce it in place
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])        # generic modules: gather, reduce, scatter
     allreduce_mean_(flat, world)
     o = 0
     for p in ps:
