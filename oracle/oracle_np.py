@@ -304,12 +304,36 @@ def _ln_bwd(dy, x, gamma):
     return dx, dg, db
 
 
-def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64, causal=False):
+def hash_dropout_mask(seed, n, p):
+    """The build's stateless dropout mask (csrc/common.h: dropout_keep_): keep element i iff
+    mix32(seed * 0x9E3779B97F4A7C15 + i) >= p * 2^32, kept values scaled by 1 / (1 - p).  Returned as a float64 multiplier [n].
+    (The reference's nn.Dropout draws from torch's RNG stream, which cannot be matched; what can be checked is that forward and
+    backward of the HIP path use ONE mask and that the arithmetic around it is the reference's.)"""
+    if p <= 0:
+        return np.ones(n)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.arange(n, dtype=np.uint64)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xFF51AFD7ED558CCD)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xC4CEB9FE1A85EC53)
+        x ^= x >> np.uint64(33)
+    thresh = np.uint64(int(p * 4294967296.0))
+    keep = (x & np.uint64(0xFFFFFFFF)) >= thresh
+    return keep.astype(np.float64) / (1.0 - p)
+
+
+def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64, causal=False, masks=None):
     """Training step of the `Transformer` registry entry by hand: ViTEnc.forward (ViT.py:117-143, dropouts 0), OadLoss on the
     [B,1,C] logits (loss.py:15-34: logits[:, -1] is the only row, target[:, -1] the last frame's label), and the full backward
     through the head, the final LayerNorm (token 0 only), every pre-norm block (Transformer.py:60-77: FFN with exact-erf GELU,
     SelfAttention of Attention.py:21-41), the learned positional table, the cls token (appended at the END, ViT.py:128) and the
-    encoding Linear.  Returns (loss, logits [B,1,C], grads keyed like the state_dict)."""
+    encoding Linear.  `masks` (optional): multiplicative dropout masks at the reference's nn.Dropout sites outside the attention
+    module: masks["pe"] [B,N,E] (ViT.py:130), masks[(l, "attn")] [B,N,E] (PreNormDrop, Transformer.py:31), masks[(l, "gelu")]
+    [B,N,mlp] and masks[(l, "ffn")] [B,N,E] (FeedForward, Transformer.py:41,46).
+    Returns (loss, logits [B,1,C], grads keyed like the state_dict)."""
+    masks = masks or {}
+    one = 1.0
     p = {k: np.asarray(v, dtype=dt) for k, v in sd.items() if k != "position_encoding.position_ids"}
     X = np.asarray(rgb, dtype=dt)
     if flow is not None:
@@ -320,7 +344,7 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
     scale = dh ** -0.5
     x = linear(X, p["linear_encoding.weight"], p["linear_encoding.bias"])
     x = np.concatenate([x, np.broadcast_to(p["cls_token"].reshape(1, 1, E), (B, 1, E))], axis=1)
-    x = x + p["position_encoding.pe.weight"][None, :N]
+    x = (x + p["position_encoding.pe.weight"][None, :N]) * masks.get("pe", one)
     cache = []
     for l in range(num_layers):
         a_, f_ = 2 * l, 2 * l + 1
@@ -333,12 +357,12 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
             sc = np.where(np.triu(np.ones((N, N), dtype=bool), 1), -np.inf, sc)
         att = softmax(sc)
         o = np.einsum("bhij,bhjd->bhid", att, v).transpose(0, 2, 1, 3).reshape(B, N, E)
-        x = x + linear(o, p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.proj.bias"])
+        x = x + linear(o, p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.proj.bias"]) * masks.get((l, "attn"), one)
         c.update(xn=xn, q=q, k=k, v=v, att=att, o=o, x_mid=x)
         xn2 = layernorm(x, p[f"encoder.net.{f_}.fn.norm.weight"], p[f"encoder.net.{f_}.fn.norm.bias"])
         u = linear(xn2, p[f"encoder.net.{f_}.fn.fn.net.0.weight"], p[f"encoder.net.{f_}.fn.fn.net.0.bias"])
-        f = gelu_erf(u)
-        x = x + linear(f, p[f"encoder.net.{f_}.fn.fn.net.3.weight"], p[f"encoder.net.{f_}.fn.fn.net.3.bias"])
+        f = gelu_erf(u) * masks.get((l, "gelu"), one)
+        x = x + linear(f, p[f"encoder.net.{f_}.fn.fn.net.3.weight"], p[f"encoder.net.{f_}.fn.fn.net.3.bias"]) * masks.get((l, "ffn"), one)
         c.update(xn2=xn2, u=u, f=f)
         cache.append(c)
     xf0 = layernorm(x[:, 0], p["pre_head_ln.weight"], p["pre_head_ln.bias"])
@@ -356,20 +380,22 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
         a_, f_ = 2 * l, 2 * l + 1
         c = cache[l]
         w2, w1 = p[f"encoder.net.{f_}.fn.fn.net.3.weight"], p[f"encoder.net.{f_}.fn.fn.net.0.weight"]
-        g[f"encoder.net.{f_}.fn.fn.net.3.weight"] = np.einsum("bne,bnm->em", dx, c["f"])
-        g[f"encoder.net.{f_}.fn.fn.net.3.bias"] = dx.sum(axis=(0, 1))
+        dbr = dx * masks.get((l, "ffn"), one)                      # gradient entering the FFN branch through its output dropout
+        g[f"encoder.net.{f_}.fn.fn.net.3.weight"] = np.einsum("bne,bnm->em", dbr, c["f"])
+        g[f"encoder.net.{f_}.fn.fn.net.3.bias"] = dbr.sum(axis=(0, 1))
         u = c["u"]
         dgelu = 0.5 * (1.0 + _erf(u / math.sqrt(2.0))) + u * np.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
-        du = (dx @ w2) * dgelu
+        du = (dbr @ w2) * masks.get((l, "gelu"), one) * dgelu
         g[f"encoder.net.{f_}.fn.fn.net.0.weight"] = np.einsum("bnm,bne->me", du, c["xn2"])
         g[f"encoder.net.{f_}.fn.fn.net.0.bias"] = du.sum(axis=(0, 1))
         dxa, g[f"encoder.net.{f_}.fn.norm.weight"], g[f"encoder.net.{f_}.fn.norm.bias"] = _ln_bwd(
             du @ w1, c["x_mid"], p[f"encoder.net.{f_}.fn.norm.weight"])
         dx = dx + dxa
         wp, wq = p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.qkv.weight"]
-        g[f"encoder.net.{a_}.fn.fn.proj.weight"] = np.einsum("bne,bnd->ed", dx, c["o"])
-        g[f"encoder.net.{a_}.fn.fn.proj.bias"] = dx.sum(axis=(0, 1))
-        do = (dx @ wp).reshape(B, N, heads, dh).transpose(0, 2, 1, 3)
+        dbr = dx * masks.get((l, "attn"), one)
+        g[f"encoder.net.{a_}.fn.fn.proj.weight"] = np.einsum("bne,bnd->ed", dbr, c["o"])
+        g[f"encoder.net.{a_}.fn.fn.proj.bias"] = dbr.sum(axis=(0, 1))
+        do = (dbr @ wp).reshape(B, N, heads, dh).transpose(0, 2, 1, 3)
         dv = np.einsum("bhij,bhid->bhjd", c["att"], do)
         da = np.einsum("bhid,bhjd->bhij", do, c["v"])
         ds = c["att"] * (da - (da * c["att"]).sum(axis=-1, keepdims=True))
@@ -380,6 +406,7 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
         dxa, g[f"encoder.net.{a_}.fn.norm.weight"], g[f"encoder.net.{a_}.fn.norm.bias"] = _ln_bwd(
             dqkv @ wq, c["x_in"], p[f"encoder.net.{a_}.fn.norm.weight"])
         dx = dx + dxa
+    dx = dx * masks.get("pe", one)
     g["position_encoding.pe.weight"] = dx.sum(axis=0)
     g["cls_token"] = dx[:, N - 1].sum(axis=0).reshape(1, 1, E)
     g["linear_encoding.weight"] = np.einsum("bte,btd->ed", dx[:, :T], X)

@@ -26,7 +26,7 @@ SYMBOLS = [
     "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
-    "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
+    "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd",
@@ -90,6 +90,7 @@ def load() -> C.CDLL:
     lib.prego_vit_workspace_bytes.argtypes = [vp, i32]
     lib.prego_vit_workspace_bytes.restype = sz
     lib.prego_vit_forward.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]
+    lib.prego_vit_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
     lib.prego_vit_train_workspace_bytes.argtypes = [vp, i32]
     lib.prego_vit_train_workspace_bytes.restype = sz
     lib.prego_vit_forward_train.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]

@@ -122,11 +122,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = f2bf(v);
             else C[(size_t)m * ldc + n] = v;
           } else if constexpr (EPI == EPI_RESIDUAL) {                 // x += v  (fp32 residual stream, in place)
+            if (epi.drop_thresh) v = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
             float* xr = (float*)C + (size_t)m * ldc + n;
             *xr = *xr + v;
           } else if constexpr (EPI == EPI_GELU_BF16) {                // FFN-1: bf16(gelu(v))
             if (epi.pre_f32) epi.pre_f32[(size_t)m * ldc + n] = v;   // training: keep the pre-activation for gelu'
-            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gelu_erf_(v));
+            float gv = gelu_erf_(v);
+            if (epi.drop_thresh) gv = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? gv * epi.drop_scale : 0.f;
+            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gv);
           } else if constexpr (EPI == EPI_STORE_BF16) {
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
           } else {                                               // EPI_QKV: split into Q, K, V [B,h,Ntok,dh]

@@ -246,12 +246,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
               }
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = gelu_erf_(o[e]);
+              if (epi.drop_thresh) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n + e, epi.drop_thresh) ? o[e] * epi.drop_scale : 0.f;
+              }
             }
             uint4 pk;
             pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
             bf16_t* ob = EPI == EPI_GELU_BF16 ? (bf16_t*)epi.out_b : (bf16_t*)Cv;
             *(uint4*)(ob + (size_t)m * ldc + n) = pk;
           } else if constexpr (EPI == EPI_RESIDUAL) {                  // fp32 residual stream, in place
+            if (epi.drop_thresh) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n + e, epi.drop_thresh) ? o[e] * epi.drop_scale : 0.f;
+            }
             float4* xr = (float4*)(C + (size_t)m * ldc + n);
             const float4 r0 = xr[0], r1 = xr[1];
             xr[0] = make_float4(r0.x + o[0], r0.y + o[1], r0.z + o[2], r0.w + o[3]);

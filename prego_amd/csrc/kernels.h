@@ -81,6 +81,9 @@ struct GemmEpi {
   float q_scale;               // softmax scale folded into Q
   void* vn;                    // EPI_QKV: V [B,h,n_tok,dh] (row-major; the attention kernels read it transposed from LDS)
   int which0;                  // EPI_QKV: index of the first output block (0 = q|k|v; 1 = the GEMM computes k|v only)
+  // training-mode nn.Dropout on the epilogue's result (EPI_RESIDUAL: on acc + bias before the residual add, Transformer.py:31,46;
+  // EPI_GELU_BF16: on gelu(.), Transformer.py:41): stateless hash mask of (seed, m * ldc + n); thresh = 0 -> no dropout
+  unsigned drop_thresh; float drop_scale; unsigned long long drop_seed;
   float* pre_f32;              // EPI_GELU_BF16, training: the pre-activation W1 x + b1 in fp32 (gelu'), leading dim = ldc; nullable
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
@@ -152,13 +155,20 @@ int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void*
 int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s);
 // ViTEnc training glue (vit_train.hip)
-void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s);
+// dropout arguments (thresh = p * 2^32, scale = 1 / (1 - p), seed): thresh = 0 means none
+void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s, unsigned drop_thresh = 0,
+                     float drop_scale = 1.f, unsigned long long drop_seed = 0);
+// out_f32 (nullable) / out_bf16 := src * dropout mask(seed, element index) * scale
+void launch_mask_convert(const float* src, size_t n, float* out_f32, void* out_bf16, unsigned drop_thresh, float drop_scale,
+                         unsigned long long drop_seed, hipStream_t s);
 void launch_vit_head_bwd(const float* x, const float* dlogits, int B, int N, int E, int C, const float* lnw, const float* lnb,
                          const float* hw, float* dx, float* scratch /*[3][B][E]*/, float* g_lnw, float* g_lnb, float* g_hw,
                          float* g_hb, hipStream_t s);
-void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s);
+void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s,
+                           unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
 void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s);
-void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
+void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
+                       unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
                      const float* hb, int C, float* out, hipStream_t s);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);

@@ -18,11 +18,17 @@ __global__ void cat_convert_kernel(const float* __restrict__ rgb, const float* _
 }
 
 __global__ void vit_tokens_kernel(const float* __restrict__ enc, const float* __restrict__ cls, const float* __restrict__ pe,
-                                  int B, int T, int E, float* __restrict__ x) {
+                                  int B, int T, int E, float* __restrict__ x, unsigned drop_thresh, float drop_scale,
+                                  unsigned long long drop_seed) {
   const int row = blockIdx.x;                       // b * (T+1) + n
   const int b = row / (T + 1), n = row % (T + 1);
   const float* src = n < T ? enc + ((size_t)b * T + n) * E : cls;
-  for (int c = threadIdx.x; c < E; c += blockDim.x) x[(size_t)row * E + c] = src[c] + pe[(size_t)n * E + c];
+  for (int c = threadIdx.x; c < E; c += blockDim.x) {
+    float v = src[c] + pe[(size_t)n * E + c];
+    // pe_dropout (ViT.py:130), training only
+    if (drop_thresh) v = dropout_keep_(drop_seed, (size_t)row * E + c, drop_thresh) ? v * drop_scale : 0.f;
+    x[(size_t)row * E + c] = v;
+  }
 }
 
 __global__ __launch_bounds__(256) void vit_head_kernel(const float* __restrict__ x, int N, int E, const float* __restrict__ lnw,
@@ -72,8 +78,9 @@ void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb
   if (rows <= 0) return;
   cat_convert_kernel<<<rows < 16384 ? rows : 16384, 256, 0, s>>>(rgb, flow, rows, d_rgb, d_flow, (bf16_t*)out_bf16);
 }
-void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s) {
-  vit_tokens_kernel<<<B * (T + 1), 256, 0, s>>>(enc, cls, pe, B, T, E, x);
+void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
+                       unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
+  vit_tokens_kernel<<<B * (T + 1), 256, 0, s>>>(enc, cls, pe, B, T, E, x, drop_thresh, drop_scale, drop_seed);
 }
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
                      const float* hb, int C, float* out, hipStream_t s) {

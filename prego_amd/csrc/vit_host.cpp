@@ -31,7 +31,23 @@ struct prego_vit {
   float *lnf_w = nullptr, *lnf_b = nullptr, *head_w = nullptr, *head_b = nullptr;
   std::vector<void*> allocs;
   bool have_weights = false;
+  // training-mode dropout (cfg['dropout']; ViT.py:130 pe_dropout, Transformer.py:31 PreNormDrop, Transformer.py:41,46 FeedForward)
+  float drop_p = 0.f;
+  unsigned long long drop_seed = 0;
 };
+// per-site mask seeds: site 0 = positional dropout, per layer: 1 = attention branch, 2 = after GELU, 3 = FFN output
+static inline unsigned long long site_seed(const prego_vit* h, int layer, int site) {
+  return h->drop_seed + 0x1000ull * (unsigned long long)(layer + 1) * (site ? 1 : 0) + (unsigned long long)site;
+}
+static inline unsigned drop_thresh_of(const prego_vit* h) { return h->drop_p > 0.f ? (unsigned)((double)h->drop_p * 4294967296.0) : 0u; }
+static inline float drop_scale_of(const prego_vit* h) { return h->drop_p > 0.f ? 1.f / (1.f - h->drop_p) : 1.f; }
+extern "C" int prego_vit_set_dropout(prego_vit* h, float p, uint64_t seed) {
+  if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
+  if (!(p >= 0.f && p < 1.f)) return prego_fail_(PREGO_EINVAL, "dropout p = %f", (double)p);
+  h->drop_p = p;
+  h->drop_seed = seed;
+  return PREGO_OK;
+}
 
 static int dmalloc(prego_vit* h, void** p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes);
@@ -207,7 +223,7 @@ struct VitTrainWs {
   size_t xb, enc, x;                     // inputs as bf16, encoding GEMM output, residual stream (final value after forward)
   std::vector<VitLayerKeep> L;
   // backward scratch
-  size_t dx, dxb, tmp, du, dub, dO, dqkv, delta, T1, T2, WT, part, head, denc, vec;
+  size_t dx, dxm, dxb, tmp, du, dub, dO, dqkv, delta, T1, T2, WT, part, head, denc, vec;
   size_t total;
   int npad, Mp, MTp;
 };
@@ -229,7 +245,7 @@ static VitTrainWs vit_train_ws(const prego_vit* h, int B) {
     l.u = put(M * mlp * 4); l.f = put(M * mlp * 2);
   }
   const size_t wide = std::max<size_t>(std::max<size_t>(3 * E, mlp), din);
-  w.dx = put(M * E * 4); w.dxb = put(M * E * 2); w.tmp = put(M * std::max<size_t>(E, mlp) * 4);
+  w.dx = put(M * E * 4); w.dxm = put(M * E * 4); w.dxb = put(M * E * 2); w.tmp = put(M * std::max<size_t>(E, mlp) * 4);
   w.du = put(M * mlp * 4); w.dub = put(M * mlp * 2); w.dO = put(M * E * 2); w.dqkv = put(M * 3 * E * 2);
   w.delta = put((size_t)B * h->heads * N * 4);
   w.T1 = put(wide * (size_t)w.Mp * 2); w.T2 = put(wide * (size_t)w.Mp * 2);
@@ -258,7 +274,9 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
   float* x = (float*)(ws + w.x);
   launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
   launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);
-  launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, x, s);
+  const unsigned dthr = drop_thresh_of(h);
+  const float dsc = drop_scale_of(h);
+  launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, x, s, dthr, dsc, site_seed(h, 0, 0));
   for (int li = 0; li < h->layers; ++li) {
     const VitLayer& l = h->L[li];
     const VitLayerKeep& k = w.L[li];
@@ -270,13 +288,15 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
     launch_gemm_bf16_nt_epi(ws + k.xn1, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
     if (launch_flash_attention_v2(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, B, N, N, h->heads, dh, causal, s, (float*)(ws + k.lse)))
       return prego_fail_(PREGO_EINVAL, "attention launch failed");
-    GemmEpi r{}; r.mode = EPI_RESIDUAL;
-    launch_gemm_bf16_nt_epi(ws + k.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);
+    GemmEpi r{}; r.mode = EPI_RESIDUAL; r.drop_thresh = dthr; r.drop_scale = dsc; r.drop_seed = site_seed(h, li, 1);
+    launch_gemm_bf16_nt_epi(ws + k.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);              // x += drop(proj(attn))
     HIPCHK(hipMemcpyAsync(ws + k.x_mid, x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s));
     launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + k.xn2, (float*)(ws + k.st2), 0.f, 0, 0, s, 0);
     GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + k.f; g.pre_f32 = (float*)(ws + k.u);
-    launch_gemm_bf16_nt_epi(ws + k.xn2, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);
-    launch_gemm_bf16_nt_epi(ws + k.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);
+    g.drop_thresh = dthr; g.drop_scale = dsc; g.drop_seed = site_seed(h, li, 2);
+    launch_gemm_bf16_nt_epi(ws + k.xn2, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);   // f = drop(gelu(.))
+    r.drop_seed = site_seed(h, li, 3);
+    launch_gemm_bf16_nt_epi(ws + k.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);     // x += drop(W2 f + b2)
   }
   launch_vit_head(x, B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
   HIPCHK(hipGetLastError());
@@ -304,6 +324,8 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
   const int B = batch, T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow, M = B * N, dh = E / h->heads, mlp = h->mlp;
   const int causal = (flags & 1) ? 1 : 0;
   const int Mp = w.Mp;
+  const unsigned dthr = drop_thresh_of(h);
+  const float dsc = drop_scale_of(h);
   float* dx = (float*)(ws + w.dx);
   float* tmp = (float*)(ws + w.tmp);
   float* part = (float*)(ws + w.part);
@@ -323,13 +345,16 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
     const VitLayer& l = h->L[li];
     const VitLayerKeep& k = w.L[li];
     float* const* g = gl + 11 * li;      // ln1 w,b | qkv w | proj w,b | ln2 w,b | ff1 w,b | ff2 w,b
-    // ---- FFN: x += W2 gelu(W1 LN2(x) + b1) + b2   (Transformer.py:35-47)
-    launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
-    launch_colsum(dx, M, E, part, g[10], s);                                                 // d b2
-    wgrad(dx, false, E, ws + k.f, true, mlp, M, Mp, T1, T2, g[9], s);                        // d W2 [E, mlp]
+    // ---- FFN: x += drop(W2 drop(gelu(W1 LN2(x) + b1)) + b2)   (Transformer.py:35-47)
+    // gradient entering a branch = dx through that branch's output dropout (same stateless mask as the forward)
+    const float* dbr = dx;
+    if (dthr) { launch_mask_convert(dx, (size_t)M * E, (float*)(ws + w.dxm), ws + w.dxb, dthr, dsc, site_seed(h, li, 3), s); dbr = (const float*)(ws + w.dxm); }
+    else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
+    launch_colsum(dbr, M, E, part, g[10], s);                                                // d b2
+    wgrad(dbr, false, E, ws + k.f, true, mlp, M, Mp, T1, T2, g[9], s);                       // d W2 [E, mlp]
     launch_transpose_convert(true, true, l.ff2_w, E, mlp, mlp, WT, E, s);                    // W2^T [mlp][E]
     launch_gemm_bf16_nt(ws + w.dxb, E, WT, E, nullptr, tmp, mlp, M, mlp, E, s);              // d f = dx . W2
-    launch_gelu_bwd(tmp, (const float*)(ws + k.u), (size_t)M * mlp, (float*)(ws + w.du), ws + w.dub, s);
+    launch_gelu_bwd(tmp, (const float*)(ws + k.u), (size_t)M * mlp, (float*)(ws + w.du), ws + w.dub, s, dthr, dsc, site_seed(h, li, 2));
     launch_colsum((const float*)(ws + w.du), M, mlp, part, g[8], s);                         // d b1
     wgrad(ws + w.du, false, mlp, ws + k.xn2, true, E, M, Mp, T1, T2, g[7], s);               // d W1 [mlp, E]
     launch_transpose_convert(true, true, l.ff1_w, mlp, E, E, WT, mlp, s);                    // W1^T [E][mlp]
@@ -339,10 +364,12 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
     launch_colsum_stage2(part, nb, 2 * E, vec, s);
     HIPCHK(hipMemcpyAsync(g[5], vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(g[6], vec + E, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
-    // ---- attention: x += proj(attn(LN1(x)))   (Attention.py:21-41)
-    launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
-    launch_colsum(dx, M, E, part, g[4], s);                                                  // d proj bias
-    wgrad(dx, false, E, ws + k.ao, true, E, M, Mp, T1, T2, g[3], s);                         // d Wproj [E, E]
+    // ---- attention: x += drop(proj(attn(LN1(x))))   (Attention.py:21-41, Transformer.py:24-32)
+    dbr = dx;
+    if (dthr) { launch_mask_convert(dx, (size_t)M * E, (float*)(ws + w.dxm), ws + w.dxb, dthr, dsc, site_seed(h, li, 1), s); dbr = (const float*)(ws + w.dxm); }
+    else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
+    launch_colsum(dbr, M, E, part, g[4], s);                                                 // d proj bias
+    wgrad(dbr, false, E, ws + k.ao, true, E, M, Mp, T1, T2, g[3], s);                        // d Wproj [E, E]
     launch_transpose_convert(true, true, l.proj_w, E, E, E, WT, E, s);                       // Wp^T
     {
       GemmEpi eb{}; eb.mode = EPI_STORE_BF16; eb.out_b = ws + w.dO;
@@ -362,7 +389,7 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
   }
   // ---- tokens: positional table, cls token, encoding Linear (ViT.py:125-129)
   float* denc = (float*)(ws + w.denc);
-  launch_vit_tokens_bwd(dx, B, T, E, denc, g_pe, g_cls, s);
+  launch_vit_tokens_bwd(dx, B, T, E, denc, g_pe, g_cls, s, dthr, dsc, site_seed(h, 0, 0));
   launch_colsum(denc, B * T, E, part, g_enc_b, s);
   wgrad(denc, false, E, ws + w.xb, true, din, B * T, w.MTp, T1, T2, g_enc_w, s);             // d W_enc [E, din]
   HIPCHK(hipGetLastError());

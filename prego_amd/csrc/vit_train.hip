@@ -9,7 +9,7 @@
 #include "kernels.h"
 
 __global__ void gelu_bwd_kernel(const float* __restrict__ df, const float* __restrict__ u, size_t n, float* __restrict__ du,
-                                bf16_t* __restrict__ du_b) {
+                                bf16_t* __restrict__ du_b, unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     const float4 g = *(const float4*)(df + i), x = *(const float4*)(u + i);
     const float gg[4] = {g.x, g.y, g.z, g.w}, xx[4] = {x.x, x.y, x.z, x.w};
@@ -19,18 +19,42 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ df, const float* __res
       // d/dx [x Phi(x)] = Phi(x) + x phi(x)
       const float cdf = 0.5f * (1.0f + erff(xx[k] * 0.70710678118654752f));
       const float pdf = 0.3989422804014327f * __expf(-0.5f * xx[k] * xx[k]);
-      o[k] = gg[k] * (cdf + xx[k] * pdf);
+      // the FFN's first Dropout sits between GELU and the second Linear (Transformer.py:41): same mask as the forward
+      const float gk = drop_thresh ? (dropout_keep_(drop_seed, i + k, drop_thresh) ? gg[k] * drop_scale : 0.f) : gg[k];
+      o[k] = gk * (cdf + xx[k] * pdf);
     }
     *(float4*)(du + i) = make_float4(o[0], o[1], o[2], o[3]);
     uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
     *(uint2*)(du_b + i) = w;
   }
 }
-void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s) {
+void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s, unsigned drop_thresh,
+                     float drop_scale, unsigned long long drop_seed) {
   if (n == 0) return;
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  gelu_bwd_kernel<<<(int)blocks, 256, 0, s>>>(df, u, n, du, (bf16_t*)du_bf16);
+  gelu_bwd_kernel<<<(int)blocks, 256, 0, s>>>(df, u, n, du, (bf16_t*)du_bf16, drop_thresh, drop_scale, drop_seed);
+}
+
+// gradient entering a dropped-out branch: out = src * mask * scale, as fp32 (bias column sums, wgrad operand) and bf16 (dgrad operand)
+__global__ void mask_convert_kernel(const float* __restrict__ src, size_t n, float* __restrict__ out, bf16_t* __restrict__ out_b,
+                                    unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+    const float4 v = *(const float4*)(src + i);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = dropout_keep_(drop_seed, i + k, drop_thresh) ? o[k] * drop_scale : 0.f;
+    if (out) *(float4*)(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+    uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
+    *(uint2*)(out_b + i) = w;
+  }
+}
+void launch_mask_convert(const float* src, size_t n, float* out_f32, void* out_bf16, unsigned drop_thresh, float drop_scale,
+                         unsigned long long drop_seed, hipStream_t s) {
+  if (n == 0) return;
+  size_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  mask_convert_kernel<<<(int)blocks, 256, 0, s>>>(src, n, out_f32, (bf16_t*)out_bf16, drop_thresh, drop_scale, drop_seed);
 }
 
 // ---- head: logits = LN(x[b,0,:]) Wh^T + bh  (ViT.py:134-138) -----------------------------------------------------
@@ -115,20 +139,23 @@ void launch_vit_head_bwd(const float* x, const float* dlogits, int B, int N, int
 // ---- tokens: x[b,n,:] = (n < T ? enc[b,n,:] : cls) + pe[n,:]   (ViT.py:126-129, PositionalEncoding.py:36-41) ------
 // grid (N, E/256): d pe[n] = sum_b dx[b,n]; d cls = sum_b dx[b,T]; denc[b*T + n] = dx[b,n] for n < T (compact rows)
 __global__ void vit_tokens_bwd_kernel(const float* __restrict__ dx, int B, int T, int E, float* __restrict__ denc,
-                                      float* __restrict__ g_pe, float* __restrict__ g_cls) {
+                                      float* __restrict__ g_pe, float* __restrict__ g_cls, unsigned drop_thresh, float drop_scale,
+                                      unsigned long long drop_seed) {
   const int n = blockIdx.x, c = blockIdx.y * blockDim.x + threadIdx.x;
   if (c >= E) return;
   const int N = T + 1;
   float a = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float v = dx[((size_t)b * N + n) * E + c];
+    float v = dx[((size_t)b * N + n) * E + c];
+    if (drop_thresh) v = dropout_keep_(drop_seed, ((size_t)b * N + n) * E + c, drop_thresh) ? v * drop_scale : 0.f;   // pe_dropout
     a += v;
     if (n < T) denc[((size_t)b * T + n) * E + c] = v;
   }
   g_pe[(size_t)n * E + c] = a;
   if (n == T) g_cls[c] = a;
 }
-void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s) {
+void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s,
+                           unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
   dim3 g(T + 1, (E + 255) / 256);
-  vit_tokens_bwd_kernel<<<g, 256, 0, s>>>(dx, B, T, E, denc, g_pe, g_cls);
+  vit_tokens_bwd_kernel<<<g, 256, 0, s>>>(dx, B, T, E, denc, g_pe, g_cls, drop_thresh, drop_scale, drop_seed);
 }

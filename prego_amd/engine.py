@@ -213,7 +213,7 @@ class MiniRoadEngine:
         for n in sizes:
             offs.append(total)
             total += (n + 63) // 64 * 64            # 256-byte aligned views
-        self._grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._grad_flat = torch.empty(total, dtype=torch.float32, device=self.device)   # every gradient tensor is overwritten by backward
         grads = {k: self._grad_flat[o:o + n].view(shapes[k]) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}
         dl_p = ptr_array([dlogits.data_ptr() + b * T * ncls * 4 for b in range(B)])
         with torch.cuda.device(self.device):

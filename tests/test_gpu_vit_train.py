@@ -74,7 +74,7 @@ def test_g5b_vit_train_step_matches_reference(layers):
     print(f"vit train L{layers}: loss {float(loss.detach()):.5f} (ref {float(g['loss']):.5f}), worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
-def test_vit_train_is_deterministic_and_rejects_dropout():
+def test_vit_train_is_deterministic_and_rejects_attention_dropout():
     from prego_amd._lib import PregoError
     from prego_amd.registry import build_criterion, build_model
     import prego_amd.loss, prego_amd.transformer  # noqa: F401
@@ -93,8 +93,8 @@ def test_vit_train_is_deterministic_and_rejects_dropout():
         runs.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k               # fixed-order sums, no atomics: bit-reproducible
-    m = build_model(_vit_cfg(num_layers=1, dropout=0.1), "cuda:0").train()
-    with pytest.raises(PregoError):
+    m = build_model(_vit_cfg(num_layers=1, attn_dropout_rate=0.1), "cuda:0").train()
+    with pytest.raises(PregoError):                               # attention-probability dropout: not implemented, said loudly
         m(rgb, flow)
 
 
@@ -147,3 +147,45 @@ def test_attention_backward_kernel_vs_oracle(N, dh, causal):
         assert err < 2e-2 * max(np.abs(wsl).max(), 1e-3) + 1e-4, (name, err, np.abs(wsl).max())
         cos = float((gsl * wsl).sum() / (np.linalg.norm(gsl) * np.linalg.norm(wsl) + 1e-30))
         assert cos > 0.9995, (name, cos)
+
+
+def test_vit_train_with_dropout_matches_oracle_with_the_same_masks():
+    """cfg['dropout'] = 0.2 on the Transformer entry: the HIP path draws stateless hash masks (seed, site, element); the oracle
+    replays EXACTLY those masks (oracle_np.hash_dropout_mask) through its hand-written forward/backward: loss and all gradients
+    must agree, which pins (a) one mask per site shared by forward and backward, (b) the 1/(1-p) scaling, (c) the four sites."""
+    from prego_amd.registry import build_criterion, build_model
+    import prego_amd.loss, prego_amd.transformer  # noqa: F401
+    p_drop, seed, layers, B, T, E, mlp = 0.2, 123456789, 2, 2, 128, 2048, 1024
+    cfg = _vit_cfg(num_layers=layers, dropout=p_drop)
+    sd = W.vit_state_dict(cfg, 20)
+    model = build_model(cfg, "cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.debug_dropout_seed = seed
+    crit = build_criterion(cfg, "cuda:0")
+    rgb = W.tsn_features((B, T, 2048), 20, "g5.rgb")
+    flow = W.tsn_features((B, T, 2048), 20, "g5.flow")
+    tgt = _targets(B, T, 86, 20, "g5b.tgt")
+    model.train()
+    loss = crit(model(torch.from_numpy(rgb).cuda(), torch.from_numpy(flow).cuda()), torch.from_numpy(tgt).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    N = T + 1
+
+    def site(layer, s_):
+        return seed + 0x1000 * (layer + 1) * (1 if s_ else 0) + s_
+    masks = {"pe": O.hash_dropout_mask(site(0, 0), B * N * E, p_drop).reshape(B, N, E)}
+    for l in range(layers):
+        masks[(l, "attn")] = O.hash_dropout_mask(site(l, 1), B * N * E, p_drop).reshape(B, N, E)
+        masks[(l, "gelu")] = O.hash_dropout_mask(site(l, 2), B * N * mlp, p_drop).reshape(B, N, mlp)
+        masks[(l, "ffn")] = O.hash_dropout_mask(site(l, 3), B * N * E, p_drop).reshape(B, N, E)
+    assert 0.75 < float((masks["pe"] > 0).mean()) < 0.85
+    ref_loss, _, ref_g = O.vit_loss_and_grads(sd, rgb, flow, tgt, heads=8, num_layers=layers, masks=masks)
+    ref_loss0, _, _ = O.vit_loss_and_grads(sd, rgb, flow, tgt, heads=8, num_layers=layers)
+    assert abs(ref_loss - ref_loss0) > 1e-3                      # the masks do change the function
+    assert abs(float(loss.detach()) - ref_loss) < 2e-2, (float(loss.detach()), ref_loss)
+    for k, pr in model.named_parameters():
+        g = pr.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+        r = ref_g[k].reshape(-1)
+        cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30))
+        assert cos > 0.995, (k, cos)
+        assert abs(np.linalg.norm(g) - np.linalg.norm(r)) < 0.10 * np.linalg.norm(r) + 1e-9, k
