@@ -560,18 +560,20 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
-    if (prefetch && t1 < h->t_max) {
+    const bool prefetch_next = prefetch && t1 < h->t_max;
+    ev = ev_begin(h, 1, s);
+    if (prefetch_next) HIPCHK(hipEventRecord(h->ev_fork, s));      // fork point: everything before the recurrence launch
+    if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
+    ev_end(ev, s);
+    if (prefetch_next) {
       // X is dead once the layer1 GEMM of this chunk has run: stream the next chunk's features into it while the recurrence
-      // (latency-bound, one wave per SIMD) holds the CUs
-      HIPCHK(hipEventRecord(h->ev_fork, s));
+      // (latency-bound, one wave per SIMD) holds the CUs.  The recurrence is launched FIRST so that its 256 workgroups are
+      // resident (placement rendezvous) before the copy's workgroups fill the wave slots
       HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       pack_chunk(t1, chunk_end(t1), h->side);
       HIPCHK(hipEventRecord(h->ev_join, h->side));
       packed = true;
     }
-    ev = ev_begin(h, 1, s);
-    if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
-    ev_end(ev, s);
 
     if (out || argmax) {
       if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, plan, base, rows, H, h->ncls,
