@@ -188,11 +188,11 @@ int prego_vit_forward(prego_vit* h, int batch, const float* rgb, const float* fl
  * grads: host array of n_tensors device fp32 tensors in prego_vit_set_weights' order and shapes, OVERWRITTEN.  All sums over
  * rows / windows run in a fixed order (bit-reproducible); the attention backward recomputes the probabilities from Q, K and the
  * forward's log-sum-exp (no [B,h,N,N] tensor) and uses no atomics.  flags bit 0: causal attention (as in forward). */
-/* nn.Dropout(p = cfg['dropout']) of the training-mode forward: pe_dropout (ViT.py:130), PreNormDrop after the attention block
- * (Transformer.py:24-32) and the two Dropouts of FeedForward (Transformer.py:41,46); stateless hash masks of (seed, site, element),
- * regenerated by backward.  The attention-probability / projection dropouts (cfg['attn_dropout_rate'], Attention.py:17,19) are
- * not implemented: that rate must be 0 (the host module rejects anything else). */
-int prego_vit_set_dropout(prego_vit* h, float p, uint64_t seed);
+/* The nn.Dropout layers of the training-mode forward.  p = cfg['dropout']: pe_dropout (ViT.py:130), PreNormDrop after the
+ * attention block (Transformer.py:24-32) and the two Dropouts of FeedForward (Transformer.py:41,46).  attn_p =
+ * cfg['attn_dropout_rate']: the attention probabilities inside the attention kernel (Attention.py:17,36) and proj_drop
+ * (Attention.py:19,40).  All are stateless hash masks of (seed, site, element), regenerated by backward. */
+int prego_vit_set_dropout(prego_vit* h, float p, float attn_p, uint64_t seed);
 size_t prego_vit_train_workspace_bytes(const prego_vit* h, int batch);
 int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
                             void* workspace, size_t workspace_bytes, prego_stream_t stream);

@@ -330,7 +330,8 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
     SelfAttention of Attention.py:21-41), the learned positional table, the cls token (appended at the END, ViT.py:128) and the
     encoding Linear.  `masks` (optional): multiplicative dropout masks at the reference's nn.Dropout sites outside the attention
     module: masks["pe"] [B,N,E] (ViT.py:130), masks[(l, "attn")] [B,N,E] (PreNormDrop, Transformer.py:31), masks[(l, "gelu")]
-    [B,N,mlp] and masks[(l, "ffn")] [B,N,E] (FeedForward, Transformer.py:41,46).
+    [B,N,mlp] and masks[(l, "ffn")] [B,N,E] (FeedForward, Transformer.py:41,46); inside it: masks[(l, "prob")] [B,h,N,N]
+    (attn_drop, Attention.py:36) and masks[(l, "proj")] [B,N,E] (proj_drop, Attention.py:40).
     Returns (loss, logits [B,1,C], grads keyed like the state_dict)."""
     masks = masks or {}
     one = 1.0
@@ -356,9 +357,11 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
         if causal:
             sc = np.where(np.triu(np.ones((N, N), dtype=bool), 1), -np.inf, sc)
         att = softmax(sc)
-        o = np.einsum("bhij,bhjd->bhid", att, v).transpose(0, 2, 1, 3).reshape(B, N, E)
-        x = x + linear(o, p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.proj.bias"]) * masks.get((l, "attn"), one)
-        c.update(xn=xn, q=q, k=k, v=v, att=att, o=o, x_mid=x)
+        att_d = att * masks.get((l, "prob"), one)                 # attn_drop on the probabilities (Attention.py:36)
+        o = np.einsum("bhij,bhjd->bhid", att_d, v).transpose(0, 2, 1, 3).reshape(B, N, E)
+        x = x + (linear(o, p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.proj.bias"])
+                 * masks.get((l, "proj"), one) * masks.get((l, "attn"), one))       # proj_drop, then PreNormDrop
+        c.update(xn=xn, q=q, k=k, v=v, att=att, att_d=att_d, o=o, x_mid=x)
         xn2 = layernorm(x, p[f"encoder.net.{f_}.fn.norm.weight"], p[f"encoder.net.{f_}.fn.norm.bias"])
         u = linear(xn2, p[f"encoder.net.{f_}.fn.fn.net.0.weight"], p[f"encoder.net.{f_}.fn.fn.net.0.bias"])
         f = gelu_erf(u) * masks.get((l, "gelu"), one)
@@ -392,12 +395,12 @@ def vit_loss_and_grads(sd, rgb, flow, target, heads, num_layers=1, dt=np.float64
             du @ w1, c["x_mid"], p[f"encoder.net.{f_}.fn.norm.weight"])
         dx = dx + dxa
         wp, wq = p[f"encoder.net.{a_}.fn.fn.proj.weight"], p[f"encoder.net.{a_}.fn.fn.qkv.weight"]
-        dbr = dx * masks.get((l, "attn"), one)
+        dbr = dx * masks.get((l, "attn"), one) * masks.get((l, "proj"), one)
         g[f"encoder.net.{a_}.fn.fn.proj.weight"] = np.einsum("bne,bnd->ed", dbr, c["o"])
         g[f"encoder.net.{a_}.fn.fn.proj.bias"] = dbr.sum(axis=(0, 1))
         do = (dbr @ wp).reshape(B, N, heads, dh).transpose(0, 2, 1, 3)
-        dv = np.einsum("bhij,bhid->bhjd", c["att"], do)
-        da = np.einsum("bhid,bhjd->bhij", do, c["v"])
+        dv = np.einsum("bhij,bhid->bhjd", c["att_d"], do)
+        da = np.einsum("bhid,bhjd->bhij", do, c["v"]) * masks.get((l, "prob"), one)
         ds = c["att"] * (da - (da * c["att"]).sum(axis=-1, keepdims=True))
         dq = np.einsum("bhij,bhjd->bhid", ds, c["k"]) * scale
         dk = np.einsum("bhij,bhid->bhjd", ds, c["q"]) * scale

@@ -90,7 +90,7 @@ def load() -> C.CDLL:
     lib.prego_vit_workspace_bytes.argtypes = [vp, i32]
     lib.prego_vit_workspace_bytes.restype = sz
     lib.prego_vit_forward.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]
-    lib.prego_vit_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
+    lib.prego_vit_set_dropout.argtypes = [vp, C.c_float, C.c_float, C.c_uint64]
     lib.prego_vit_train_workspace_bytes.argtypes = [vp, i32]
     lib.prego_vit_train_workspace_bytes.restype = sz
     lib.prego_vit_forward_train.argtypes = [vp, i32, vp, vp, vp, i32, vp, sz, vp]

@@ -29,7 +29,10 @@ typedef short v4s_t __attribute__((ext_vector_type(4)));
 template <int DH, int QG>
 __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* __restrict__ out,
-    int Nq, int N, int heads, int causal, float* __restrict__ lse) {
+    int Nq, int N, int heads, int causal, float* __restrict__ lse, unsigned drop_thresh, float drop_scale,
+    unsigned long long drop_seed) {
+  // drop_thresh != 0: training-mode nn.Dropout on the attention probabilities (Attention.py:17,36): a stateless hash mask of
+  // (seed, (bh * Nq + query) * N + key) multiplies P where it enters P.V; the softmax denominator sums the undropped P
   constexpr int KS = DH / 32, DT = DH / 16;
   constexpr int CPR = DH / 8;                         // 16-byte chunks per row
   constexpr int SW = CPR < 16 ? CPR : 16;             // XOR swizzle period: chunk position = chunk ^ (row & (SW - 1))
@@ -135,6 +138,11 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
         float p[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { p[e] = __expf(st[u][t][e] - msafe); rs += p[e]; }
+        if (drop_thresh) {
+          const size_t rowi = ((size_t)bh * Nq + (own[u] < Nq ? own[u] : Nq - 1)) * N + k0 + t * 16 + 4 * g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) p[e] = dropout_keep_(drop_seed, rowi + e, drop_thresh) ? p[e] : 0.f;
+        }
         pw[t >> 1][2 * (t & 1)] = pack_bf16x2(p[0], p[1]);
         pw[t >> 1][2 * (t & 1) + 1] = pack_bf16x2(p[2], p[3]);
       }
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
 #pragma unroll
   for (int u = 0; u < QG; ++u)
     if (own[u] < Nq) {
-      const float inv = 1.0f / l_run[u];
+      const float inv = drop_scale / l_run[u];                               // 1 / (1 - p) of the probability dropout (1 without it)
       if (lse != nullptr && g == 0) lse[(size_t)bh * Nq + own[u]] = m_run[u] + logf(l_run[u]);
       bf16_t* orow = out + ((size_t)b * Nq + own[u]) * heads * DH + (size_t)hd * DH;
 #pragma unroll
@@ -186,7 +194,9 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
 // V row-major [B,h,N,dh]; Nq queries per (batch, head) at positions 0..Nq-1 (Nq == N for self-attention; Nq = 1: only token 0,
 // the last encoder layer of ViTEnc whose output is read at token 0 only, ViT.py:136)
 int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
-                              int causal, hipStream_t s, float* lse) {
+                              int causal, hipStream_t s, float* lse, unsigned drop_thresh, float drop_scale,
+                              unsigned long long drop_seed) {
+  if (!drop_thresh) drop_scale = 1.f;
   const int qg = Nq > 192 ? 2 : 1;                   // 129-token windows: 3 x 64 query slots instead of 2 x 128
   dim3 grid((Nq + 64 * qg - 1) / (64 * qg), B * heads);
 #define FA2(D, G)                                                                                                \
@@ -195,7 +205,7 @@ int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void*
     static DeviceOnce once;                                                                                      \
     once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_v2_kernel<D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
     flash_attention_v2_kernel<D, G><<<grid, 256, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, Nq, N, \
-                                                           heads, causal, lse);                                  \
+                                                           heads, causal, lse, drop_thresh, drop_scale, drop_seed);      \
   } while (0)
   if (dh == 256) { if (qg == 2) FA2(256, 2); else FA2(256, 1); }
   else if (dh == 128) { if (qg == 2) FA2(128, 2); else FA2(128, 1); }

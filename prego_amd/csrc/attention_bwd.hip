@@ -30,7 +30,10 @@ template <int DH, bool BYKEY>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
     const bf16_t* __restrict__ Qs, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
     const bf16_t* __restrict__ dO, const float* __restrict__ lse, const float* __restrict__ delta,
-    bf16_t* __restrict__ dqkv, int N, int heads, int causal, float q_scale) {
+    bf16_t* __restrict__ dqkv, int N, int heads, int causal, float q_scale, unsigned drop_thresh, float drop_scale,
+    unsigned long long drop_seed) {
+  // drop_thresh != 0: the forward dropped the probabilities (mask of (seed, (bh * N + query) * N + key), scale 1 / (1 - p)):
+  // dV uses the dropped P, the gradient of the probabilities passes through the same mask; delta = rowsum(dO * O) still holds
   constexpr int KS = DH / 32;            // k-steps over the head dim (S, dP)
   constexpr int DT = DH / 16;            // 16-row tiles of the transposed outputs
   constexpr int LD = DH + 8;             // LDS row pitch (elements); (DH+8)*2 bytes is a multiple of 8 (ds_read_b64_tr_b16)
@@ -121,7 +124,15 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
           l_ = lse[(size_t)bh * N + qi]; d_ = delta[(size_t)bh * N + qi];
         } else { l_ = own_lse; d_ = own_delta; }
         p[e] = ok ? __expf(x1[t][e] - l_) : 0.f;
-        ds[e] = p[e] * (x2[t][e] - d_);
+        float dp = x2[t][e];
+        float pd = p[e];                                         // the probability as it entered P.V
+        if (drop_thresh) {
+          const int qc = q < N ? q : N - 1, kc = key < N ? key : N - 1;
+          const float mk = dropout_keep_(drop_seed, ((size_t)bh * N + qc) * N + kc, drop_thresh) ? drop_scale : 0.f;
+          dp *= mk; pd *= mk;
+        }
+        ds[e] = p[e] * (dp - d_);
+        p[e] = pd;
       }
       const int s = t >> 1, half = t & 1;                        // k-step, which four of its eight elements
       pw[s][2 * half] = pack_bf16x2(p[0], p[1]); pw[s][2 * half + 1] = pack_bf16x2(p[2], p[3]);
@@ -200,7 +211,8 @@ __global__ __launch_bounds__(256) void attention_delta_kernel(const bf16_t* __re
 
 // dqkv [B*N, 3*heads*dh] bf16 := gradients of the fused qkv projection's output.  q_scale = dh^-0.5 (Attention.py:14).
 int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                         float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s) {
+                         float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s,
+                         unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
   if (dh % 4) return -1;
   attention_delta_kernel<<<(B * N * heads + 3) / 4, 256, 0, s>>>((const bf16_t*)dO, (const bf16_t*)O, delta, B, N, heads, dh);
   dim3 grid((N + 63) / 64, B * heads);
@@ -213,9 +225,9 @@ int launch_attention_bwd(const void* Qs, const void* K, const void* V, const voi
       (void)hipFuncSetAttribute((const void*)attention_bwd_kernel<D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     });                                                                                                                       \
     attention_bwd_kernel<D, true><<<grid, 256, lds, s>>>((const bf16_t*)Qs, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
-                                                         lse, delta, (bf16_t*)dqkv, N, heads, causal, q_scale);               \
+                                                         lse, delta, (bf16_t*)dqkv, N, heads, causal, q_scale, drop_thresh, drop_scale, drop_seed); \
     attention_bwd_kernel<D, false><<<grid, 256, lds, s>>>((const bf16_t*)Qs, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
-                                                          lse, delta, (bf16_t*)dqkv, N, heads, causal, q_scale);              \
+                                                          lse, delta, (bf16_t*)dqkv, N, heads, causal, q_scale, drop_thresh, drop_scale, drop_seed); \
   } while (0)
   if (dh == 256) AB(256);
   else if (dh == 128) AB(128);

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             else C[(size_t)m * ldc + n] = v;
           } else if constexpr (EPI == EPI_RESIDUAL) {                 // x += v  (fp32 residual stream, in place)
             if (epi.drop_thresh) v = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
+            if (epi.drop2_thresh) v = dropout_keep_(epi.drop2_seed, (size_t)m * ldc + n, epi.drop2_thresh) ? v * epi.drop2_scale : 0.f;
             float* xr = (float*)C + (size_t)m * ldc + n;
             *xr = *xr + v;
           } else if constexpr (EPI == EPI_GELU_BF16) {                // FFN-1: bf16(gelu(v))

@@ -260,6 +260,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #pragma unroll
               for (int e = 0; e < 8; ++e) o[e] = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n + e, epi.drop_thresh) ? o[e] * epi.drop_scale : 0.f;
             }
+            if (epi.drop2_thresh) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = dropout_keep_(epi.drop2_seed, (size_t)m * ldc + n + e, epi.drop2_thresh) ? o[e] * epi.drop2_scale : 0.f;
+            }
             float4* xr = (float4*)(C + (size_t)m * ldc + n);
             const float4 r0 = xr[0], r1 = xr[1];
             xr[0] = make_float4(r0.x + o[0], r0.y + o[1], r0.z + o[2], r0.w + o[3]);

@@ -84,6 +84,7 @@ struct GemmEpi {
   // training-mode nn.Dropout on the epilogue's result (EPI_RESIDUAL: on acc + bias before the residual add, Transformer.py:31,46;
   // EPI_GELU_BF16: on gelu(.), Transformer.py:41): stateless hash mask of (seed, m * ldc + n); thresh = 0 -> no dropout
   unsigned drop_thresh; float drop_scale; unsigned long long drop_seed;
+  unsigned drop2_thresh; float drop2_scale; unsigned long long drop2_seed;   // a second, independent mask on the same value (proj_drop, Attention.py:19,40)
   float* pre_f32;              // EPI_GELU_BF16, training: the pre-activation W1 x + b1 in fp32 (gelu'), leading dim = ldc; nullable
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
@@ -150,17 +151,20 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
 // Transformer path (attention.hip, vit.hip)
 // attention forward (attention.hip): query on the lane, V row-major [B,h,N,dh], Nq queries against N keys
 int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
-                              int causal, hipStream_t s, float* lse = nullptr);
+                              int causal, hipStream_t s, float* lse = nullptr, unsigned drop_thresh = 0, float drop_scale = 1.f,
+                              unsigned long long drop_seed = 0);
 // attention backward (attention_bwd.hip): dqkv [B*N, 3*heads*dh] bf16; delta: scratch fp32 [B*heads*N]
 int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
-                         float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s);
+                         float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s,
+                         unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
 // ViTEnc training glue (vit_train.hip)
 // dropout arguments (thresh = p * 2^32, scale = 1 / (1 - p), seed): thresh = 0 means none
 void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void* du_bf16, hipStream_t s, unsigned drop_thresh = 0,
                      float drop_scale = 1.f, unsigned long long drop_seed = 0);
 // out_f32 (nullable) / out_bf16 := src * dropout mask(seed, element index) * scale
 void launch_mask_convert(const float* src, size_t n, float* out_f32, void* out_bf16, unsigned drop_thresh, float drop_scale,
-                         unsigned long long drop_seed, hipStream_t s);
+                         unsigned long long drop_seed, hipStream_t s, unsigned drop2_thresh = 0, float drop2_scale = 1.f,
+                         unsigned long long drop2_seed = 0);
 void launch_vit_head_bwd(const float* x, const float* dlogits, int B, int N, int E, int C, const float* lnw, const float* lnb,
                          const float* hw, float* dx, float* scratch /*[3][B][E]*/, float* g_lnw, float* g_lnb, float* g_hw,
                          float* g_hb, hipStream_t s);

@@ -229,8 +229,10 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
 }
 
 // ---- plan -------------------------------------------------------------------------------------
-// recurrence cost per time step (us) by live 16-clip tiles per group, measured (scripts/gru_stamps.py)
-static const double kStepCost[5] = {0.0, 2.4, 4.4, 6.4, 8.4};
+// recurrence cost per time step (us) by live 16-clip tiles per group, measured (scripts/probes/slot_sweep.sh, round 2: 512 clips x
+// 512 frames forced into 128 / 256 / 512 slots = 2.01 / 4.03 / 8.55 us per step): the tiles of a step run one after the other,
+// so the cost is linear in the tile count and the fewest slots that cover the clips win unless a longer slot chain dominates
+static const double kStepCost[5] = {0.0, 2.0, 4.03, 6.3, 8.55};
 
 // Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
 // backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
@@ -282,7 +284,9 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
     return c;
   };
   Cand best;
+  static const int force_slots = getenv("PREGO_PLAN_SLOTS") ? atoi(getenv("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
   if (want_single || n <= per_layer) best = pack(n);
+  else if (force_slots > 0) best = pack(std::min(n, std::min(force_slots, max_slots)));
   else {
     best = pack(std::min(n, per_layer));
     for (int S = 2 * per_layer; S <= max_slots; S *= 2) {

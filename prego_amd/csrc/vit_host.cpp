@@ -33,18 +33,23 @@ struct prego_vit {
   bool have_weights = false;
   // training-mode dropout (cfg['dropout']; ViT.py:130 pe_dropout, Transformer.py:31 PreNormDrop, Transformer.py:41,46 FeedForward)
   float drop_p = 0.f;
+  float attn_drop_p = 0.f;         // cfg['attn_dropout_rate']: attention probabilities (Attention.py:17,36) and proj_drop (Attention.py:19,40)
   unsigned long long drop_seed = 0;
 };
-// per-site mask seeds: site 0 = positional dropout, per layer: 1 = attention branch, 2 = after GELU, 3 = FFN output
+// per-site mask seeds: site 0 = positional dropout, per layer: 1 = attention branch, 2 = after GELU, 3 = FFN output,
+// 4 = attention probabilities, 5 = proj_drop
 static inline unsigned long long site_seed(const prego_vit* h, int layer, int site) {
   return h->drop_seed + 0x1000ull * (unsigned long long)(layer + 1) * (site ? 1 : 0) + (unsigned long long)site;
 }
 static inline unsigned drop_thresh_of(const prego_vit* h) { return h->drop_p > 0.f ? (unsigned)((double)h->drop_p * 4294967296.0) : 0u; }
 static inline float drop_scale_of(const prego_vit* h) { return h->drop_p > 0.f ? 1.f / (1.f - h->drop_p) : 1.f; }
-extern "C" int prego_vit_set_dropout(prego_vit* h, float p, uint64_t seed) {
+static inline unsigned athr_of(const prego_vit* h) { return h->attn_drop_p > 0.f ? (unsigned)((double)h->attn_drop_p * 4294967296.0) : 0u; }
+static inline float asc_of(const prego_vit* h) { return h->attn_drop_p > 0.f ? 1.f / (1.f - h->attn_drop_p) : 1.f; }
+extern "C" int prego_vit_set_dropout(prego_vit* h, float p, float attn_p, uint64_t seed) {
   if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
-  if (!(p >= 0.f && p < 1.f)) return prego_fail_(PREGO_EINVAL, "dropout p = %f", (double)p);
+  if (!(p >= 0.f && p < 1.f) || !(attn_p >= 0.f && attn_p < 1.f)) return prego_fail_(PREGO_EINVAL, "dropout p = %f, attn p = %f", (double)p, (double)attn_p);
   h->drop_p = p;
+  h->attn_drop_p = attn_p;
   h->drop_seed = seed;
   return PREGO_OK;
 }
@@ -286,16 +291,18 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
     e.mode = EPI_QKV; e.q = ws + k.q; e.k = ws + k.k; e.vn = ws + k.vn; e.n_tok = N;
     e.heads = h->heads; e.dh = dh; e.emb = E; e.q_scale = 1.0f / sqrtf((float)dh);
     launch_gemm_bf16_nt_epi(ws + k.xn1, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
-    if (launch_flash_attention_v2(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, B, N, N, h->heads, dh, causal, s, (float*)(ws + k.lse)))
+    if (launch_flash_attention_v2(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, B, N, N, h->heads, dh, causal, s, (float*)(ws + k.lse),
+                                  athr_of(h), asc_of(h), site_seed(h, li, 4)))
       return prego_fail_(PREGO_EINVAL, "attention launch failed");
     GemmEpi r{}; r.mode = EPI_RESIDUAL; r.drop_thresh = dthr; r.drop_scale = dsc; r.drop_seed = site_seed(h, li, 1);
+    r.drop2_thresh = athr_of(h); r.drop2_scale = asc_of(h); r.drop2_seed = site_seed(h, li, 5);        // proj_drop, then PreNormDrop
     launch_gemm_bf16_nt_epi(ws + k.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);              // x += drop(proj(attn))
     HIPCHK(hipMemcpyAsync(ws + k.x_mid, x, (size_t)M * E * 4, hipMemcpyDeviceToDevice, s));
     launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + k.xn2, (float*)(ws + k.st2), 0.f, 0, 0, s, 0);
     GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + k.f; g.pre_f32 = (float*)(ws + k.u);
     g.drop_thresh = dthr; g.drop_scale = dsc; g.drop_seed = site_seed(h, li, 2);
     launch_gemm_bf16_nt_epi(ws + k.xn2, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);   // f = drop(gelu(.))
-    r.drop_seed = site_seed(h, li, 3);
+    r.drop_seed = site_seed(h, li, 3); r.drop2_thresh = 0;
     launch_gemm_bf16_nt_epi(ws + k.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);     // x += drop(W2 f + b2)
   }
   launch_vit_head(x, B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
@@ -366,8 +373,11 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
     HIPCHK(hipMemcpyAsync(g[6], vec + E, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
     // ---- attention: x += drop(proj(attn(LN1(x))))   (Attention.py:21-41, Transformer.py:24-32)
     dbr = dx;
-    if (dthr) { launch_mask_convert(dx, (size_t)M * E, (float*)(ws + w.dxm), ws + w.dxb, dthr, dsc, site_seed(h, li, 1), s); dbr = (const float*)(ws + w.dxm); }
-    else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
+    if (dthr || athr_of(h)) {
+      launch_mask_convert(dx, (size_t)M * E, (float*)(ws + w.dxm), ws + w.dxb, dthr, dsc, site_seed(h, li, 1), s, athr_of(h), asc_of(h),
+                          site_seed(h, li, 5));
+      dbr = (const float*)(ws + w.dxm);
+    } else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
     launch_colsum(dbr, M, E, part, g[4], s);                                                 // d proj bias
     wgrad(dbr, false, E, ws + k.ao, true, E, M, Mp, T1, T2, g[3], s);                        // d Wproj [E, E]
     launch_transpose_convert(true, true, l.proj_w, E, E, E, WT, E, s);                       // Wp^T
@@ -376,7 +386,7 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
       launch_gemm_bf16_nt_epi(ws + w.dxb, E, WT, E, nullptr, nullptr, E, M, E, E, eb, s);    // d o = dx . Wp (bf16, [B,N,h*dh])
     }
     if (launch_attention_bwd(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, ws + w.dO, (const float*)(ws + k.lse), (float*)(ws + w.delta),
-                             ws + w.dqkv, B, N, h->heads, dh, causal, 1.0f / sqrtf((float)dh), s))
+                             ws + w.dqkv, B, N, h->heads, dh, causal, 1.0f / sqrtf((float)dh), s, athr_of(h), asc_of(h), site_seed(h, li, 4)))
       return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
     wgrad(ws + w.dqkv, true, 3 * E, ws + k.xn1, true, E, M, Mp, T1, T2, g[2], s);            // d Wqkv [3E, E]
     launch_transpose_convert(true, true, l.qkv_w, 3 * E, E, E, WT, 3 * E, s);                // Wqkv^T [E][3E]

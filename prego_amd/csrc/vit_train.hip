@@ -38,23 +38,29 @@ void launch_gelu_bwd(const float* df, const float* u, size_t n, float* du, void*
 
 // gradient entering a dropped-out branch: out = src * mask * scale, as fp32 (bias column sums, wgrad operand) and bf16 (dgrad operand)
 __global__ void mask_convert_kernel(const float* __restrict__ src, size_t n, float* __restrict__ out, bf16_t* __restrict__ out_b,
-                                    unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
+                                    unsigned drop_thresh, float drop_scale, unsigned long long drop_seed, unsigned drop2_thresh,
+                                    float drop2_scale, unsigned long long drop2_seed) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
     const float4 v = *(const float4*)(src + i);
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = dropout_keep_(drop_seed, i + k, drop_thresh) ? o[k] * drop_scale : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      if (drop_thresh) o[k] = dropout_keep_(drop_seed, i + k, drop_thresh) ? o[k] * drop_scale : 0.f;
+      if (drop2_thresh) o[k] = dropout_keep_(drop2_seed, i + k, drop2_thresh) ? o[k] * drop2_scale : 0.f;
+    }
     if (out) *(float4*)(out + i) = make_float4(o[0], o[1], o[2], o[3]);
     uint2 w; w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]);
     *(uint2*)(out_b + i) = w;
   }
 }
 void launch_mask_convert(const float* src, size_t n, float* out_f32, void* out_bf16, unsigned drop_thresh, float drop_scale,
-                         unsigned long long drop_seed, hipStream_t s) {
+                         unsigned long long drop_seed, hipStream_t s, unsigned drop2_thresh, float drop2_scale,
+                         unsigned long long drop2_seed) {
   if (n == 0) return;
   size_t blocks = (n / 4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  mask_convert_kernel<<<(int)blocks, 256, 0, s>>>(src, n, out_f32, (bf16_t*)out_bf16, drop_thresh, drop_scale, drop_seed);
+  mask_convert_kernel<<<(int)blocks, 256, 0, s>>>(src, n, out_f32, (bf16_t*)out_bf16, drop_thresh, drop_scale, drop_seed, drop2_thresh,
+                                                  drop2_scale, drop2_seed);
 }
 
 // ---- head: logits = LN(x[b,0,:]) Wh^T + bh  (ViT.py:134-138) -----------------------------------------------------

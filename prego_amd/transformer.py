@@ -3,8 +3,8 @@
 `attn_dropout_rate` on top of the yaml), same `forward(rgb, flow) -> {'logits': [B,1,C]}` (raw logits in both modes),
 same state_dict keys/shapes, so reference checkpoints load.  bf16 MFMA operands, fp32 residual
 stream / LayerNorm / softmax.  Training (trainer/train.py:20-24) runs through `prego_vit_forward_train` / `prego_vit_backward`
-behind a torch.autograd.Function, with cfg['dropout'] as stateless hash masks at the reference's four nn.Dropout sites outside
-the attention module; cfg['attn_dropout_rate'] must be 0 there (not implemented: the module says so instead of skipping it)."""
+behind a torch.autograd.Function, with cfg['dropout'] and cfg['attn_dropout_rate'] as stateless hash masks at the reference's six
+nn.Dropout sites (positional, attention probabilities, proj_drop, after the attention block, twice inside the FFN)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -132,10 +132,6 @@ class ViTEnc(nn.Module):
 
     def forward(self, sequence_input_rgb, sequence_input_flow):
         if self.training and torch.is_grad_enabled():
-            if self.attn_dropout_rate != 0:
-                raise PregoError("ViTEnc training on the HIP path needs cfg['attn_dropout_rate'] == 0 "
-                                 f"(got {self.attn_dropout_rate}): the attention-probability / projection dropouts are not implemented "
-                                 "there (cfg['dropout'] is)")
             names = _tensor_order(self.num_layers)
             sd = dict(self.named_parameters())
             return {"logits": _ViTTrainFn.apply(self, sequence_input_rgb, sequence_input_flow, *[sd[k] for k in names]).unsqueeze(1)}
@@ -171,10 +167,11 @@ class _ViTTrainFn(torch.autograd.Function):
         if getattr(model, "_ws_train", None) is None or model._ws_train.numel() < need:
             model._ws_train = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((B, model.out_dim), dtype=torch.float32, device=dev)
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.dropout_rate > 0 else 0      # torch's RNG drives the mask seed
+        any_drop = model.dropout_rate > 0 or model.attn_dropout_rate > 0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if any_drop else 0      # torch's RNG drives the mask seed
         seed = getattr(model, "debug_dropout_seed", seed)
         with torch.cuda.device(dev):
-            check(lib.prego_vit_set_dropout(model._h, float(model.dropout_rate), seed & 0xFFFFFFFFFFFFFFFF))
+            check(lib.prego_vit_set_dropout(model._h, float(model.dropout_rate), float(model.attn_dropout_rate), seed & 0xFFFFFFFFFFFFFFFF))
             check(lib.prego_vit_forward_train(model._h, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
                                               C.c_void_p(out.data_ptr()), 1 if model.causal else 0,
                                               C.c_void_p(model._ws_train.data_ptr()), model._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))

@@ -74,8 +74,7 @@ def test_g5b_vit_train_step_matches_reference(layers):
     print(f"vit train L{layers}: loss {float(loss.detach()):.5f} (ref {float(g['loss']):.5f}), worst cosine {worst[0]:.5f} ({worst[1]})")
 
 
-def test_vit_train_is_deterministic_and_rejects_attention_dropout():
-    from prego_amd._lib import PregoError
+def test_vit_train_is_deterministic():
     from prego_amd.registry import build_criterion, build_model
     import prego_amd.loss, prego_amd.transformer  # noqa: F401
     cfg = _vit_cfg(num_layers=1)
@@ -93,9 +92,6 @@ def test_vit_train_is_deterministic_and_rejects_attention_dropout():
         runs.append({k: p.grad.detach().clone() for k, p in model.named_parameters()})
     for k in runs[0]:
         assert torch.equal(runs[0][k], runs[1][k]), k               # fixed-order sums, no atomics: bit-reproducible
-    m = build_model(_vit_cfg(num_layers=1, attn_dropout_rate=0.1), "cuda:0").train()
-    with pytest.raises(PregoError):                               # attention-probability dropout: not implemented, said loudly
-        m(rgb, flow)
 
 
 @pytest.mark.parametrize("N,dh,causal", [(129, 256, 0), (129, 256, 1), (70, 128, 0), (200, 64, 1), (64, 256, 0)])
@@ -149,14 +145,15 @@ def test_attention_backward_kernel_vs_oracle(N, dh, causal):
         assert cos > 0.9995, (name, cos)
 
 
-def test_vit_train_with_dropout_matches_oracle_with_the_same_masks():
+@pytest.mark.parametrize("p_drop,p_attn", [(0.2, 0.0), (0.1, 0.15), (0.0, 0.25)])
+def test_vit_train_with_dropout_matches_oracle_with_the_same_masks(p_drop, p_attn):
     """cfg['dropout'] = 0.2 on the Transformer entry: the HIP path draws stateless hash masks (seed, site, element); the oracle
     replays EXACTLY those masks (oracle_np.hash_dropout_mask) through its hand-written forward/backward: loss and all gradients
     must agree, which pins (a) one mask per site shared by forward and backward, (b) the 1/(1-p) scaling, (c) the four sites."""
     from prego_amd.registry import build_criterion, build_model
     import prego_amd.loss, prego_amd.transformer  # noqa: F401
-    p_drop, seed, layers, B, T, E, mlp = 0.2, 123456789, 2, 2, 128, 2048, 1024
-    cfg = _vit_cfg(num_layers=layers, dropout=p_drop)
+    seed, layers, B, T, E, mlp, heads = 123456789, 2, 2, 128, 2048, 1024, 8
+    cfg = _vit_cfg(num_layers=layers, dropout=p_drop, attn_dropout_rate=p_attn)
     sd = W.vit_state_dict(cfg, 20)
     model = build_model(cfg, "cuda:0")
     model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -178,7 +175,9 @@ def test_vit_train_with_dropout_matches_oracle_with_the_same_masks():
         masks[(l, "attn")] = O.hash_dropout_mask(site(l, 1), B * N * E, p_drop).reshape(B, N, E)
         masks[(l, "gelu")] = O.hash_dropout_mask(site(l, 2), B * N * mlp, p_drop).reshape(B, N, mlp)
         masks[(l, "ffn")] = O.hash_dropout_mask(site(l, 3), B * N * E, p_drop).reshape(B, N, E)
-    assert 0.75 < float((masks["pe"] > 0).mean()) < 0.85
+        masks[(l, "prob")] = O.hash_dropout_mask(site(l, 4), B * heads * N * N, p_attn).reshape(B, heads, N, N)
+        masks[(l, "proj")] = O.hash_dropout_mask(site(l, 5), B * N * E, p_attn).reshape(B, N, E)
+    assert abs(float((masks["pe"] > 0).mean()) - (1 - p_drop)) < 0.02 and abs(float((masks[(0, "prob")] > 0).mean()) - (1 - p_attn)) < 0.02
     ref_loss, _, ref_g = O.vit_loss_and_grads(sd, rgb, flow, tgt, heads=8, num_layers=layers, masks=masks)
     ref_loss0, _, _ = O.vit_loss_and_grads(sd, rgb, flow, tgt, heads=8, num_layers=layers)
     assert abs(ref_loss - ref_loss0) > 1e-3                      # the masks do change the function
