@@ -91,6 +91,18 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
   dma(0, 0);
   __syncthreads();                                                           // vmcnt(0) + barrier: tile 0 landed
   const int qp = l15 >> 2, pp = l15 & 3;
+  // per-lane LDS element offsets, computed ONCE: everything that varies inside the tile loop (key sub-tile t, buffer, k-step
+  // half, +16 rows) is a compile-time constant that folds into the ds_read offset field
+  //   row fragments of K: row 16 t + l15, chunk (4 ks + g) ^ (l15 & (SW-1))            -> kbase[ks] + t * 16 * DH
+  //   transposed reads of V: row 32 s + 4 g + qp (+16), chunk (2 dt + (pp >> 1)) ^ r15 -> vbase[dt & 7] + (dt >> 3) * 128 + ...
+  int kbase[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kbase[ks] = l15 * DH + (((ks * 4 + g) ^ (l15 & (SW - 1))) << 3);
+  constexpr int NVB = DT < 8 ? DT : 8;
+  int vbase[NVB];
+  const int r15 = (4 * g + qp) & (SW - 1);
+#pragma unroll
+  for (int d = 0; d < NVB; ++d) vbase[d] = (4 * g + qp) * DH + (((2 * d + (pp >> 1)) ^ r15) << 3) + 4 * (pp & 1);
   for (int kt = 0; kt < n_tiles; ++kt) {
     const int buf = kt & 1, k0 = kt * AK;
     if (kt + 1 < n_tiles) dma(buf ^ 1, kt + 1);                              // lands under this tile's MFMAs
@@ -106,8 +118,7 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int row = t * 16 + l15;
-        const bf16x8 kf = *(const bf16x8*)(cK + row * DH + (((ks * 4 + g) ^ (row & (SW - 1))) << 3));
+        const bf16x8 kf = *(const bf16x8*)(cK + kbase[ks] + t * 16 * DH);
 #pragma unroll
         for (int u = 0; u < QG; ++u) st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], st[u][t], 0, 0, 0);
       }
@@ -128,9 +139,13 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
         }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[u], mx);
+      // deferred rescale: the running reference maximum only moves when the tile's maximum exceeds it by more than 8 (for some
+      // query of the wave), so exp(s - m) stays below e^8 and the O / l rescale (128 accumulator registers through the VALU) is
+      // rare instead of once per tile; the result is the same softmax (any reference point cancels in O / l)
+      const bool bump = __any(mx > m_run[u] + 8.0f) || m_run[u] == -INFINITY;
+      const float m_new = bump ? fmaxf(m_run[u], mx) : m_run[u];
       const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __expf(m_run[u] - msafe);
+      const float alpha = bump ? __expf(m_run[u] - msafe) : 1.0f;
       float rs = 0.f;
       unsigned pw[2][4];
 #pragma unroll
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
       rs += __shfl_xor(rs, 32, 64);
       l_run[u] = l_run[u] * alpha + rs;
       m_run[u] = m_new;
-      if (__any(alpha != 1.0f)) {                                            // the running maximum moved for some query of the wave
+      if (bump) {                                                            // wave-uniform
 #pragma unroll
         for (int d = 0; d < DT; ++d) { o[u][d][0] *= alpha; o[u][d][1] *= alpha; o[u][d][2] *= alpha; o[u][d][3] *= alpha; }
       }
@@ -163,12 +178,14 @@ __global__ __launch_bounds__(256, 1) void flash_attention_v2_kernel(
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int ra = 32 * s2 + 4 * g + qp, rb = ra + 16;                   // rb & (SW-1) == ra & (SW-1)
-        const int cc = (((2 * dt + (pp >> 1)) ^ (ra & (SW - 1))) << 3) + 4 * (pp & 1);
+        // rows 32 s + 4 g + qp and + 16 (same swizzle key: both = 4 g + qp mod 16); dt >= 8 is 16 chunks = 128 elements further
+        const int off = vbase[dt & (NVB - 1)] + (dt >= NVB ? 128 : 0) + 32 * s2 * DH;
         typedef __attribute__((address_space(3))) v4s_t* lds_v4s;
-        const v4s_t ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + ra * DH + cc));
-        const v4s_t tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + rb * DH + cc));
-        const bf16x8 vf = {ta[0], ta[1], ta[2], ta[3], tb[0], tb[1], tb[2], tb[3]};
+        const v4s_t ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + off));
+        const v4s_t tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s)(cV + off + 16 * DH));
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t ua = __builtin_bit_cast(u32x2_t, ta), ub = __builtin_bit_cast(u32x2_t, tb);      // register concatenation, no ALU
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, (u32x4){ua[0], ua[1], ub[0], ub[1]});
 #pragma unroll
         for (int u = 0; u < QG; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[u][s2], o[u][dt], 0, 0, 0);
       }

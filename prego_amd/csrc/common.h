@@ -24,8 +24,11 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
 __device__ __forceinline__ float bf2f(bf16_t b) {
   return __builtin_bit_cast(float, (unsigned)b << 16);
 }
+// two floats -> packed bf16x2 as ONE v_cvt_pk_bf16_f32 (the scalar form is two converts + an or_sdwa); same RNE rounding
+typedef __bf16 bf16x2_v_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_v_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_v_){lo, hi}, bf16x2_v_));
 }
 
 // streaming (read-once) 16-byte load
