@@ -114,10 +114,14 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   const int place = __builtin_amdgcn_readfirstlane(s_place[2]);
   if (place < 0) return;                      // rendezvous timed out (abort word set)
   const bool local = place == 1;              // whole group on one XCD, verified
-  if (g * 16 >= a.n_clips) return;            // group without slots
+  // Slots are dealt to the groups INTERLEAVED: slot s of a layer of 16 G slots goes to group s % G, column s / G of its tile.
+  // The slots are sorted by load, so every group gets a cross-section of the loads and its live columns thin out over the
+  // whole run (instead of group 0 holding the 16 longest slots to the end): the per-step gather below skips dead columns, so
+  // the 1 MB-per-step L2 burst of an XCD - what bounds the hand-off - shrinks with the number of live clips.
+  if (g >= a.n_clips) return;                 // group without slots (its most loaded slot is slot g)
   {                                           // group whose slots have all ended before this launch (nact never grows)
     typedef const __attribute__((address_space(4))) int* cint_p0;
-    if (g * 16 >= ((cint_p0)a.nact)[a.t0]) return;
+    if (g >= ((cint_p0)a.nact)[a.t0]) return;
   }
   const int l15 = lane & 15, l4 = lane >> 4;
 
@@ -153,8 +157,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   for (int e = 0; e < OWN_R; ++e) bhn[e] = a.b_hn[ucol + e];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    sidx[ct] = ct * 16 * a.G + g * 16 + l15;
-    tfirst[ct] = ct * 16 * a.G + g * 16;
+    sidx[ct] = ct * 16 * a.G + l15 * a.G + g;
+    tfirst[ct] = ct * 16 * a.G + g;
 #pragma unroll
     for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = (sidx[ct] < a.n_clips) ? a.h_state[(size_t)sidx[ct] * HID + ucol + e] : 0.f;
   }
@@ -285,14 +289,18 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         u32x4 hb[NKS];
         unsigned spins = 0;
+        // a lane's 16 bytes of a fragment belong to ONE clip column (lane & 15): columns whose slot has ended are not fetched
+        // (an offset past the buffer's num_records returns zeros without a memory access) and never count as stale
+        const bool col_live = sidx[ct] < na;
+        const int lane_off = col_live ? lane * 16 : 0x7FFF0000;
         if (local) {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_NT);
         } else {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_SC1);
         }
 #pragma unroll
         for (int sg = 0; sg < NSEG; ++sg) {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 #pragma unroll
             for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks)
               badv |= ((hb[ks][0] ^ eword) | (hb[ks][1] ^ eword)) | ((hb[ks][2] ^ eword) | (hb[ks][3] ^ eword));   // tag bit survives iff stale
-            return !__all((badv & TAGM) == 0u);
+            return !__all(!col_live || (badv & TAGM) == 0u);
           };
           if (seg_stale()) {
             for (;;) {
@@ -315,11 +323,11 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               if (local && spins < 6u) {
 #pragma unroll
                 for (int ks = sg * SEGK; ks < NKS; ++ks)
-                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_NT);
               } else {
 #pragma unroll
                 for (int ks = sg * SEGK; ks < NKS; ++ks)
-                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+                  hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * GRU_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_SC1);
               }
               if (!seg_stale()) break;
             }
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         }
         // ---- (4) publish h_t of this tile for step t+1 (fire and forget)
         const bool restart = (t + 1 == nstart[ct]);          // the slot's next clip begins at step t+1: it sees h = 0
-        if (more && tfirst[ct] < na_n) publish(ct, tl & 1, (unsigned)((tl >> 1) & 1), restart);
+        if (more && sidx[ct] < na_n) publish(ct, tl & 1, (unsigned)((tl >> 1) & 1), restart);   // dead columns are never read
         STAMP(3);
         // ---- (5) outputs
         if (sidx[ct] < na) {
