@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = blockIdx.x % a.G, w = blockIdx.x / a.G;
-  if (g * 16 >= a.n_clips) return;            // group without clips
+  // clips are dealt to the groups interleaved (clip s of a layer of 16 G -> group s % G, column s / G), as in the forward
+  // recurrence: a train.py batch of 16 windows then runs as 2 columns on each of the 8 XCDs instead of 16 columns on one, and
+  // the gather below fetches live columns only, so an XCD's L2 serves 1/8 of the 96 KB-per-CU dGH burst
+  if (g >= a.n_clips) return;                 // group without clips
   const int l15 = lane & 15, l4 = lane >> 4;
   // ---- placement: does the whole group sit on one XCD? (sync[16+g] = XCC id mask, sync[32+g] = arrivals) ----------------
   __shared__ int s_local;
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
   float carry[NCT][OWN_R];                    // dh_{t+1} * z_{t+1} of my (unit, clip) pairs
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    sidx[ct] = ct * 16 * a.G + g * 16 + l15;
-    tfirst[ct] = ct * 16 * a.G + g * 16;
+    sidx[ct] = ct * 16 * a.G + l15 * a.G + g;
+    tfirst[ct] = ct * 16 * a.G + g;
 #pragma unroll
     for (int e = 0; e < OWN_R; ++e) carry[ct][e] = 0.f;
   }
@@ -174,14 +177,17 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         // all of the wave's fragments in flight first (one L2 round trip, not NKS of them), then the products
         u32x4 hb[NKS];
+        // a lane's 16 bytes belong to ONE clip column (lane & 15): columns that were not alive at step t+1 published nothing
+        // and are not fetched (an offset past num_records returns zeros without a memory access)
+        const int lane_off = sidx[ct] < na_next ? lane * 16 : 0x7FFF0000;
         if (local) {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_NT);
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_NT);
         } else {
 #pragma unroll
           for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane * 16, 0, AUX_SC1);
+            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_SC1);
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
