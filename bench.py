@@ -300,6 +300,27 @@ def secondary(dev, lens, sd):
                          "ms": ms, "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
                                                 "note": "3 x forward FLOPs over the whole step; 128 sequential BPTT steps: latency-bound"}}
+    # ---- BASELINE configs[0] shape and the streaming mode (f4): 1 clip x 256 frames in one call, and frame-by-frame with the GRU
+    # state carried by the caller (h_last -> h0), the online-detector use the reference never exposes
+    m.eval()
+    eng = m.engine()
+    one = torch.randn(256, 2048, device=dev).clamp_(min=0)
+    ms = _time_ms(lambda: eng.forward_ragged([one], None, softmax=True, want_out=True, want_argmax=True), n=20)
+    res["clip256_ms"] = ms
+    frames = [one[i:i + 1].contiguous() for i in range(64)]
+    state = {"h": None}
+
+    def stream64():
+        h = None
+        for f in frames:
+            _, _, h = eng.forward_ragged([f], None, softmax=True, want_out=True, want_argmax=True, h0=h, want_h_last=True)
+        state["h"] = h
+    ms = _time_ms(stream64, n=5, warm=2)
+    eng.check()
+    res["stream_step_us"] = ms * 1e3 / 64
+    res["latency"] = {"clip256_ms": res["clip256_ms"], "stream_step_us": res["stream_step_us"],
+                      "note": "one 256-frame clip per call (zero flow): 256 sequential recurrence steps; streaming: one frame per "
+                              "call, 6 kernel launches + host call overhead per frame, state through h_last -> h0"}
     del m, opt, crit
     # ---- ViTEnc forward (a11, a13, a14)
     vcfg = assembly101_cfg(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0)
