@@ -83,6 +83,7 @@ struct SlotPlan {
   const int* seg_off;     // [n_slots + 1]
   const int* seg_clip;    // [n_clips] caller's clip index
   const int* seg_start;   // [n_clips] first step of the segment
+  const int* blk_step;    // [ceil(rows / 32)] step of packed row 32 b (row -> step without a binary search: head kernel)
   int s_max;
   int n_slots;
 };

@@ -9,6 +9,7 @@
 // HBM-bound on reading relu(h) (2 KB/row in bf16).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define HM 4      // 16-row tiles per wave
 template <typename WT, int NTC>
@@ -152,11 +153,200 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// v2 (bf16, C <= 96): W_c never leaves the register file and the frames ride on the MFMA lane.
+//   logits^T[class, frame] = W_c[class, k] . relu(h)^T[k, frame]:  A = W_c fragments (register resident: wave q keeps the K-quarter
+//   [256 q, 256 q + 256) of all NTC class tiles = 32 NTC VGPRs), B = relu(h) rows read straight from HBM (a lane's 16 bytes are
+//   8 consecutive k of ONE frame: no LDS, no re-layout).  The round-1 kernel re-read W_c from L2 for every 64 rows (3 KB of L2
+//   traffic per row beside the 2 KB of HBM) in a K loop of 32 dependent round trips.
+// A workgroup is persistent over blocks of 32 frames (two 16-frame tiles); per block a wave loads its 16 fragments, runs 16 NTC
+// MFMAs, and the four K-quarter partials meet in LDS (double buffered: one barrier per block); the NEXT block's fragments are
+// already in flight during all of that.  Waves 0 and 1 then own one frame tile each: with the classes in the accumulator
+// registers and the frame on the lane, softmax / argmax are in-register over 4 NTC values + two shuffles, and the
+// probabilities leave as 16-byte stores of four consecutive classes.  The partials are added in K order (bit-reproducible).
+// ------------------------------------------------------------------------------------------------------
+template <int NTC>
+__global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
+    const bf16_t* __restrict__ Hrelu, const bf16_t* __restrict__ Wc, const float* __restrict__ bc, SlotPlan plan, int row0,
+    int nrows, int C, int apply_softmax, float* const* __restrict__ out_ptrs, int* const* __restrict__ argmax_ptrs,
+    const int2* __restrict__ rowmap /*nullable: (clip, frame) of every row of this chunk, written by the pack kernel*/) {
+  constexpr int HID = 1024, KS = 8;                  // k-steps of 32 per K-quarter
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* part = (f32x4*)smem;                        // [2 parities][4 src waves][2 frame tiles][NTC][64 lanes]
+  constexpr int PSTRIDE = 4 * 2 * NTC * 64;
+  const int lane = threadIdx.x & 63, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, g = lane >> 4;
+  // resident W_c fragments: A operand, row = class 16 j + l15, k = 256 q + 32 ks + 8 g
+  bf16x8 wc[NTC][KS];
+#pragma unroll
+  for (int j = 0; j < NTC; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) wc[j][ks] = *(const bf16x8*)(Wc + (size_t)(j * 16 + l15) * HID + q * 256 + ks * 32 + 8 * g);
+  float bias[NTC][4];                                // class 16 j + 4 g + e
+#pragma unroll
+  for (int j = 0; j < NTC; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[j][e] = bc[j * 16 + 4 * g + e];
+
+  const int nblk = (nrows + 31) / 32;
+  // plan tables as plain pointers (the SlotPlan struct passed by reference would live in scratch)
+  const int* __restrict__ p_rowoff = plan.rowoff; const int* __restrict__ p_seg_off = plan.seg_off;
+  const int* __restrict__ p_seg_clip = plan.seg_clip; const int* __restrict__ p_seg_start = plan.seg_start;
+  const int* __restrict__ p_blk = plan.blk_step;
+  const int s_max = plan.s_max;
+  bf16x8 cur[2][KS], nxt[2][KS];
+#define HEAD_LOAD(DST, BLK)                                                                                             \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+      int r_ = (BLK) * 32 + t * 16 + l15; if (r_ > nrows - 1) r_ = nrows - 1;                                           \
+      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                               \
+        const u32x4 v_ = __builtin_nontemporal_load((const u32x4*)(Hrelu + (size_t)r_ * HID + q * 256 + ks * 32 + 8 * g)); \
+        DST[t][ks] = __builtin_bit_cast(bf16x8, v_);                                                                    \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  } while (0)
+  int blk = blockIdx.x;
+  if (blk < nblk) HEAD_LOAD(cur, blk);
+  int parity = 0;
+  for (; blk < nblk; blk += gridDim.x) {
+    const int bn = blk + gridDim.x;
+    if (bn < nblk) HEAD_LOAD(nxt, bn);                                        // in flight under this block
+    // destination of my frame (waves 0 / 1 own frame tile q; every lane looks its frame l15 up: 4x redundant, off the MFMA path)
+    float* op = nullptr; int* ap = nullptr;
+    const int myrow = blk * 32 + q * 16 + l15;
+    if (q < 2 && myrow < nrows && rowmap != nullptr) {
+      const int2 ct = rowmap[myrow];
+      op = out_ptrs ? out_ptrs[ct.x] : nullptr;
+      if (op) op += (size_t)ct.y * C;
+      ap = argmax_ptrs ? argmax_ptrs[ct.x] : nullptr;
+      if (ap) ap += ct.y;
+    } else if (q < 2 && myrow < nrows) {
+      const int row = row0 + myrow;
+      // largest step with rowoff[step] <= row: start at the tabulated step of row 32 * (row / 32) and walk forward (a step holds
+      // >= 1 row, typically 128: zero or one hop) - a binary search over the 34 k steps was ~16 dependent L2 round trips per block
+      int lo = p_blk[row >> 5];
+      while (lo + 1 < s_max && p_rowoff[lo + 1] <= row) ++lo;
+      const int slot = row - p_rowoff[lo];
+      int k = p_seg_off[slot];
+      const int kend = p_seg_off[slot + 1];
+      while (k + 1 < kend && p_seg_start[k + 1] <= lo) ++k;
+      const int clip = p_seg_clip[k], t = lo - p_seg_start[k];
+      op = out_ptrs ? out_ptrs[clip] : nullptr;
+      if (op) op += (size_t)t * C;
+      ap = argmax_ptrs ? argmax_ptrs[clip] : nullptr;
+      if (ap) ap += t;
+    }
+    f32x4 acc[2][NTC];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[j][ks], cur[t][ks], acc[t][j], 0, 0, 0);
+    // K-quarter partials -> LDS (a wave keeps the partial of the frame tile it finishes itself)
+    f32x4* pw = part + parity * PSTRIDE;
+    if (q != 0) {
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) pw[((q * 2 + 0) * NTC + j) * 64 + lane] = acc[0][j];
+    }
+    if (q != 1) {
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) pw[((q * 2 + 1) * NTC + j) * 64 + lane] = acc[1][j];
+    }
+    __syncthreads();
+    if (q < 2) {
+      float v[NTC][4];
+#pragma unroll
+      for (int j = 0; j < NTC; ++j) {
+        const f32x4 mine = q == 0 ? acc[0][j] : acc[1][j];                    // value select: no runtime register indexing
+        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {                                   // K order 0..3, own partial from registers
+          const f32x4 p = (src == q) ? mine : pw[((src * 2 + q) * NTC + j) * 64 + lane];
+          sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+        }
+        v[j][0] = sum[0] + bias[j][0]; v[j][1] = sum[1] + bias[j][1]; v[j][2] = sum[2] + bias[j][2]; v[j][3] = sum[3] + bias[j][3];
+      }
+      // softmax / argmax over the classes of my frame: in-lane over (j, e), then across the four k-groups g
+      float mx = -INFINITY; int mi = 0x7fffffff;
+#pragma unroll
+      for (int j = 0; j < NTC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = j * 16 + 4 * g + e;
+          if (c < C && v[j][e] > mx) { mx = v[j][e]; mi = c; }                 // ascending c inside the lane: first max wins
+        }
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float omx = __shfl_xor(mx, o, 64);
+        const int omi = __shfl_xor(mi, o, 64);
+        if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+      }
+      if (apply_softmax) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = j * 16 + 4 * g + e;
+            v[j][e] = c < C ? __expf(v[j][e] - mx) : 0.f;
+            sm += v[j][e];
+          }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.0f / sm;
+#pragma unroll
+        for (int j = 0; j < NTC; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] *= inv;
+      }
+      if (op) {
+#pragma unroll
+        for (int j = 0; j < NTC; ++j) {
+          const int c = j * 16 + 4 * g;
+          if (c + 3 < C && ((C & 3) == 0)) *(float4*)(op + c) = make_float4(v[j][0], v[j][1], v[j][2], v[j][3]);   // rows are 16-byte aligned iff C % 4 == 0
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c + e < C) op[c + e] = v[j][e];
+          }
+        }
+      }
+      if (ap && g == 0) *ap = mi;
+    }
+    parity ^= 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) cur[t][ks] = nxt[t][ks];
+  }
+#undef HEAD_LOAD
+}
+
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
                         int row0, int nrows, int hid, int C, int apply_softmax,
-                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s) {
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap) {
   if (nrows <= 0) return 0;
   const int ntc = (C + 15) / 16;
+  static const bool no_v2 = getenv("PREGO_HEAD_V1") != nullptr;                // A/B knob
+  if (bf16 && hid == 1024 && ntc <= 6 && !no_v2) {     // the register-resident form, for EVERY size: a row's result must not depend on the batch
+    const int nblk = (nrows + 31) / 32;
+    const int grid2 = nblk < 256 ? nblk : 256;
+#define HV2(N)                                                                                                      \
+  case N: {                                                                                                         \
+    const size_t lds = (size_t)2 * 4 * 2 * N * 64 * 16;                                                             \
+    static DeviceOnce once;                                                                                         \
+    once.run([&] { (void)hipFuncSetAttribute((const void*)head_softmax_v2_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+    head_softmax_v2_kernel<N><<<grid2, 256, lds, s>>>((const bf16_t*)Hrelu, (const bf16_t*)Wc, bc, plan, row0, nrows, C,  \
+                                                      apply_softmax, out_ptrs, argmax_ptrs, (const int2*)rowmap);    \
+    return 0;                                                                                                       \
+  }
+    switch (ntc) { HV2(1) HV2(2) HV2(3) HV2(4) HV2(5) HV2(6) default: break; }
+#undef HV2
+  }
   const int grid = (nrows + 64 * HM - 1) / (64 * HM);
 #define HL(WT, N)                                                                                             \
   head_softmax_kernel<WT, N><<<grid, 256, 0, s>>>((const WT*)Hrelu, (const WT*)Wc, bc, plan, row0, nrows,     \

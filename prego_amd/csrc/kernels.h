@@ -24,7 +24,7 @@ struct DeviceOnce {
 // host-visible copy of the slot schedule descriptor (layout identical to common.h's SlotPlan)
 #ifndef PREGO_HAVE_SLOTPLAN
 struct SlotPlan {
-  const int* rowoff; const int* nact; const int* seg_off; const int* seg_clip; const int* seg_start;
+  const int* rowoff; const int* nact; const int* seg_off; const int* seg_clip; const int* seg_start; const int* blk_step;
   int s_max; int n_slots;
 };
 #define PREGO_HAVE_SLOTPLAN 1
@@ -91,7 +91,8 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
                              int N, int K, GemmEpi epi, hipStream_t s);
 
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0);
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0,
+                      void* rowmap = nullptr /* int2 [nrows]: (clip, frame) of every packed row, for the head kernel */);
 void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
                     bool in_bf16 = false);
@@ -114,7 +115,7 @@ size_t gru_hx_bytes(bool bf16, int hid, int G);
 int gru_max_tiles();
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
                         int row0, int nrows, int hid, int C, int apply_softmax,
-                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s);
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap = nullptr);
 void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
                          hipStream_t s);
 void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s);

@@ -83,6 +83,8 @@ struct prego_miniroad {
   std::vector<int32_t> plan_lens;
   std::vector<int> h_rowoff, h_nact, h_sorted;      // h_sorted: first clip of each slot (slot order)
   std::vector<int> h_seg_off, h_seg_clip, h_seg_start;
+  std::vector<int> h_blkstep;    // step of packed row 32 b
+  int* d_blkstep = nullptr; size_t cap_b = 0;
   int n_slots = 0;
   bool plan_single = true;       // one clip per slot (required for h0 / h_last / training)
   bool plan_want_single = false;
@@ -166,7 +168,9 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->d_rowoff, h->cap_t * 4); A((void**)&h->d_nact, h->cap_t * 4);
   A((void**)&h->d_sorted, h->cap_c * 4); A((void**)&h->d_seg_off, (h->cap_c + 1) * 4);
   A((void**)&h->d_seg_clip, h->cap_c * 4); A((void**)&h->d_seg_start, h->cap_c * 4);
-  h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + 1024;
+  h->cap_b = (size_t)1 << 19;                    // 16.7 M packed rows per call before the table has to grow
+  A((void**)&h->d_blkstep, h->cap_b * 4);
+  h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + h->cap_b * 4 + 1024;
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
   h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
@@ -190,7 +194,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
@@ -317,6 +321,16 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   for (int t = smax; t >= 1; --t) { alive += cnt[t]; h->h_nact[t - 1] = alive; }
   h->h_rowoff.assign((size_t)smax + 1, 0);
   for (int t = 0; t < smax; ++t) h->h_rowoff[t + 1] = h->h_rowoff[t] + h->h_nact[t];
+  {                                  // step of every 32nd packed row (the head kernel's row -> step lookup starts there)
+    const int total = h->h_rowoff[smax];
+    h->h_blkstep.assign((size_t)(total + 31) / 32, 0);
+    int st = 0;
+    for (size_t b = 0; b < h->h_blkstep.size(); ++b) {
+      const int row = (int)b * 32;
+      while (st + 1 < smax && h->h_rowoff[st + 1] <= row) ++st;
+      h->h_blkstep[b] = st;
+    }
+  }
   h->plan_dirty = true;              // device copies are staged by the caller (stage_tables)
   h->t_max = smax;
   h->n_slots = S;
@@ -329,6 +343,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
 static SlotPlan device_plan(const prego_miniroad* h) {
   SlotPlan p;
   p.rowoff = h->d_rowoff; p.nact = h->d_nact; p.seg_off = h->d_seg_off; p.seg_clip = h->d_seg_clip; p.seg_start = h->d_seg_start;
+  p.blk_step = h->d_blkstep;
   p.s_max = h->t_max; p.n_slots = h->n_slots;
   return p;
 }
@@ -338,7 +353,8 @@ static SlotPlan device_plan(const prego_miniroad* h) {
 static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_count, hipStream_t s) {
   if (h->pin_busy) { HIPCHK(hipEventSynchronize(h->pin_ev)); h->pin_busy = false; }
   const size_t smax = (size_t)h->t_max, S = (size_t)h->n_slots, n = h->h_seg_clip.size();
-  if (h->plan_dirty && (smax + 1 > h->cap_t || n + 1 > h->cap_c)) {
+  const size_t nb = h->h_blkstep.size();
+  if (h->plan_dirty && (smax + 1 > h->cap_t || n + 1 > h->cap_c || nb > h->cap_b)) {
     // a clip longer than the tables reserved at create (or more clips): grow once, outside the steady state
     HIPCHK(hipStreamSynchronize(s));
     if (smax + 1 > h->cap_t) {
@@ -352,9 +368,14 @@ static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_c
       HIPCHK(hipMalloc((void**)&h->d_sorted, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_off, (h->cap_c + 1) * 4));
       HIPCHK(hipMalloc((void**)&h->d_seg_clip, h->cap_c * 4)); HIPCHK(hipMalloc((void**)&h->d_seg_start, h->cap_c * 4));
     }
+    if (nb > h->cap_b) {
+      (void)hipFree(h->d_blkstep);
+      h->cap_b = nb + 4096;
+      HIPCHK(hipMalloc((void**)&h->d_blkstep, h->cap_b * 4));
+    }
     (void)hipHostFree(h->pin);
     h->pin = nullptr;
-    h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + 1024;
+    h->pin_bytes = (size_t)4 * max_clips_of(h) * sizeof(void*) + 2 * h->cap_t * 4 + 4 * (h->cap_c + 1) * 4 + h->cap_b * 4 + 1024;
     HIPCHK(hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault));
   }
   char* p = h->pin;
@@ -372,6 +393,7 @@ static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_c
     HIPCHK(put(h->d_seg_off, h->h_seg_off.data(), (S + 1) * 4));
     HIPCHK(put(h->d_seg_clip, h->h_seg_clip.data(), n * 4));
     HIPCHK(put(h->d_seg_start, h->h_seg_start.data(), n * 4));
+    HIPCHK(put(h->d_blkstep, h->h_blkstep.data(), nb * 4));
     h->plan_dirty = false;
   }
   HIPCHK(hipEventRecord(h->pin_ev, s));
@@ -379,7 +401,7 @@ static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_c
   return PREGO_OK;
 }
 
-struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, total; };
+struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, map, total; };
 // bf16 mode, inference (no PREGO_FWD_KEEP): the two projections' outputs stay bf16 between the kernels (what a bf16 autocast
 // of the reference does too).  They are the largest HBM streams of the pass (20 KB per frame in fp32) and the store tail of a
 // GEMM tile is bound by bytes: with fp32 C the projections run 1.23 / 1.10 PFLOP/s (K = 4096 / 2048), without any C store 1.41 /
@@ -402,7 +424,8 @@ static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
   r.hraw = keep ? (size_t)h->hid * 4 : 0;
   r.gates = keep ? (size_t)h->hid * 4 * 4 : 0;      // r, z, n, W_hn h + b_hn
   r.stats = keep ? 8 : 0;                           // LayerNorm mean, rstd
-  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw + r.gates + r.stats;
+  r.map = 16;                                       // row -> (clip, frame) for the head's scatter, two chunks deep
+  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw + r.gates + r.stats + r.map;
   return r;
 }
 
@@ -511,6 +534,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     h->kept_kx = kx; h->kept_rows = total_rows;
   }
 
+  char* RM = (char*)carve((size_t)cap_rows * rb.map);        // [2][cap_rows] int2: chunk c uses half c & 1 (the pack of chunk c+1
+                                                             // runs under the recurrence of chunk c, before the head of chunk c)
   // initial state (sorted order)
   const int H = h->hid, E = h->emb;
   if (h0) launch_permute_rows(h0, h->h_state, h->d_sorted, n_slots, H, 1, s);        // one clip per slot here
@@ -528,23 +553,23 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     if (t1_ > h->t_max) t1_ = h->t_max;
     return t1_;
   };
-  auto pack_chunk = [&](int t0_, int t1_, hipStream_t st) {
+  auto pack_chunk = [&](int t0_, int t1_, hipStream_t st, int ci_) {
     const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
     EventPair* evp = ev_begin(h, 2, st);
     launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
-                     st == s ? 0 : h->prefetch_grid);
+                     st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8);
     ev_end(evp, st);
     if (h->timing) h->pack_bytes += (double)rows_ * (kx * 4.0 + rb.x);
   };
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
-  int t0 = 0;
+  int t0 = 0, ci = 0;             // ci: chunk counter (parity of the row-map half)
   while (t0 < h->t_max) {
     const int base = h->h_rowoff[t0];
     const int t1 = chunk_end(t0);
     const int rows = h->h_rowoff[t1] - base;
     EventPair* ev;
-    if (!packed) pack_chunk(t0, t1, s);
+    if (!packed) pack_chunk(t0, t1, s, ci);
     packed = false;
 
     ev = ev_begin(h, 0, s);
@@ -574,18 +599,19 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       // (latency-bound, one wave per SIMD) holds the CUs.  The recurrence is launched FIRST so that its 256 workgroups are
       // resident (placement rendezvous) before the copy's workgroups fill the wave slots
       HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      pack_chunk(t1, chunk_end(t1), h->side);
+      pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
       HIPCHK(hipEventRecord(h->ev_join, h->side));
       packed = true;
     }
 
     if (out || argmax) {
       if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, plan, base, rows, H, h->ncls,
-                              (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s))
+                              (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s, RM + (size_t)(ci & 1) * cap_rows * 8))
         return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
     }
     if (packed) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
     t0 = t1;
+    ++ci;
   }
   if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
   HIPCHK(hipGetLastError());

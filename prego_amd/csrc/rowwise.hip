@@ -12,12 +12,15 @@
 template <typename OutT>
 __global__ __launch_bounds__(256) void pack_rows_kernel(
     const float* const* __restrict__ rgb_ptrs, const float* const* __restrict__ flow_ptrs, SlotPlan plan,
-    int row0, int nrows, int d_rgb, int d_flow, OutT* __restrict__ X) {
+    int row0, int nrows, int d_rgb, int d_flow, OutT* __restrict__ X, int2* __restrict__ rowmap /*nullable: [nrows] (clip, frame)*/) {
   const int din = d_rgb + d_flow;
   for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
     const int row = row0 + r;
     int clip, t;
     plan_clip_of_row(plan, row, clip, t);
+    // the row -> (clip, frame) map this kernel had to compute anyway, kept for the head kernel's scatter (8 B per row instead of
+    // a chain of dependent table look-ups per row there)
+    if (rowmap != nullptr && threadIdx.x == 0) rowmap[r] = make_int2(clip, t);
     const float* rgb = rgb_ptrs ? rgb_ptrs[clip] : nullptr;
     const float* flow = flow_ptrs ? flow_ptrs[clip] : nullptr;   // nullptr = all-zero flow half
     OutT* dst = X + (size_t)r * din;
@@ -142,14 +145,14 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
 // grid_limit > 0: at most that many workgroups (each walks rows at a stride): a THROTTLED stream for the copy that runs beside
 // the latency-bound recurrence (fewer loads in flight per CU = less queueing in front of the recurrence's gather)
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit) {
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap) {
   if (nrows <= 0) return;
   int grid = nrows < 65536 ? nrows : 65536;
   if (grid_limit > 0 && grid > grid_limit) grid = grid_limit;
   if (bf16)
-    pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X);
+    pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X, (int2*)rowmap);
   else
-    pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X);
+    pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X, (int2*)rowmap);
 }
 
 void launch_ln_relu(bool bf16, const void* Yv, const float* gamma, const float* beta, int nrows, int E, float eps, void* out,
