@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -699,21 +700,35 @@ extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* con
   if (!lens || !logits || !target || !loss_out) return fail(PREGO_EINVAL, "loss: NULL argument");
   if (n_clips <= 0 || n_clips > LOSS_MAX_CLIPS) return fail(PREGO_EINVAL, "loss: %d clips (max %d)", n_clips, LOSS_MAX_CLIPS);
   if (n_classes <= 0 || n_classes > 128) return fail(PREGO_EINVAL, "loss: num_classes %d must be in 1..128", n_classes);
-  static void* scratch[64] = {nullptr};
+  // per-device scratch of this handle-free op: device pointer tables + a PINNED host staging copy fenced by an event (the
+  // async H2D copy reads the staging buffer after this call has returned, so it is neither a stack nor a pageable buffer)
+  struct LossScratch { void* dev = nullptr; void* pin = nullptr; hipEvent_t ev = nullptr; bool busy = false; };
+  static LossScratch scratch[64];
+  static std::mutex scratch_mu;
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return fail(PREGO_EINVAL, "device %d", dev);
   const size_t MC = LOSS_MAX_CLIPS;
-  if (!scratch[dev]) HIPCHK(hipMalloc(&scratch[dev], 4 * MC * sizeof(void*)));
-  void** d = (void**)scratch[dev];
+  std::lock_guard<std::mutex> guard(scratch_mu);
+  LossScratch& sc = scratch[dev];
+  if (!sc.dev) {
+    HIPCHK(hipMalloc(&sc.dev, 4 * MC * sizeof(void*)));
+    HIPCHK(hipHostMalloc(&sc.pin, 4 * MC * sizeof(void*), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming));
+  }
+  if (sc.busy) { HIPCHK(hipEventSynchronize(sc.ev)); sc.busy = false; }
+  void** d = (void**)sc.dev;
   hipStream_t s = (hipStream_t)stream;
-  std::vector<const void*> tab(4 * MC, nullptr);
+  const void** tab = (const void**)sc.pin;
   for (int i = 0; i < n_clips; ++i) {
     if (lens[i] <= 0 || !logits[i] || !target[i]) return fail(PREGO_EINVAL, "loss: clip %d", i);
     tab[0 * MC + i] = logits[i]; tab[1 * MC + i] = target[i]; tab[2 * MC + i] = dlogits ? dlogits[i] : nullptr;
   }
   std::memcpy(&tab[3 * MC], lens, (size_t)n_clips * 4);        // 4th table doubles as the lens array
-  HIPCHK(hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, s));
+  for (int k = 0; k < 4; ++k)                                  // only the used prefix of each table travels
+    HIPCHK(hipMemcpyAsync(d + k * MC, tab + k * MC, (size_t)n_clips * sizeof(void*), hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(sc.ev, s));
+  sc.busy = true;
   launch_oad_loss((const float* const*)d, (const float* const*)(d + MC), (const int*)(d + 3 * MC), n_clips, n_classes,
                   loss_out, dlogits ? (float* const*)(d + 2 * MC) : nullptr, grad_scale, s);
   HIPCHK(hipGetLastError());
