@@ -43,9 +43,13 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  // causal: the linear workgroup id (handed to the XCDs round-robin) is split as (rank of the block by work, bh): heaviest blocks
+  // first, the same mix of heavy and light blocks on every XCD (see flash_attention_v2_kernel)
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y, n_bh = (int)gridDim.y;
+  const int bh = causal ? lin % n_bh : (int)blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int blk = !causal ? (int)blockIdx.x : (BYKEY ? lin / n_bh : (int)gridDim.x - 1 - lin / n_bh);
   const int E = heads * DH;
-  const int own = blockIdx.x * 64 + wave * 16 + l15;            // my key (BYKEY) / my query
+  const int own = blk * 64 + wave * 16 + l15;                   // my key (BYKEY) / my query
   const int own_ld = own < N ? own : N - 1;
   const size_t hbase = (size_t)bh * N * DH;                     // [B,h,N,DH] tensors
   const size_t abase = (size_t)b * N * E + (size_t)hd * DH;     // [B,N,E] tensors, this head's columns
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
   }
 
   // swept range: causal -> a key only meets queries >= key, a query only keys <= query
-  const int blk_lo = blockIdx.x * 64, blk_hi = blk_lo + 63;
+  const int blk_lo = blk * 64, blk_hi = blk_lo + 63;
   const int n_tiles = (N + BQ - 1) / BQ;
   const int t_begin = (causal && BYKEY) ? blk_lo / BQ : 0;
   const int t_end = (causal && !BYKEY) ? ((blk_hi < N - 1 ? blk_hi : N - 1) / BQ + 1) : n_tiles;
