@@ -235,6 +235,13 @@ int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float
 int prego_debug_attention_bwd(int batch, int len, int heads, int dh, int causal, const void* qs, const void* k, const void* v,
                               const void* o, const void* dout, const float* lse, void* dqkv, prego_stream_t stream);
 
+/* Debug / unit test only: the attention forward kernel alone (every head-dim / shape variant is reachable from here).
+ * qs (= q * dh^-0.5): device bf16 [batch, heads, n_query, dh], queries at sequence positions 0 .. n_query-1; k, v: device bf16
+ * [batch, heads, len, dh]; out: device bf16 [batch, n_query, heads*dh]; lse: device fp32 [batch, heads, n_query] or NULL.
+ * Synchronises the stream. */
+int prego_debug_attention_fwd(int batch, int n_query, int len, int heads, int dh, int causal, const void* qs, const void* k,
+                              const void* v, void* out, float* lse, prego_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

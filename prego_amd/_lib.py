@@ -29,7 +29,7 @@ SYMBOLS = [
     "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
-    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd",
+    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
 ]
 
 
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_handle_workspace_bytes.restype = sz
     lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.prego_debug_attention_bwd.argtypes = [i32] * 5 + [vp] * 7 + [vp]
+    lib.prego_debug_attention_fwd.argtypes = [i32] * 6 + [vp] * 5 + [vp]
     lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:          # fail loudly at load time if the library is stale
         getattr(lib, name)

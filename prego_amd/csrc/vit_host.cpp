@@ -420,6 +420,18 @@ extern "C" int prego_debug_attention_bwd(int batch, int len, int heads, int dh, 
   return PREGO_OK;
 }
 
+// debug / unit test: the attention forward kernel alone (tests/test_gpu_transformer.py)
+extern "C" int prego_debug_attention_fwd(int batch, int n_query, int len, int heads, int dh, int causal, const void* qs, const void* k,
+                                         const void* v, void* out, float* lse, prego_stream_t stream) {
+  if (!qs || !k || !v || !out || batch <= 0 || len <= 0 || heads <= 0 || n_query <= 0 || n_query > len)
+    return prego_fail_(PREGO_EINVAL, "debug attention fwd: bad arguments");
+  const int rc = launch_flash_attention_v2(qs, k, v, out, batch, n_query, len, heads, dh, causal ? 1 : 0, (hipStream_t)stream, lse);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  if (rc) return prego_fail_(PREGO_EINVAL, "debug attention fwd: unsupported head dim %d", dh);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
 // ---- AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170,35-57 ---------------------------------------------
 // the attention arithmetic shared by the stateless op and the handle: wqkv bf16 [3D][D] (rows q | k | v), bqkv fp32 [3D],
 // wob bf16 [D][D]; act = 5 activation buffers of M*D bf16 (x, q, k, v, attention output)

@@ -194,3 +194,53 @@ def test_vit_no_rgb_flow_only():
         got = m(torch.zeros(2, 128, 0, device="cuda"), torch.from_numpy(x).cuda())["logits"].cpu().numpy()
     ref = O.vit_forward(sd, x, None, heads=8)["logits"]
     assert np.abs(got - ref).max() < 1e-2
+
+
+@pytest.mark.parametrize("Nq,N,dh,causal", [
+    (129, 129, 256, 0), (1, 129, 256, 0),            # ViTEnc window + cls token; the token-0-only last block
+    (200, 200, 64, 1), (300, 300, 128, 1), (257, 257, 256, 1), (193, 193, 128, 0), (448, 448, 64, 0),   # 8-wave shape, ragged
+    (1024, 1024, 256, 1),                            # BASELINE configs[3]: 8 causal query blocks of 16 ... 2 key tiles
+    (64, 64, 128, 1), (130, 130, 64, 1),             # 4-wave shape
+])
+def test_attention_forward_kernel_vs_fp64(Nq, N, dh, causal):
+    """softmax(q k^T dh^-0.5 [+ triu mask]) v (Attention.py:30-38, attn.py:43-55) for every head dim and workgroup shape of the
+    forward kernel, queries at positions 0..Nq-1, and its log-sum-exp output (what the backward pass recomputes P from).
+    Inputs are bf16-exact, so only the kernel's own rounding shows (P and the output are rounded to bf16)."""
+    import ctypes as C
+    from prego_amd import _lib
+    lib = _lib.load()
+    B, h = 2, 3
+    rng = np.random.default_rng(Nq * 7 + N + dh + causal)
+
+    def bf(a):
+        return torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16).float().numpy().astype(np.float64)
+    q = bf(rng.standard_normal((B, h, Nq, dh)) * 1.5)
+    k = bf(rng.standard_normal((B, h, N, dh)))
+    v = bf(rng.standard_normal((B, h, N, dh)))
+    qs = bf(q * dh ** -0.5)
+    s = np.einsum("bhid,bhjd->bhij", qs, k)
+    if causal:
+        s = np.where(np.arange(N)[None, :] > np.arange(Nq)[:, None], -np.inf, s)
+    mx = s.max(-1, keepdims=True)
+    p = np.exp(s - mx)
+    lse = (mx + np.log(p.sum(-1, keepdims=True)))[..., 0]
+    want = np.einsum("bhij,bhjd->bhid", p / p.sum(-1, keepdims=True), v).transpose(0, 2, 1, 3).reshape(B, Nq, h * dh)
+
+    def dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).cuda()
+    tq, tk, tv = dev(qs), dev(k), dev(v)
+    out = torch.full((B, Nq, h * dh), float("nan"), dtype=torch.bfloat16, device="cuda")
+    tl = torch.full((B, h, Nq), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.prego_debug_attention_fwd(B, Nq, N, h, dh, causal, tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out.data_ptr(),
+                                       tl.data_ptr(), None)
+    assert rc == 0
+    got = out.float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    err = np.abs(got - want).max()
+    assert err < 1e-2 * max(1.0, np.abs(want).max()), (err, np.abs(want).max())
+    assert np.abs(tl.cpu().numpy() - lse).max() < 2e-3
+    # without the lse output (the inference path) the result is the same, bit for bit
+    out2 = torch.empty_like(out)
+    assert lib.prego_debug_attention_fwd(B, Nq, N, h, dh, causal, tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out2.data_ptr(),
+                                         None, None) == 0
+    assert torch.equal(out, out2)
