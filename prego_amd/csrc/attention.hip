@@ -17,7 +17,7 @@
 //   * P^T is ALREADY the B operand of O^T += V_tile^T P^T (two 16-row accumulator tiles = the 8 k-elements of a lane, in the
 //     order {4g..4g+3, 16+4g..16+4g+3}): no LDS round trip for P,
 //   * V stays ROW-major [key][d] and is read transposed by ds_read_b64_tr_b16 in that k order: no V^T tensor at all,
-//   * the output leaves as 8-byte stores of four consecutive head-dim elements.
+//   * the output leaves as 16-byte stores of eight consecutive head-dim elements (one lane-row swap per pair of tiles).
 // A wave owns QG groups of 16 queries (QG = 2: 128 queries per workgroup): every K / V fragment read from LDS feeds QG MFMAs,
 // which halves the LDS bytes per FLOP (dh = 256 is otherwise LDS-bound: each wave re-reads the whole 64 KB tile pair).
 // K and V tiles of 64 keys are double-buffered in LDS: tile kt+1 travels global -> registers while tile kt is multiplied and
@@ -268,21 +268,26 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
     __builtin_amdgcn_s_waitcnt(0x0F70);             /* vmcnt(0) */   // this wave's pieces of the next tile have landed ...
     __syncthreads();                                   // ... everyone's have, and everyone is done reading this one
   }
-  // epilogue: out[b, q, head*DH + d] = O^T[d][q] / l ; d = 16 dt + 4 g + e -> one 8-byte store per dt
+  // epilogue: out[b, q, head*DH + d] = O^T[d][q] / l ; a lane holds d = 16 dt + 4 g .. + 3 (8 bytes) per dt.  Lanes g and g ^ 1 trade
+  // halves of two dt's (v_permlane16_swap) so every lane stores 16 contiguous bytes: 8 stores per query instead of 16 (the
+  // store tail is issue-bound).  The swaps run on all lanes; only the stores are masked.
 #pragma unroll
-  for (int u = 0; u < QG; ++u)
-    if (own[u] < Nq) {
-      const float inv = drop_scale / l_run[u];                               // 1 / (1 - p) of the probability dropout (1 without it)
-      if (lse != nullptr && g == 0) lse[(size_t)bh * Nq + own[u]] = m_run[u] + logf(l_run[u]);
-      bf16_t* orow = out + ((size_t)b * Nq + own[u]) * heads * DH + (size_t)hd * DH;
+  for (int u = 0; u < QG; ++u) {
+    const bool live = own[u] < Nq;
+    const float inv = drop_scale / l_run[u];                                 // 1 / (1 - p) of the probability dropout (1 without it)
+    if (live && lse != nullptr && g == 0) lse[(size_t)bh * Nq + own[u]] = m_run[u] + logf(l_run[u]);
+    bf16_t* orow = out + ((size_t)b * Nq + (live ? own[u] : 0)) * heads * DH + (size_t)hd * DH;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        uint2 w;
-        w.x = pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv);
-        w.y = pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv);
-        *(uint2*)(orow + dt * 16 + 4 * g) = w;
-      }
+    for (int dt = 0; dt < DT; dt += 2) {
+      const unsigned a0 = pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), a1 = pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv);
+      const unsigned b0 = pack_bf16x2(o[u][dt + 1][0] * inv, o[u][dt + 1][1] * inv), b1 = pack_bf16x2(o[u][dt + 1][2] * inv, o[u][dt + 1][3] * inv);
+      // odd 16-lane rows of (a0, a1) <-> even rows of (b0, b1): g even keeps a (its own d's of dt) and receives g + 1's;
+      // g odd ends with both halves of dt + 1
+      const auto x = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+      const auto y = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      if (live) *(uint4*)(orow + (dt + (g & 1)) * 16 + 8 * (g >> 1)) = make_uint4(x[0], y[0], x[1], y[1]);
     }
+  }
 }
 
 // V row-major [B,h,N,dh]; Nq queries per (batch, head) at positions 0..Nq-1 (Nq == N for self-attention; Nq = 1: only token 0,
