@@ -337,7 +337,23 @@ def secondary(dev, lens, sd):
     res["vit"] = {"shape": "256 windows x 128 frames, heads 8, 1 layer", "ms": ms,
                   "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "SURVEY 8d: 7.69 GFLOP per window (algorithmic)"}}
-    del vm, xr, xf
+    del xr, xf
+    # ---- ViTEnc training step (the row the round-1 verdict added: trainer forward/backward through the Transformer entry)
+    vcrit = build_criterion(vcfg, dev)
+    vopt = FusedAdamW([{"params": list(vm.parameters()), "initial_lr": 1e-4}], lr=1e-4, weight_decay=0.05, model=vm)
+    xr = torch.randn(16, 128, 2048, device=dev)
+    xf = torch.randn(16, 128, 2048, device=dev)
+
+    def vit_train_step():
+        vm.train()
+        loss = vcrit(vm(xr, xf), tgt)
+        vopt.zero_grad(set_to_none=True)
+        loss.backward()
+        vopt.step()
+    ms = _time_ms(vit_train_step)
+    res["vit_train_step_ms"] = ms
+    res["vit_train_step"] = {"shape": "16 windows x 128 frames, 1 layer: fwd + OadLoss + backward + fused AdamW (handle copies refreshed by the step)", "ms": ms}
+    del vm, xr, xf, vopt, vcrit
     # ---- causal AttentionLayer (a12, BASELINE configs[3])
     sdA = W.attention_layer_state_dict(2048, 20)
     names = ("query_projection", "key_projection", "value_projection", "out_projection")

@@ -198,6 +198,12 @@ int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const flo
                             void* workspace, size_t workspace_bytes, prego_stream_t stream);
 int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
                        void* workspace, size_t workspace_bytes, prego_stream_t stream);
+/* optimizer.step() (train.py:24, AdamW of main.py:62-67) for the handle's tensors (prego_vit_set_weights' order and shapes):
+ * prego_adamw_step's arithmetic, and the handle's converted copies (bf16 matrices, fp32 vectors) are rewritten from the updated
+ * values in the same pass - no prego_vit_set_weights (5 + 4 per layer conversions and 10 + 7 per layer copies) after the step. */
+int prego_vit_adamw_step(prego_vit* h, float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, int n_tensors, int64_t step, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, prego_stream_t stream);
 
 /* AttentionLayer(FullAttention(mask_flag=causal)) of attn.py:139-170,35-57,10-18 as a stateless op (BASELINE config 4:
  * long-window causal attention).  x, out: device fp32 [batch, len, d_model]; projection weights [d_model, d_model] and

@@ -29,7 +29,7 @@ SYMBOLS = [
     "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
-    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
+    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step",
 ]
 
 
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     f32 = C.c_float
     lib.prego_adamw_step.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i64, f32, f32, f32, f32, f32, vp]
     lib.prego_miniroad_adamw_step.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, f32, f32, f32, f32, f32, vp]
+    lib.prego_vit_adamw_step.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i64, f32, f32, f32, f32, f32, vp]
     lib.prego_vit_create.argtypes = [C.POINTER(vp)] + [i32] * 8
     lib.prego_vit_destroy.argtypes = [vp]
     lib.prego_vit_destroy.restype = None

@@ -129,6 +129,35 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
   return PREGO_OK;
 }
 
+// optimizer.step() on the handle's tensors: fused AdamW that also rewrites the handle's operand copies (csrc/optim.hip)
+extern "C" int prego_vit_adamw_step(prego_vit* h, float* const* params, const float* const* grads, float* const* exp_avg,
+                                    float* const* exp_avg_sq, int n_tensors, int64_t step, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, prego_stream_t stream) {
+  if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return prego_fail_(PREGO_EINVAL, "vit adamw: NULL argument");
+  if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "vit adamw step before set_weights");
+  if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d tensors, got %d", prego_vit_num_tensors(h), n_tensors);
+  const long long E = h->emb, din = h->d_rgb + h->d_flow, mlp = h->mlp;
+  // set_weights order; matrices (bf16 copies) and vectors (fp32 copies) go in two launches, one copy element type each
+  std::vector<float*> pm, pv_; std::vector<const float*> gm, gv; std::vector<float*> mm, mv, vm, vv; std::vector<void*> cm, cv;
+  std::vector<long long> nm, nv;
+  int k = 0;
+  auto mat = [&](void* copy, long long n) { pm.push_back(params[k]); gm.push_back(grads[k]); mm.push_back(exp_avg[k]); vm.push_back(exp_avg_sq[k]); cm.push_back(copy); nm.push_back(n); ++k; };
+  auto vec = [&](void* copy, long long n) { pv_.push_back(params[k]); gv.push_back(grads[k]); mv.push_back(exp_avg[k]); vv.push_back(exp_avg_sq[k]); cv.push_back(copy); nv.push_back(n); ++k; };
+  for (int i = 0; i < n_tensors; ++i) if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return prego_fail_(PREGO_EINVAL, "vit adamw: tensor %d is NULL", i);
+  mat(h->enc_w, E * din); vec(h->enc_b, E); vec(h->cls, E); vec(h->pe, (long long)(h->window + 1) * E);
+  for (auto& l : h->L) {
+    vec(l.ln1_w, E); vec(l.ln1_b, E); mat(l.qkv_w, 3 * E * E); mat(l.proj_w, E * E); vec(l.proj_b, E); vec(l.ln2_w, E); vec(l.ln2_b, E);
+    mat(l.ff1_w, mlp * E); vec(l.ff1_b, mlp); mat(l.ff2_w, E * mlp); vec(l.ff2_b, E);
+  }
+  vec(h->lnf_w, E); vec(h->lnf_b, E); vec(h->head_w, (long long)h->ncls * E); vec(h->head_b, h->ncls);
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_adamw((int)pm.size(), pm.data(), gm.data(), mm.data(), vm.data(), cm.data(), nm.data(), true, step, lr, beta1, beta2, eps, weight_decay, s) ||
+      launch_adamw((int)pv_.size(), pv_.data(), gv.data(), mv.data(), vv.data(), cv.data(), nv.data(), false, step, lr, beta1, beta2, eps, weight_decay, s))
+    return prego_fail_(PREGO_EINVAL, "vit adamw: bad step %lld", (long long)step);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
 struct VitWs { size_t xb, enc, x, xn, q, k, vn, ao, f, x0, q0, ao0, xn0, f0, total; };
 static VitWs vit_ws(const prego_vit* h, int B) {
   const size_t E = h->emb, T = h->window, N = T + 1, din = h->d_rgb + h->d_flow;

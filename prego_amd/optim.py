@@ -2,7 +2,8 @@
 entries - 'step', 'exp_avg', 'exp_avg_sq' - so optimizer state dicts interchange), with the arithmetic in ONE fused HIP launch
 over all tensors (csrc/optim.hip) instead of torch's per-op kernels.  For a `MiniROAD` model the step also rewrites the engine's
 bf16 / fp32 operand copies of the weights from the updated values in the same pass, so the training loop never re-ingests the
-17.9 M parameters (`prego_miniroad_set_weights`) after `optimizer.step()`."""
+17.9 M parameters (`prego_miniroad_set_weights`) after `optimizer.step()`; for a `Transformer` (ViTEnc) model the same through
+`prego_vit_adamw_step` (its set_weights is 5 + 4 per layer conversions and 10 + 7 per layer device copies)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -20,6 +21,8 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._model = model if model is not None and hasattr(model, "engine") and hasattr(model, "gru") else None
+        # the "Transformer" entry (ViTEnc): same idea through prego_vit_adamw_step
+        self._vit = model if model is not None and hasattr(model, "_handle") and hasattr(model, "pre_head_ln") else None
 
     def _state(self, p):
         st = self.state[p]
@@ -64,8 +67,26 @@ class FusedAdamW(torch.optim.Optimizer):
                     ps = want
                     states = [self.state[p] for p in ps]
                     grads = [p.grad.contiguous() for p in ps]
+            fused_vit = False
+            if self._vit is not None and not fused_model:
+                from .transformer import _tensor_order
+                v = self._vit
+                named = dict(v.named_parameters())
+                want = [named[k] for k in _tensor_order(v.num_layers)]
+                fused_vit = len(ps) == len(want) and {id(p) for p in ps} == {id(p) for p in want}
+                if fused_vit:               # prego_vit_set_weights' order
+                    ps = want
+                    states = [self.state[p] for p in ps]
+                    grads = [p.grad.contiguous() for p in ps]
             with torch.cuda.device(dev):
-                if fused_model:
+                if fused_vit:
+                    self._vit._handle()     # weights ingested (a no-op after the forward of this step)
+                    check(lib.prego_vit_adamw_step(
+                        self._vit._h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
+                        ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
+                        len(ps), *hyper, C.c_void_p(_stream_ptr(dev))))
+                    # parameter versions did not move and the handle's copies are those of the new values: no re-ingest
+                elif fused_model:
                     eng = m.engine()        # weights already ingested (versions unchanged since the forward)
                     check(lib.prego_miniroad_adamw_step(
                         eng.h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),

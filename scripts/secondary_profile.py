@@ -46,7 +46,7 @@ elif which in ("vit", "vit_train"):
                 vm(xr, xf)
     else:
         crit = build_criterion(vcfg, dev)
-        opt = FusedAdamW([{"params": list(vm.parameters())}], lr=1e-4, weight_decay=0.05)
+        opt = FusedAdamW([{"params": list(vm.parameters())}], lr=1e-4, weight_decay=0.05, model=vm)
         xr, xf = torch.randn(16, 128, 2048, device=dev), torch.randn(16, 128, 2048, device=dev)
         tgt = torch.zeros(16, 128, 86, device=dev)
         tgt[:, :, 3] = 1

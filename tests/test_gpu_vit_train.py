@@ -188,3 +188,48 @@ def test_vit_train_with_dropout_matches_oracle_with_the_same_masks(p_drop, p_att
         cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30))
         assert cos > 0.995, (k, cos)
         assert abs(np.linalg.norm(g) - np.linalg.norm(r)) < 0.10 * np.linalg.norm(r) + 1e-9, k
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+def test_fused_adamw_refreshes_vit_handle(layers):
+    """train.py:20-24 on the `Transformer` entry with FusedAdamW(model=...): prego_vit_adamw_step rewrites the handle's bf16 / fp32
+    copies from the updated values, so prego_vit_set_weights is never called again - and the trajectory (losses, parameters,
+    eval logits after three steps) is bit-identical to the generic fused step + re-ingest (same kernel arithmetic, same values
+    rounded to bf16 once)."""
+    from prego_amd import _lib
+    from prego_amd.optim import FusedAdamW
+    from prego_amd.registry import build_criterion, build_model
+    import prego_amd.loss, prego_amd.transformer  # noqa: F401
+    cfg = _vit_cfg(num_layers=layers)
+    sd = W.vit_state_dict(cfg, 20)
+    rgb = torch.from_numpy(W.tsn_features((3, 128, 2048), 22, "va.rgb")).cuda()
+    flow = torch.from_numpy(W.tsn_features((3, 128, 2048), 22, "va.flow")).cuda()
+    tgt = torch.from_numpy(_targets(3, 128, 86, 22, "va.tgt")).cuda()
+    lib = _lib.load()
+    res = {}
+    for kind in ("handle", "generic"):
+        model = build_model(cfg, "cuda:0")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        crit = build_criterion(cfg, "cuda:0")
+        opt = FusedAdamW([{"params": list(model.parameters())}], lr=1e-3, weight_decay=0.05, model=model if kind == "handle" else None)
+        losses = []
+        vers = []
+        for _ in range(3):
+            model.train()
+            loss = crit(model(rgb, flow), tgt)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            vers.append(model._ver)
+        model.eval()
+        with torch.no_grad():
+            logits = model(rgb, flow)["logits"]
+        torch.cuda.synchronize()
+        res[kind] = (losses, logits.clone(), {k: p.detach().clone() for k, p in model.named_parameters()}, vers, model._ver)
+    # the handle path never re-ingested (the version key of the ingested weights did not move), the generic path did every step
+    assert res["handle"][3][0] == res["handle"][4] and res["generic"][3][0] != res["generic"][4]
+    assert res["handle"][0] == res["generic"][0] and res["handle"][0][2] < res["handle"][0][0]
+    for k in res["handle"][2]:
+        assert torch.equal(res["handle"][2][k], res["generic"][2][k]), k
+    assert torch.equal(res["handle"][1], res["generic"][1])
