@@ -98,6 +98,20 @@ int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int32_t* lens, 
                            float* h_last, int flags, void* workspace, size_t workspace_bytes,
                            prego_stream_t stream);
 
+/* Streaming inference, the online use of the model: ONE new frame for each of n_streams <= 16 independent streams -
+ * MROAD.forward (rnn.py:51-71) with T = 1 and h0 = the state the previous call left.
+ *   rgb / flow     device fp32 [n_streams, d_rgb] / [n_streams, d_flow], one frame per stream; flow == NULL = zero flow half
+ *                  (rgb is ignored by a --no_rgb model)
+ *   h_state        device fp32 [n_streams, hid], read and OVERWRITTEN with the new state (zeros before a stream's first frame)
+ *   out            device fp32 [n_streams, n_classes]: probabilities (PREGO_FWD_SOFTMAX in flags) or logits; nullable
+ *   argmax         device int32 [n_streams]; nullable
+ * Four kernel launches, no plan, no workspace, no host staging (the general forward() with n_clips = 1, lens = {1}, h0, h_last is
+ * the same arithmetic in eight launches plus table staging).  bf16 handles only (PREGO_EINVAL otherwise: use forward()).
+ * Projection outputs stay fp32 here (forward()'s inference path rounds them to bf16), so the two paths agree to the operand
+ * rounding, not bit for bit. */
+int prego_miniroad_step(prego_miniroad* h, int n_streams, const float* rgb, const float* flow, float* h_state, float* out,
+                        int32_t* argmax, int flags, prego_stream_t stream);
+
 /* Synchronises `stream` and reports a recurrence timeout (PREGO_ETIMEOUT) or HIP error since the last check. */
 int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream);
 

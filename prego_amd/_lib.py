@@ -29,7 +29,7 @@ SYMBOLS = [
     "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
-    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step",
+    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
 ]
 
 
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     lib.prego_miniroad_workspace_bytes.restype = sz
     lib.prego_miniroad_forward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp),
                                            C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp, sz, vp]
+    lib.prego_miniroad_step.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp]
     lib.prego_miniroad_check.argtypes = [vp, vp]
     lib.prego_miniroad_timing_enable.argtypes = [vp, i32]
     lib.prego_miniroad_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),

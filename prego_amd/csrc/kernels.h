@@ -177,3 +177,16 @@ void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int 
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
                      const float* hb, int C, float* out, hipStream_t s);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);
+
+// streaming step (stream_step.hip): skinny products for n <= 16 rows, one frame per stream
+struct StreamGemv {
+  const void* W;        // [Nout][K] bf16
+  const void* X;        // input columns [0, kx1): [n][ldx], fp32 or bf16 (x_bf16)
+  const void* X2;       // input columns [kx1, K): [n][ldx2]; nullptr = zeros
+  const float* bias;    // nullable
+  float* Y;             // [n][Nout]
+  int Nout, K, kx1, ldx, ldx2, x_bf16;
+};
+int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s);
+int launch_stream_gates_head(const float* gi, const float* gh, const float* b_hn, float* h_state, const void* wc, const float* bc, int n,
+                              int H, int C, int softmax, float* out, int* argmax, hipStream_t s);

@@ -74,6 +74,7 @@ struct prego_miniroad {
   unsigned* abort_word = nullptr;
   float* h_state = nullptr;     // [max_clips][H]
   unsigned long long* stamps = nullptr;   // debug phase counters (PREGO_GRU_STAMPS=1)
+  char* st_scratch = nullptr;   // streaming step: y [16][emb] f32 | e [16][emb] bf16 | gi [16][3H] f32 | gh [16][3H] f32
   bool use_stamps = false;
   // training
   float drop_p = 0.f;
@@ -181,6 +182,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
+  A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
   if (e == hipSuccess) e = hipMemset(h->hx, 0, gru_hx_bytes(h->bf16, H, h->G));
@@ -195,7 +197,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs, h->d_blkstep};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
@@ -615,6 +617,37 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ++ci;
   }
   if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// streaming step: one frame for each of n <= 16 streams (stream_step.hip)
+extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float* rgb, const float* flow, float* h_state, float* out,
+                                   int32_t* argmax, int flags, prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (!h->have_weights) return fail(PREGO_EINVAL, "step before set_weights");
+  if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 handles (fp32 operands: use forward() with h0 / h_last)");
+  if (n_streams < 1 || n_streams > 16) return fail(PREGO_EINVAL, "step: %d streams (1..16 per call)", n_streams);
+  if (!h_state) return fail(PREGO_EINVAL, "step: h_state is NULL");
+  if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "step: rgb is NULL");
+  if (h->d_rgb == 0 && !flow) return fail(PREGO_EINVAL, "a model without rgb features (--no_rgb) needs the flow frame");
+  hipStream_t s = (hipStream_t)stream;
+  const int E = h->emb, H = h->hid, din = h->d_rgb + h->d_flow;
+  float* Y = (float*)h->st_scratch;
+  void* Eb = h->st_scratch + (size_t)16 * E * 4;
+  float* GI = (float*)(h->st_scratch + (size_t)16 * E * 6);
+  float* GH = GI + (size_t)16 * 3 * H;
+  const bool with_flow = flow != nullptr && h->d_flow > 0;
+  // layer1: K = the columns actually present (a zero flow half drops its half of K, as in forward())
+  StreamGemv l1{h->w1, rgb, with_flow ? flow : nullptr, h->b1, Y, E, din, h->d_rgb, h->d_rgb, h->d_flow, 0};
+  if (launch_stream_gemv(1, &l1, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported layer1 shape %d x %d", E, din);
+  launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false);
+  StreamGemv g2[2] = {{h->w_ih, Eb, nullptr, h->bias2, GI, 3 * H, E, E, E, 0, 1},
+                      {h->w_hh, h_state, nullptr, nullptr, GH, 3 * H, H, H, H, 0, 0}};
+  if (launch_stream_gemv(2, g2, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported GRU shape %d / %d", E, H);
+  if (launch_stream_gates_head(GI, GH, h->b_hn, h_state, h->w_c, h->b_c, n_streams, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, out,
+                               (int*)argmax, s)) return fail(PREGO_EINVAL, "step: unsupported head shape %d x %d", h->ncls, H);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

@@ -162,6 +162,40 @@ class MiniRoadEngine:
                 C.c_void_p(h_last.data_ptr()) if h_last is not None else None,
                 flags, C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(_stream_ptr(self.device))))
 
+    # -- streaming (online use) ------------------------------------------------
+    def step(self, rgb: Optional[torch.Tensor], flow: Optional[torch.Tensor], h: torch.Tensor, softmax: bool = True,
+             out: Optional[torch.Tensor] = None, argmax: Optional[torch.Tensor] = None):
+        """One new frame for each of n <= 16 independent streams: rgb [n, d_rgb] / flow [n, d_flow] (None = zero flow) fp32 cuda
+        contiguous, h [n, hid] fp32 cuda = the GRU state, UPDATED IN PLACE (zeros before a stream's first frame).
+        Returns (probabilities or logits [n, C], argmax int32 [n]); pass `out` / `argmax` to reuse buffers.  bf16 engines run
+        the four-launch fast path (prego_miniroad_step); fp32 engines the general forward with h0 / h_last."""
+        d_rgb, d_flow, emb, hid, ncls = self.dims
+        src = rgb if d_rgb > 0 else flow
+        if src is None:
+            raise PregoError("step: a --no_rgb model needs the flow frame" if d_rgb == 0 else "step: rgb is None")
+        n = src.shape[0]
+        for t, d in ((rgb if d_rgb > 0 else None, d_rgb), (flow, d_flow), (h, hid)):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, d)):
+                raise PregoError(f"step: expected contiguous fp32 cuda [{n}, {d}], got {tuple(t.shape)} {t.dtype} on {t.device}")
+        if out is None:
+            out = torch.empty((n, ncls), dtype=torch.float32, device=self.device)
+        if argmax is None:
+            argmax = torch.empty((n,), dtype=torch.int32, device=self.device)
+        if self.compute_dtype != "bf16":
+            rl = [rgb[i:i + 1] for i in range(n)] if d_rgb > 0 else None
+            fl = [flow[i:i + 1] for i in range(n)] if flow is not None else None
+            o, a, hl = self.forward_ragged(rl, fl, softmax=softmax, want_out=True, want_argmax=True, h0=h, want_h_last=True)
+            h.copy_(hl)
+            out.copy_(torch.cat(o))
+            argmax.copy_(torch.cat(a))
+            return out, argmax
+        with torch.cuda.device(self.device):
+            check(self.lib.prego_miniroad_step(
+                self.h, n, C.c_void_p(rgb.data_ptr()) if (rgb is not None and d_rgb > 0) else None,
+                C.c_void_p(flow.data_ptr()) if flow is not None else None, C.c_void_p(h.data_ptr()), C.c_void_p(out.data_ptr()),
+                C.c_void_p(argmax.data_ptr()), _lib.FWD_SOFTMAX if softmax else 0, C.c_void_p(_stream_ptr(self.device))))
+        return out, argmax
+
     # -- training ------------------------------------------------------------------------
     def set_dropout(self, p: float, seed: int):
         check(self.lib.prego_miniroad_set_dropout(self.h, float(p), int(seed) & 0xFFFFFFFFFFFFFFFF))

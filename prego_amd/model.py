@@ -85,3 +85,10 @@ class MROAD(nn.Module):
         """Ragged batched inference (the data-parallel hot path): many whole videos per call."""
         eng = self.engine()
         return eng.forward_ragged(rgb_list, flow_list, softmax=True, want_out=want_probs, want_argmax=want_argmax)
+
+    @torch.no_grad()
+    def step(self, rgb, flow, h):
+        """Online inference (not exposed by the reference, whose eval loop runs whole videos): one new frame per stream.
+        rgb [n, d_rgb] / flow [n, d_flow] (None = zeros), h [n, hidden_dim] = the GRU state, updated in place.  Returns
+        (probabilities [n, C], argmax int32 [n]) - the eval branch of MROAD.forward (rnn.py:66-70) at T = 1 with h0 = h."""
+        return self.engine().step(rgb, flow, h, softmax=True)

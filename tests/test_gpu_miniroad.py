@@ -252,3 +252,61 @@ def test_single_stream_models_no_rgb_no_flow(which):
     for k, p in m.named_parameters():
         g = p.grad.cpu().numpy()
         assert np.abs(g - ref_g[k]).max() < 2e-3 * max(np.abs(ref_g[k]).max(), 1e-6) + 1e-7, k
+
+
+@pytest.mark.parametrize("n,zero_flow", [(1, False), (3, False), (16, False), (2, True)])
+def test_streaming_step_fast_path_vs_oracle_and_batched(n, zero_flow):
+    """prego_miniroad_step (four launches per frame, state carried by the caller): n streams fed frame by frame for T frames
+    equal MROAD.forward on the whole sequences - against the numpy oracle at the north-star tolerance for bf16 operands, and
+    against the batched GPU path (same operand rounding, different summation order and fp32 instead of bf16 projection outputs)."""
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    m = _model(cfg, sd, "bf16")
+    eng = m.engine()
+    T = 24
+    rgb = np.stack([W.tsn_features((T, 2048), 31, f"st.rgb{i}") for i in range(n)])
+    flow = None if zero_flow else np.stack([W.tsn_features((T, 2048), 31, f"st.flow{i}") for i in range(n)])
+    trgb = torch.from_numpy(rgb).cuda()
+    tflow = None if flow is None else torch.from_numpy(flow).cuda()
+    h = torch.zeros((n, 1024), device="cuda")
+    probs, args = [], []
+    for t in range(T):
+        p, a = m.step(trgb[:, t].contiguous(), None if tflow is None else tflow[:, t].contiguous(), h)
+        probs.append(p.clone())
+        args.append(a.clone())
+    eng.check()
+    got = torch.stack(probs, 1).cpu().numpy()                     # [n, T, C]
+    garg = torch.stack(args, 1).cpu().numpy()
+    ref = O.miniroad_forward(sd, rgb, flow, keep=True)
+    assert np.abs(got - ref["logits"]).max() < 1e-2
+    assert np.allclose(got.sum(-1), 1.0, atol=1e-4)
+    assert np.array_equal(garg, got.argmax(-1))
+    # batched path on the same sequences, incl. the final state
+    outs, _, hl = eng.forward_ragged([trgb[i] for i in range(n)], None if tflow is None else [tflow[i] for i in range(n)],
+                                     softmax=True, want_out=True, want_argmax=False, want_h_last=True)
+    eng.check()
+    assert np.abs(got - torch.stack(outs).cpu().numpy()).max() < 5e-3
+    assert (h - hl).abs().max().item() < 5e-3
+    assert np.abs(h.cpu().numpy() - ref["h_last"]).max() < 1e-2
+
+
+def test_streaming_step_rejects_misuse():
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20)
+    m = _model(cfg, sd, "bf16")
+    h = torch.zeros((17, 1024), device="cuda")
+    x = torch.zeros((17, 2048), device="cuda")
+    from prego_amd._lib import PregoError
+    with pytest.raises(PregoError):
+        m.step(x, None, h)                 # 17 streams: 16 per call
+    with pytest.raises(PregoError):
+        m.step(x[:2], None, h[:3])         # state rows != frames
+    # an fp32 engine serves step() through the general forward (h0 / h_last)
+    m32 = _model(cfg, sd, "fp32")
+    h2 = torch.zeros((2, 1024), device="cuda")
+    r = torch.from_numpy(W.tsn_features((2, 2048), 32, "st32")).cuda()
+    p, a = m32.step(r, None, h2)
+    m32.engine().check()
+    ref = O.miniroad_forward(sd, r.cpu().numpy()[:, None], None, keep=True)
+    assert np.abs(p.cpu().numpy() - ref["logits"][:, 0]).max() < 1e-3
+    assert np.abs(h2.cpu().numpy() - ref["h_last"]).max() < 1e-3
