@@ -310,3 +310,23 @@ def test_streaming_step_rejects_misuse():
     ref = O.miniroad_forward(sd, r.cpu().numpy()[:, None], None, keep=True)
     assert np.abs(p.cpu().numpy() - ref["logits"][:, 0]).max() < 1e-3
     assert np.abs(h2.cpu().numpy() - ref["h_last"]).max() < 1e-3
+
+
+@pytest.mark.parametrize("which", ["no_rgb", "no_flow"])
+def test_streaming_step_single_stream_models(which):
+    """the fast path on a --no_rgb / --no_flow model (Epic-tent dims: 12 classes = one class tile, K = 2048 for layer1)"""
+    cfg = epic_tent_cfg(**{which: True}, dropout=0.0)
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    m = _model(cfg, sd, "bf16")
+    n, T = 2, 12
+    feat = W.tsn_features((n, T, 2048), 33, f"st.single.{which}")
+    x = torch.from_numpy(feat).cuda()
+    h = torch.zeros((n, 1024), device="cuda")
+    got = []
+    for t in range(T):
+        fr = x[:, t].contiguous()
+        p, _ = m.step(None, fr, h) if which == "no_rgb" else m.step(fr, None, h)
+        got.append(p.clone())
+    m.engine().check()
+    ref = O.miniroad_forward(sd, feat, None)["logits"]
+    assert np.abs(torch.stack(got, 1).cpu().numpy() - ref).max() < 1e-2
