@@ -200,7 +200,7 @@ def test_vit_no_rgb_flow_only():
     (129, 129, 256, 0), (1, 129, 256, 0),            # ViTEnc window + cls token; the token-0-only last block
     (200, 200, 64, 1), (300, 300, 128, 1), (257, 257, 256, 1), (193, 193, 128, 0), (448, 448, 64, 0),   # 8-wave shape, ragged
     (1024, 1024, 256, 1),                            # BASELINE configs[3]: 8 causal query blocks of 16 ... 2 key tiles
-    (64, 64, 128, 1), (130, 130, 64, 1),             # 4-wave shape
+    (64, 64, 128, 1), (130, 130, 64, 1), (129, 129, 256, 1), (1, 129, 256, 1),   # 4-wave shape, causal (incl. token 0 only)
 ])
 def test_attention_forward_kernel_vs_fp64(Nq, N, dh, causal):
     """softmax(q k^T dh^-0.5 [+ triu mask]) v (Attention.py:30-38, attn.py:43-55) for every head dim and workgroup shape of the
