@@ -105,7 +105,7 @@ int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int32_t* lens, 
  *   h_state        device fp32 [n_streams, hid], read and OVERWRITTEN with the new state (zeros before a stream's first frame)
  *   out            device fp32 [n_streams, n_classes]: probabilities (PREGO_FWD_SOFTMAX in flags) or logits; nullable
  *   argmax         device int32 [n_streams]; nullable
- * Four kernel launches, no plan, no workspace, no host staging (the general forward() with n_clips = 1, lens = {1}, h0, h_last is
+ * Three kernel launches for <= 4 streams (LayerNorm inside the W_ih product), four above; no plan, no workspace, no host staging (the general forward() with n_clips = 1, lens = {1}, h0, h_last is
  * the same arithmetic in eight launches plus table staging).  bf16 handles only (PREGO_EINVAL otherwise: use forward()).
  * Projection outputs stay fp32 here (forward()'s inference path rounds them to bf16), so the two paths agree to the operand
  * rounding, not bit for bit. */

@@ -186,6 +186,9 @@ struct StreamGemv {
   const float* bias;    // nullable
   float* Y;             // [n][Nout]
   int Nout, K, kx1, ldx, ldx2, x_bf16;
+  const float* ln_g = nullptr;   // non-null (with ln_b): X is the fp32 pre-LayerNorm row, normalised + ReLU inside the kernel (n <= 4, K % 2048 == 0)
+  const float* ln_b = nullptr;
+  float ln_eps = 1e-5f;
 };
 int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s);
 int launch_stream_gates_head(const float* gi, const float* gh, const float* b_hn, float* h_state, const void* wc, const float* bc, int n,

@@ -642,9 +642,13 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   // layer1: K = the columns actually present (a zero flow half drops its half of K, as in forward())
   StreamGemv l1{h->w1, rgb, with_flow ? flow : nullptr, h->b1, Y, E, din, h->d_rgb, h->d_rgb, h->d_flow, 0};
   if (launch_stream_gemv(1, &l1, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported layer1 shape %d x %d", E, din);
-  launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false);
-  StreamGemv g2[2] = {{h->w_ih, Eb, nullptr, h->bias2, GI, 3 * H, E, E, E, 0, 1},
+  // LayerNorm + ReLU: inside the W_ih product for <= 4 streams (three launches per frame), the batched kernel otherwise
+  static const bool no_fuse = getenv("PREGO_STEP_NO_LN_FUSE") != nullptr;
+  const bool fuse_ln = n_streams <= 4 && E % 2048 == 0 && !no_fuse;
+  if (!fuse_ln) launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false);
+  StreamGemv g2[2] = {{h->w_ih, fuse_ln ? (const void*)Y : (const void*)Eb, nullptr, h->bias2, GI, 3 * H, E, E, E, 0, fuse_ln ? 0 : 1},
                       {h->w_hh, h_state, nullptr, nullptr, GH, 3 * H, H, H, H, 0, 0}};
+  if (fuse_ln) { g2[0].ln_g = h->ln_g; g2[0].ln_b = h->ln_b; g2[0].ln_eps = 1e-5f; }
   if (launch_stream_gemv(2, g2, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported GRU shape %d / %d", E, H);
   if (launch_stream_gates_head(GI, GH, h->b_hn, h_state, h->w_c, h->b_c, n_streams, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, out,
                                (int*)argmax, s)) return fail(PREGO_EINVAL, "step: unsupported head shape %d x %d", h->ncls, H);

@@ -4,7 +4,7 @@
 //
 // With one row per stream every layer is a skinny product that reads its whole weight matrix once (36 MB of bf16 per frame):
 // HBM-latency bound, so the design goal is "everything in flight at once, as few launches as possible" - not the batched
-// path's tiling.  Four launches per frame instead of the batched path's seven plus its plan / table staging:
+// path's tiling.  Three (<= 4 streams: LayerNorm inside the second product) or four launches per frame instead of the batched path's seven plus its plan / table staging:
 //   stream_gemv        layer1: y = [rgb | flow] W1^T + b1            (fp32 features converted in registers, no pack kernel)
 //   ln_relu_rows       LayerNorm + ReLU (the batched path's kernel, rowwise.hip)
 //   stream_gemv x 2    gi = e W_ih^T + b_ih (+ b_hh for r, z)  and  gh = h W_hh^T   in ONE launch (two problem descriptors)
@@ -23,6 +23,9 @@ struct GemvProb {
   const void* X2;              // input columns [kx1, K): [n][ldx2]; nullptr = zeros (all-zero flow half)
   const float* bias;           // [Nout], nullable
   float* Y;                    // [n][Nout] fp32
+  const float* ln_g;           // non-null: X is the fp32 PRE-LayerNorm row [n][K] (n <= 4): the workgroup normalises it itself
+  const float* ln_b;
+  float ln_eps;
   int Nout, K, kx1, ldx, ldx2, x_bf16, block0;
 };
 struct GemvArgs { GemvProb p[2]; int nprob, n, rows; };
@@ -33,9 +36,15 @@ struct GemvArgs { GemvProb p[2]; int nprob, n, rows; };
 // A lane requests 32 CONTIGUOUS bytes of its weight row per pair of k-steps (the four lanes of a row cover one 128-byte line);
 // the contraction index is permuted accordingly - MFMA 2p takes columns 16 g .. 16 g + 7 of the pair's 64, MFMA 2p + 1 columns
 // 16 g + 8 .. 16 g + 15 - and the input fragment is loaded with the same permutation.
-template <int MAXKS>
+// LNX: problems whose ln_g is set take their input through LayerNorm + ReLU (rnn.py:41-42) inside the kernel: the workgroup loads
+// the <= 4 pre-LayerNorm rows (requests issued BEFORE the weight requests, so that waiting for them leaves the weights in
+// flight), computes the two-pass statistics with two block reductions, and reads its input fragments from the normalised bf16
+// rows in LDS.  384 workgroups repeat the same 8 KB row: cheaper than the extra launch of a LayerNorm kernel (5.9 us).
+template <int MAXKS, bool LNX>
 __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(GemvArgs a) {
   __shared__ f32x4 red[4][64];
+  __shared__ __attribute__((aligned(16))) bf16_t xs[LNX ? 4 : 1][LNX ? MAXKS * 128 : 8];
+  __shared__ float sred[2][4][4];
   const int pi = (a.nprob > 1 && (int)blockIdx.x >= a.p[1].block0) ? 1 : 0;
   const GemvProb p = a.p[pi];
   const int tid = threadIdx.x, lane = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,6 +54,27 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
   const bool live = l15 < a.n, wlive = l15 < a.rows;
   const bf16_t* wrow = p.W + (size_t)(j0 + (wlive ? l15 : 0)) * p.K + q * kq + 16 * g;
   constexpr int MAXP = MAXKS / 2;
+  const bool ln = LNX && p.ln_g != nullptr;                  // workgroup-uniform
+  constexpr int EPL = MAXKS / 2;                             // elements of a row per thread at the largest K (K / 256)
+  float yv[LNX ? 4 : 1][LNX ? EPL : 1], gv[LNX ? EPL : 1], bv[LNX ? EPL : 1];
+  const int epl = p.K >> 8;                                  // K % 2048 == 0 in this mode: 8 or 16 elements per thread
+  if constexpr (LNX) {
+    if (ln) {
+#pragma unroll
+      for (int c = 0; c < EPL; c += 4)
+        if (c < epl) {
+          const f32x4 g4 = *(const f32x4*)(p.ln_g + tid * epl + c), b4 = *(const f32x4*)(p.ln_b + tid * epl + c);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { gv[c + k] = g4[k]; bv[c + k] = b4[k]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 y4 = r < a.n ? *(const f32x4*)((const float*)p.X + (size_t)r * p.ldx + tid * epl + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yv[r][c + k] = y4[k];
+          }
+        }
+    }
+  }
 
   u32x4 wa[MAXP][2];
   u32x4 xr[MAXP][4];
@@ -56,11 +86,53 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
       wa[pr][1] = __builtin_nontemporal_load((const u32x4*)(wrow + pr * 64 + 8));
     }
   }
+  if constexpr (LNX) {
+    if (ln) {
+      const float invK = 1.0f / (float)p.K;
+      float mu[4], rstd[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r < a.n) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) if (c < epl) sacc += yv[r][c];
+        sacc = wave_sum(sacc);
+        if (lane == 0) sred[0][q][r] = sacc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r < a.n) {
+        mu[r] = ((sred[0][0][r] + sred[0][1][r]) + (sred[0][2][r] + sred[0][3][r])) * invK;
+        float qacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < EPL; ++c) if (c < epl) { const float d = yv[r][c] - mu[r]; qacc += d * d; }
+        qacc = wave_sum(qacc);
+        if (lane == 0) sred[1][q][r] = qacc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (r < a.n) {
+        rstd[r] = 1.0f / sqrtf(((sred[1][0][r] + sred[1][1][r]) + (sred[1][2][r] + sred[1][3][r])) * invK + p.ln_eps);
+#pragma unroll
+        for (int c = 0; c < EPL; c += 2)
+          if (c < epl) {
+            const float o0 = fmaxf((yv[r][c] - mu[r]) * rstd[r] * gv[c] + bv[c], 0.f);
+            const float o1 = fmaxf((yv[r][c + 1] - mu[r]) * rstd[r] * gv[c + 1] + bv[c + 1], 0.f);
+            *(unsigned*)(&xs[r][tid * epl + c]) = pack_bf16x2(o0, o1);
+          }
+      }
+      __syncthreads();
+    }
+  }
 #pragma unroll
   for (int pr = 0; pr < MAXP; ++pr) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) xr[pr][v] = (u32x4){0u, 0u, 0u, 0u};
-    if (pr < npair) {
+    if (LNX && ln) {
+      if (pr < npair && live) {                              // n <= 4 rows: live lanes are l15 < n
+        const bf16_t* src = &xs[l15][q * kq + pr * 64 + 16 * g];
+        xr[pr][0] = *(const u32x4*)src; xr[pr][1] = *(const u32x4*)(src + 8);
+      }
+    } else if (pr < npair) {
       const int kb = q * kq + pr * 64;                       // wave-uniform: a pair lies in ONE input half (kx1 % 64 == 0)
       const bool first = kb < p.kx1;
       const void* base = first ? p.X : p.X2;
@@ -82,7 +154,7 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
   for (int pr = 0; pr < MAXP; ++pr)
     if (pr < npair) {
       u32x4 x0 = xr[pr][0], x1 = xr[pr][1];
-      if (!p.x_bf16) {
+      if (!p.x_bf16 && !(LNX && ln)) {
         const f32x4 f0 = __builtin_bit_cast(f32x4, xr[pr][0]), f1 = __builtin_bit_cast(f32x4, xr[pr][1]);
         const f32x4 f2 = __builtin_bit_cast(f32x4, xr[pr][2]), f3 = __builtin_bit_cast(f32x4, xr[pr][3]);
         x0 = (u32x4){pack_bf16x2(f0[0], f0[1]), pack_bf16x2(f0[2], f0[3]), pack_bf16x2(f1[0], f1[1]), pack_bf16x2(f1[2], f1[3])};
@@ -200,12 +272,18 @@ int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s) {
   a.rows = tiles16 < 200 ? 8 : 16;                           // fewer than ~one workgroup per CU at 16 rows: halve the tile
   int blocks = 0;
   for (int i = 0; i < nprob; ++i) {
-    a.p[i] = GemvProb{(const bf16_t*)pr[i].W, pr[i].X, pr[i].X2, pr[i].bias, pr[i].Y, pr[i].Nout, pr[i].K, pr[i].kx1, pr[i].ldx, pr[i].ldx2,
-                      pr[i].x_bf16, blocks};
+    a.p[i] = GemvProb{(const bf16_t*)pr[i].W, pr[i].X, pr[i].X2, pr[i].bias, pr[i].Y, pr[i].ln_g, pr[i].ln_b, pr[i].ln_eps, pr[i].Nout, pr[i].K,
+                      pr[i].kx1, pr[i].ldx, pr[i].ldx2, pr[i].x_bf16, blocks};
     blocks += pr[i].Nout / a.rows;
   }
-  if (kmax > 2048) stream_gemv_kernel<32><<<blocks, 256, 0, s>>>(a);
-  else stream_gemv_kernel<16><<<blocks, 256, 0, s>>>(a);
+  bool any_ln = false;
+  for (int i = 0; i < nprob; ++i)
+    if (pr[i].ln_g != nullptr) {
+      if (n > 4 || pr[i].K % 2048 || pr[i].kx1 != pr[i].K || pr[i].x_bf16 || !pr[i].ln_b) return -1;
+      any_ln = true;
+    }
+  if (kmax > 2048) { if (any_ln) stream_gemv_kernel<32, true><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<32, false><<<blocks, 256, 0, s>>>(a); }
+  else { if (any_ln) stream_gemv_kernel<16, true><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<16, false><<<blocks, 256, 0, s>>>(a); }
   return 0;
 }
 

@@ -168,7 +168,7 @@ class MiniRoadEngine:
         """One new frame for each of n <= 16 independent streams: rgb [n, d_rgb] / flow [n, d_flow] (None = zero flow) fp32 cuda
         contiguous, h [n, hid] fp32 cuda = the GRU state, UPDATED IN PLACE (zeros before a stream's first frame).
         Returns (probabilities or logits [n, C], argmax int32 [n]); pass `out` / `argmax` to reuse buffers.  bf16 engines run
-        the four-launch fast path (prego_miniroad_step); fp32 engines the general forward with h0 / h_last."""
+        the three / four-launch fast path (prego_miniroad_step); fp32 engines the general forward with h0 / h_last."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
         src = rgb if d_rgb > 0 else flow
         if src is None:

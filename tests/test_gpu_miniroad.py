@@ -254,7 +254,7 @@ def test_single_stream_models_no_rgb_no_flow(which):
         assert np.abs(g - ref_g[k]).max() < 2e-3 * max(np.abs(ref_g[k]).max(), 1e-6) + 1e-7, k
 
 
-@pytest.mark.parametrize("n,zero_flow", [(1, False), (3, False), (16, False), (2, True)])
+@pytest.mark.parametrize("n,zero_flow", [(1, False), (3, False), (4, False), (5, False), (16, False), (2, True)])
 def test_streaming_step_fast_path_vs_oracle_and_batched(n, zero_flow):
     """prego_miniroad_step (four launches per frame, state carried by the caller): n streams fed frame by frame for T frames
     equal MROAD.forward on the whole sequences - against the numpy oracle at the north-star tolerance for bf16 operands, and
