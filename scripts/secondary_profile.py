@@ -1,6 +1,6 @@
 """Workload for `rocprofv3 --kernel-trace --stats` over the secondary paths (one path per invocation, so that each kernel-stats
 file is one path): train (MiniROAD train step 16 x 128), vit (ViTEnc forward, 256 windows x 128), vit_train (ViTEnc train step,
-16 windows x 128), attn (causal AttentionLayer B = 16, L = 1024).
+16 windows x 128), attn (causal AttentionLayer B = 16, L = 1024), step (the streaming fast path, 1 and 16 streams).
     rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 scripts/secondary_profile.py vit"""
 import os
 import sys
@@ -63,5 +63,20 @@ elif which == "attn":
     x = torch.randn(16, 1024, 2048, device=dev)
     for _ in range(n + 2):
         attention_layer(x, *wargs, n_heads=8, mask_flag=True)
+elif which == "step":
+    # the online fast path (prego_miniroad_step): 200 frames of one stream (rgb + flow), then 200 frames of 16 streams
+    cfg = assembly101_cfg(compute_dtype="bf16")
+    m = build_model(cfg, dev)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.miniroad_state_dict(cfg, 20).items()})
+    m.eval()
+    eng = m.engine()
+    for ns in (1, 16):
+        x = torch.randn(ns, 2048, device=dev).clamp_(min=0)
+        f = torch.randn(ns, 2048, device=dev).clamp_(min=0)
+        h = torch.zeros(ns, 1024, device=dev)
+        out, arg = torch.empty(ns, 86, device=dev), torch.empty(ns, dtype=torch.int32, device=dev)
+        for _ in range(200):
+            eng.step(x, f, h, out=out, argmax=arg)
+    eng.check()
 torch.cuda.synchronize()
 print("done", which)
