@@ -54,6 +54,9 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
   const bool live = l15 < a.n, wlive = l15 < a.rows;
   const bf16_t* wrow = p.W + (size_t)(j0 + (wlive ? l15 : 0)) * p.K + q * kq + 16 * g;
   constexpr int MAXP = MAXKS / 2;
+  // every global request of the kernel goes out up front: a dependent round trip to memory costs ~2 us here, the arithmetic nothing
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && q == 0 && 4 * g < a.rows) bias4 = *(const f32x4*)(p.bias + j0 + 4 * g);
   const bool ln = LNX && p.ln_g != nullptr;                  // workgroup-uniform
   constexpr int EPL = MAXKS / 2;                             // elements of a row per thread at the largest K (K / 256)
   float yv[LNX ? 4 : 1][LNX ? EPL : 1], gv[LNX ? EPL : 1], bv[LNX ? EPL : 1];
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
   if (q == 0 && 4 * g < a.rows) {
     // accumulator element e of lane (column l15 = stream, g): output feature j0 + 4 g + e
     f32x4 r = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    if (p.bias != nullptr) { const f32x4 b = *(const f32x4*)(p.bias + j0 + 4 * g); r += b; }
+    r += bias4;
     if (live) *(f32x4*)(p.Y + (size_t)l15 * p.Nout + j0 + 4 * g) = r;
   }
 }
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* 
   for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) wa[ct][ks] = *(const bf16x8*)(wc + (size_t)(ct * 16 + l15) * H + q * 256 + ks * 32 + 8 * g);
+  const float bc_t = tid < C ? bc[tid] : 0.f;               // requested with everything else (a late load is one more ~2 us round trip)
   const float* gis = gi + (size_t)s * 3 * H;
   const float* ghs = gh + (size_t)s * 3 * H;
   {
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* 
   __syncthreads();
   if (tid < C) {                                              // class c = tile c / 16, row c % 16 = 4 g + e
     const int ct = tid >> 4, r = tid & 15, gg = r >> 2, e = r & 3;
-    sl[tid] = ((redh[0][ct][gg][e] + redh[1][ct][gg][e]) + (redh[2][ct][gg][e] + redh[3][ct][gg][e])) + bc[tid];
+    sl[tid] = ((redh[0][ct][gg][e] + redh[1][ct][gg][e]) + (redh[2][ct][gg][e] + redh[3][ct][gg][e])) + bc_t;
   }
   __syncthreads();
   if (q == 0) {
