@@ -323,7 +323,7 @@ def secondary(dev, lens, sd):
     ms = _time_ms(stream64, n=5, warm=2)
     eng.check()
     res["stream_step_us"] = ms * 1e3 / 64
-    # the streaming fast path (prego_miniroad_step: four launches per frame, state updated in place), 1 and 16 streams per call
+    # the streaming fast path (prego_miniroad_step: three / four launches per frame, state updated in place), 1 and 16 streams per call
     hs1 = torch.zeros((1, 1024), device=dev)
     outb, argb = torch.empty((16, 86), device=dev), torch.empty((16,), dtype=torch.int32, device=dev)
 
@@ -344,7 +344,7 @@ def secondary(dev, lens, sd):
     res["step16_us"] = ms * 1e3 / 64
     res["latency"] = {"clip256_ms": res["clip256_ms"], "stream_step_us": res["stream_step_us"], "step_us": res["step_us"],
                       "step16_us": res["step16_us"],
-                      "step_note": "prego_miniroad_step: one frame per call for 1 stream (zero flow) / 16 streams (rgb + flow), 4 launches, "
+                      "step_note": "prego_miniroad_step: one frame per call for 1 stream (zero flow, 3 launches) / 16 streams (rgb + flow, 4 launches), "
                                    "state in place; stream_step_us is the same through the general forward (h0 -> h_last)",
                       "note": "one 256-frame clip per call (zero flow): 256 sequential recurrence steps; streaming: one frame per "
                               "call, 6 kernel launches + host call overhead per frame, state through h_last -> h0"}

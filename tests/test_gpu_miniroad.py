@@ -256,7 +256,7 @@ def test_single_stream_models_no_rgb_no_flow(which):
 
 @pytest.mark.parametrize("n,zero_flow", [(1, False), (3, False), (4, False), (5, False), (16, False), (2, True)])
 def test_streaming_step_fast_path_vs_oracle_and_batched(n, zero_flow):
-    """prego_miniroad_step (four launches per frame, state carried by the caller): n streams fed frame by frame for T frames
+    """prego_miniroad_step (three launches per frame up to 4 streams, four above; state carried by the caller): n streams fed frame by frame for T frames
     equal MROAD.forward on the whole sequences - against the numpy oracle at the north-star tolerance for bf16 operands, and
     against the batched GPU path (same operand rounding, different summation order and fp32 instead of bf16 projection outputs)."""
     cfg = assembly101_cfg()
