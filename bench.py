@@ -206,7 +206,8 @@ def main():
                    "frac": gemm_tflops / peak, "traffic": traffic.get("gemm_bytes_per_launch"),
                    "avg_launch_ms": kt["gemm_ms"] / n_l, "launches": kt["gemm_launches"], "ms_per_step": kt["gemm_ms"] / args.steps}
         rl_gru = {"bound": "mfma", "kernel": "gru_recurrence_kernel (persistent, T sequential steps: latency-bound, see DESIGN.md section 5)",
-                  "achieved": gru_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gru_tflops / peak, "traffic": None,
+                  "achieved": gru_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gru_tflops / peak,
+                  "traffic": traffic.get("gru_bytes_per_launch"),      # HBM-side bytes (gi in, relu(h) out); the per-step hand-off stays in the XCDs' L2
                   "avg_launch_ms": kt["gru_ms"] / max(1, kt["gru_launches"]), "launches": kt["gru_launches"],
                   "ms_per_step": kt["gru_ms"] / args.steps, "us_per_timestep": kt["gru_ms"] / args.steps * 1e3 / max(lens),
                   "sequential_timesteps": max(lens)}

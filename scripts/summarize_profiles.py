@@ -37,8 +37,10 @@ if rows:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
     g = [r for r in rows if "gemm_bf16_nt" in r["kernel"]]
     p = [r for r in rows if "pack_rows" in r["kernel"]]
+    u = [r for r in rows if "gru_recurrence_kernel" in r["kernel"]]
     tot = lambda rs: sum((r["read_bytes_per_launch_corrected_x2"] + r["write_bytes_per_launch"]) * r["launches"] for r in rs) / max(1, sum(r["launches"] for r in rs))
-    json.dump({"source": f"profiles/{tag}_pmc_traffic.csv", "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p)},
+    json.dump({"source": f"profiles/{tag}_pmc_traffic.csv", "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p),
+               "gru_bytes_per_launch": tot(u)},
               open(os.path.join(dst, "traffic_latest.json"), "w"))
     for r in rows[:12]:
         print(r)
