@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             float gv = gelu_erf_(v);
             if (epi.drop_thresh) gv = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? gv * epi.drop_scale : 0.f;
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gv);
+          } else if constexpr (EPI == EPI_TOKENS) {                   // x[b, t] = v + pe[t], row m = b n_tok + t -> m + b
+            const int b = m / epi.n_tok, t = m - b * epi.n_tok;
+            ((float*)C)[(size_t)(m + b) * ldc + n] = v + epi.pe[(size_t)t * ldc + n];
           } else if constexpr (EPI == EPI_STORE_BF16) {
             ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
           } else {                                               // EPI_QKV: split into Q, K, V [B,h,Ntok,dh]
@@ -363,6 +366,7 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
     case EPI_RESIDUAL: GL(EPI_RESIDUAL); break;
     case EPI_GELU_BF16: GL(EPI_GELU_BF16); break;
     case EPI_STORE_BF16: GL(EPI_STORE_BF16); break;
+    case EPI_TOKENS: GL(EPI_TOKENS); break;
     default: GL(EPI_QKV); break;
   }
 #undef GL

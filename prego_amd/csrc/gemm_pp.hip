@@ -268,6 +268,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
             const float4 r0 = xr[0], r1 = xr[1];
             xr[0] = make_float4(r0.x + o[0], r0.y + o[1], r0.z + o[2], r0.w + o[3]);
             xr[1] = make_float4(r1.x + o[4], r1.y + o[5], r1.z + o[6], r1.w + o[7]);
+          } else if constexpr (EPI == EPI_TOKENS) {                     // token rows of the ViT residual stream: + pe[t], one row per window skipped
+            const int b = m / epi.n_tok, t = m - b * epi.n_tok;
+            const float4* pr = (const float4*)(epi.pe + (size_t)t * ldc + n);
+            const float4 p0 = pr[0], p1 = pr[1];
+            float4* xr = (float4*)(C + (size_t)(m + b) * ldc + n);
+            xr[0] = make_float4(o[0] + p0.x, o[1] + p0.y, o[2] + p0.z, o[3] + p0.w);
+            xr[1] = make_float4(o[4] + p1.x, o[5] + p1.y, o[6] + p1.z, o[7] + p1.w);
           } else if constexpr (EPI == EPI_QKV) {                        // 8 consecutive columns = one head, one of q / k / v
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
             const int blk = n / epi.emb, r = n - blk * epi.emb, which = blk + epi.which0;
@@ -326,6 +333,7 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_GELU_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     int d = 0;
     (void)hipGetDevice(&d);
     if (d >= 0 && d < 64) (void)hipGetSymbolAddress((void**)&zero_bias[d], HIP_SYMBOL(g_pp_zero_bias));
@@ -339,6 +347,7 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     case EPI_STORE_BF16: PPL(EPI_STORE_BF16); break;
     case EPI_RESIDUAL: PPL(EPI_RESIDUAL); break;
     case EPI_GELU_BF16: PPL(EPI_GELU_BF16); break;
+    case EPI_TOKENS: PPL(EPI_TOKENS); break;
     default: PPL(EPI_QKV); break;
   }
 #undef PPL

@@ -72,7 +72,7 @@ size_t gru_bptt_hx_bytes(bool bf16, int hid, int G);
 int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s);
 
 // GEMM epilogues (bf16 kernel): what happens to acc + bias
-enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU_BF16 = 2, EPI_STORE_BF16 = 3, EPI_QKV = 4 };
+enum { EPI_STORE = 0, EPI_RESIDUAL = 1, EPI_GELU_BF16 = 2, EPI_STORE_BF16 = 3, EPI_QKV = 4, EPI_TOKENS = 5 };
 struct GemmEpi {
   int mode;
   void* out_b;                 // bf16 output (EPI_GELU_BF16 / EPI_STORE_BF16), leading dim = ldc
@@ -86,6 +86,9 @@ struct GemmEpi {
   unsigned drop_thresh; float drop_scale; unsigned long long drop_seed;
   unsigned drop2_thresh; float drop2_scale; unsigned long long drop2_seed;   // a second, independent mask on the same value (proj_drop, Attention.py:19,40)
   float* pre_f32;              // EPI_GELU_BF16, training: the pre-activation W1 x + b1 in fp32 (gelu'), leading dim = ldc; nullable
+  // EPI_TOKENS (ViT.py:125-129 in the encoding GEMM's epilogue): GEMM row m = b n_tok + t goes to row m + b of C (one cls row per
+  // window is left for the caller) with the learned positional row pe[t] added: x[b, t] = W_enc f + b_enc + pe[t]
+  const float* pe;
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
@@ -174,6 +177,7 @@ void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, fl
 void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s);
 void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
                        unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
+void launch_vit_cls_rows(const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
                      const float* hb, int C, float* out, hipStream_t s);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);

@@ -31,6 +31,12 @@ __global__ void vit_tokens_kernel(const float* __restrict__ enc, const float* __
   }
 }
 
+// the cls row of every window: x[b, T] = cls + pe[T] (ViT.py:126-129; the frame rows come out of the encoding GEMM's epilogue)
+__global__ void vit_cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pe, int T, int E, float* __restrict__ x) {
+  float* xr = x + ((size_t)blockIdx.x * (T + 1) + T) * E;
+  for (int c = threadIdx.x; c < E; c += blockDim.x) xr[c] = cls[c] + pe[(size_t)T * E + c];
+}
+
 __global__ __launch_bounds__(256) void vit_head_kernel(const float* __restrict__ x, int N, int E, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, const float* __restrict__ hw,
                                                        const float* __restrict__ hb, int C, float* __restrict__ out) {
@@ -81,6 +87,9 @@ void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb
 void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
                        unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
   vit_tokens_kernel<<<B * (T + 1), 256, 0, s>>>(enc, cls, pe, B, T, E, x, drop_thresh, drop_scale, drop_seed);
+}
+void launch_vit_cls_rows(const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s) {
+  vit_cls_rows_kernel<<<B, 256, 0, s>>>(cls, pe, T, E, x);
 }
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
                      const float* hb, int C, float* out, hipStream_t s) {

@@ -235,8 +235,18 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   const int causal = (flags & 1) ? 1 : 0;
   const bool all_rows = (flags & 2) != 0;             // bit 1 (debug / A-B): run the last block on every token as well
   launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
-  launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);   // ViT.py:125
-  launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);              // ViT.py:126-129
+  // ViT.py:125-129: the encoding GEMM writes the residual stream itself (frame rows + positional rows in its epilogue: no fp32
+  // encoding tensor, no token kernel pass); the cls row of every window is B short rows
+  static const bool no_epi_tokens = getenv("PREGO_VIT_TOKENS_KERNEL") != nullptr;       // A/B: the separate token kernel
+  if (no_epi_tokens || B * T < 4096) {       // small batches: the 128 x 128 kernel's per-element epilogue costs more than the token kernel
+    launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);
+    launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);
+  } else {
+    GemmEpi te{};
+    te.mode = EPI_TOKENS; te.pe = h->pe; te.n_tok = T;
+    launch_gemm_bf16_nt_epi(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.x), E, B * T, E, din, te, s);
+    launch_vit_cls_rows(h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);
+  }
   for (int li = 0; li < h->layers; ++li) {
     const bool last = li + 1 == h->layers && !all_rows;
     const int rc = last ? encoder_block_token0(h, h->L[li], (const float*)(ws + w.x), ws, w, B, N, causal, s)
