@@ -41,7 +41,7 @@
 
 #define SPIN_LIMIT (1u << 22)
 #ifndef GRU_NSEG
-#define GRU_NSEG 4                           // segments of the gather validated and multiplied one after the other
+#define GRU_NSEG 2                           // segments of the gather validated and multiplied one after the other (A/B at the end of round 2, per launch: 1: 1.434, 2: 1.413, 4: 1.434, 8: 1.588 ms)
 #endif
 #define GRU_MAX_TILES 8                      // clip tiles per group the exchange buffer is laid out for (128 slots)
 
