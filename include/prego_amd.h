@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define PREGO_ABI_VERSION 1
+/* 1: round 1.  2: round 2 entry points (step, adamw, vit, attention layer, window vote) and the grown forward workspace.
+ * 3: round 3 (fp16 operand mode, device AP, window_vote marks windows with an id outside [0, n_classes) as -1). */
+#define PREGO_ABI_VERSION 3
 
 enum {
   PREGO_OK = 0,
@@ -149,7 +151,8 @@ int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens,
 /* utils/aggregate.py:55-72 on the device: the per-frame argmax of ONE video (device int32 [n_frames], as prego_miniroad_forward
  * writes it) is cut into consecutive windows of `window` frames (the reference uses 200; the last one may be shorter) and every
  * window votes for its most frequent class, the lowest class id winning a tie (np.argmax(np.bincount(.))).
- * votes: device int32 [ceil(n_frames / window)].  n_classes <= 128.  The de-duplication / change lists of aggregate.py:75-78
+ * votes: device int32 [ceil(n_frames / window)].  n_classes <= 128; a window that holds an id outside [0, n_classes) votes -1
+ * (np.bincount raises on a negative id; the host wrapper turns the marker into an error).  The de-duplication / change lists of aggregate.py:75-78
  * then run over one value per window instead of one per frame. */
 int prego_window_vote(const int32_t* argmax, int64_t n_frames, int window, int n_classes, int32_t* votes, prego_stream_t stream);
 

@@ -64,6 +64,9 @@ def aggregate_device(preds: dict, gts: dict, output_path: str | None = None, win
     out = {}
     for key, (v, T) in votes.items():
         w = v.cpu().numpy()
+        if (w < 0).any():
+            raise PregoError(f"aggregate_device: pred[{key!r}] holds a class id outside [0, {n_classes}) "
+                             "(np.bincount of utils/aggregate.py:60 would raise / count a class the model does not have)")
         gt = list(gts[key])
         # the per-frame sequence is constant inside a window: duplicates and change points follow from the window values
         keep = np.concatenate(([True], w[1:] != w[:-1]))

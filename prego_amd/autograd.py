@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import torch
 
+from ._lib import PregoError
 from .engine import _PARAM_ORDER, oad_loss
 
 
@@ -15,11 +16,17 @@ class _MiniRoadTrainFn(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.layer1[3].p > 0 else 0   # torch RNG drives the mask seed
         eng.set_dropout(model.layer1[3].p, seed)
         out = eng.forward_train(rgb, flow)
-        ctx.eng = eng
+        # the kept activations and the dropout seed live in the engine (one workspace per model): a second training forward
+        # before this one's backward overwrites them, so every forward takes a generation number and backward checks it
+        eng._train_gen = getattr(eng, "_train_gen", 0) + 1
+        ctx.eng, ctx.gen = eng, eng._train_gen
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if getattr(ctx.eng, "_train_gen", 0) != ctx.gen:
+            raise PregoError("MiniROAD backward: another training forward ran on this model since the forward of this graph; its kept "
+                             "activations were overwritten (run backward before the next forward, or use torch.no_grad() / eval() for it)")
         grads = ctx.eng.backward(dout)
         return (None, None, None) + tuple(grads[k] for k in _PARAM_ORDER)
 

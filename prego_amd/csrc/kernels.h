@@ -145,7 +145,7 @@ int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, cons
                        int relu = 1, int accumulate = 0);
 
 // post-processing (postproc.hip)
-int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, int* bad, hipStream_t s);
+int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, hipStream_t s);
 
 // fused multi-tensor AdamW (optim.hip)
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,

@@ -353,6 +353,8 @@ static SlotPlan device_plan(const prego_miniroad* h) {
 
 // Stage the per-call pointer table (and, when the plan changed, the plan arrays) through the handle's pinned buffer.
 // `tab4` = 4 * max_clips pointers.  The previous call's copies are fenced by pin_ev before the buffer is rewritten.
+// The host blocks here until the PREVIOUS call's table copies have left the pinned buffer: CPU run-ahead is one call deep
+// (a second forward() can be enqueued while the first runs, a third waits for the first's H2D copies, not for its kernels).
 static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_count, hipStream_t s) {
   if (h->pin_busy) { HIPCHK(hipEventSynchronize(h->pin_ev)); h->pin_busy = false; }
   const size_t smax = (size_t)h->t_max, S = (size_t)h->n_slots, n = h->h_seg_clip.size();
@@ -566,6 +568,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   };
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
+  // every exit path after a fork joins the side stream: an error return while the next chunk's pack is still writing X / RM
+  // would leave the caller's stream unordered against it (the next forward on this handle could race with that pack)
+  struct SideJoin {
+    prego_miniroad* h; bool pending = false;
+    ~SideJoin() { if (pending) (void)hipStreamSynchronize(h->side); }
+  } side_join{h};
   int t0 = 0, ci = 0;             // ci: chunk counter (parity of the row-map half)
   while (t0 < h->t_max) {
     const int base = h->h_rowoff[t0];
@@ -603,6 +611,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       // resident (placement rendezvous) before the copy's workgroups fill the wave slots
       HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
+      side_join.pending = true;
       HIPCHK(hipEventRecord(h->ev_join, h->side));
       packed = true;
     }
@@ -612,7 +621,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                               (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s, RM + (size_t)(ci & 1) * cap_rows * 8))
         return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
     }
-    if (packed) HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    if (packed) { HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0)); side_join.pending = false; }
     t0 = t1;
     ++ci;
   }
@@ -943,7 +952,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
 extern "C" int prego_window_vote(const int32_t* argmax, int64_t n_frames, int window, int n_classes, int32_t* votes,
                                  prego_stream_t stream) {
   if (!argmax || !votes) return fail(PREGO_EINVAL, "window_vote: NULL argument");
-  if (launch_window_vote(argmax, n_frames, window, n_classes, votes, nullptr, (hipStream_t)stream))
+  if (launch_window_vote(argmax, n_frames, window, n_classes, votes, (hipStream_t)stream))
     return fail(PREGO_EINVAL, "window_vote: n_frames %lld, window %d, n_classes %d (1..128)", (long long)n_frames, window, n_classes);
   HIPCHK(hipGetLastError());
   return PREGO_OK;

@@ -17,7 +17,9 @@ struct AdamDesc {
   void* copy;                 // nullable: operand copy of the updated parameter
   long long n;
   int block0;                 // first block of this tensor
-  int copy_bf16;
+  short copy_bf16;
+  short vec;                  // 16-byte accesses allowed: n % 4 == 0 and every base pointer 16-byte aligned (checked on the host:
+                              // the generic ABI takes arbitrary pointers, e.g. views at odd storage offsets)
 };
 struct AdamTable { AdamDesc d[ADAM_MAX_TENSORS]; int n; };
 
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float lr, flo
     const long long i = base + ((long long)u * 256 + threadIdx.x) * 4;
     if (i >= d.n) break;
     float pv[4], gv[4], mv[4], vv[4];
-    const bool full = i + 4 <= d.n && ((d.n & 3) == 0);          // 16-byte path: tensors whose size is a multiple of 4 floats
+    const bool full = d.vec != 0 && i + 4 <= d.n;                  // 16-byte path (size a multiple of 4 floats, aligned bases)
     if (full) {
       const float4 a = *(const float4*)(d.p + i), b = *(const float4*)(d.g + i), c = *(const float4*)(d.m + i), e = *(const float4*)(d.v + i);
       pv[0] = a.x; pv[1] = a.y; pv[2] = a.z; pv[3] = a.w; gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
@@ -85,7 +87,11 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
     for (int i = 0; i < tab.n; ++i) {
       const int k = t0 + i;
       if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k] || numel[k] <= 0) return -1;
-      tab.d[i] = AdamDesc{params[k], grads[k], exp_avg[k], exp_avg_sq[k], copies ? copies[k] : nullptr, numel[k], blocks, copy_bf16 ? 1 : 0};
+      void* cp = copies ? copies[k] : nullptr;
+      const uintptr_t bits = (uintptr_t)params[k] | (uintptr_t)grads[k] | (uintptr_t)exp_avg[k] | (uintptr_t)exp_avg_sq[k] | (uintptr_t)cp;
+      const short vec = ((bits & 15) == 0 && (numel[k] & 3) == 0) ? 1 : 0;
+      if (bits & 3) return -1;                                   // not even float-aligned
+      tab.d[i] = AdamDesc{params[k], grads[k], exp_avg[k], exp_avg_sq[k], cp, numel[k], blocks, (short)(copy_bf16 ? 1 : 0), vec};
       blocks += (int)((numel[k] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK);
     }
     adamw_kernel<<<blocks, 256, 0, s>>>(tab, lr, b1, b2, eps, wd, bc1, bc2_sqrt);

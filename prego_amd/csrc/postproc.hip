@@ -10,12 +10,14 @@
 #define VOTE_MAX_CLASSES 128
 
 __global__ __launch_bounds__(256) void window_vote_kernel(const int* __restrict__ pred, long long n_frames, int window, int n_classes,
-                                                          int* __restrict__ votes, int* __restrict__ bad /*nullable: set to 1 on an id out of range*/) {
+                                                          int* __restrict__ votes) {
   __shared__ int hist[4][VOTE_MAX_CLASSES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long n_win = (n_frames + window - 1) / window;
   for (long long w0 = (long long)blockIdx.x * 4; w0 < n_win; w0 += (long long)gridDim.x * 4) {   // block-uniform trip count
     const long long w = w0 + wave;
+    bool bad_id = false;                      // an id outside [0, n_classes): np.bincount would raise (negative) or count a class the
+                                              // model does not have - the window votes -1 and the host turns that into an error
     hist[wave][lane] = 0; hist[wave][lane + 64] = 0;
     __syncthreads();
     if (w < n_win) {
@@ -24,7 +26,7 @@ __global__ __launch_bounds__(256) void window_vote_kernel(const int* __restrict_
       for (long long i = s + lane; i < e; i += 64) {
         const int c = pred[i];
         if (c >= 0 && c < n_classes) atomicAdd(&hist[wave][c], 1);
-        else if (bad) *bad = 1;
+        else bad_id = true;
       }
     }
     __syncthreads();
@@ -38,17 +40,18 @@ __global__ __launch_bounds__(256) void window_vote_kernel(const int* __restrict_
         const int oc = __shfl_xor(best_cnt, off, 64), oi = __shfl_xor(best_id, off, 64);
         if (oc > best_cnt || (oc == best_cnt && oi < best_id)) { best_cnt = oc; best_id = oi; }
       }
+      if (__any(bad_id)) best_id = -1;
       if (lane == 0) votes[w] = best_id;
     }
     __syncthreads();
   }
 }
 
-int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, int* bad, hipStream_t s) {
+int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, hipStream_t s) {
   if (n_frames <= 0 || window <= 0 || n_classes <= 0 || n_classes > VOTE_MAX_CLASSES) return -1;
   const long long n_win = (n_frames + window - 1) / window;
   long long blocks = (n_win + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-  window_vote_kernel<<<(int)blocks, 256, 0, s>>>(pred, n_frames, window, n_classes, votes, bad);
+  window_vote_kernel<<<(int)blocks, 256, 0, s>>>(pred, n_frames, window, n_classes, votes);
   return 0;
 }

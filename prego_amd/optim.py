@@ -50,9 +50,7 @@ class FusedAdamW(torch.optim.Optimizer):
             steps = {int(st["step"].item()) for st in states}
             if len(steps) != 1:
                 raise PregoError("FusedAdamW: parameters of one group must share the step count")
-            step = steps.pop() + 1
-            for st in states:
-                st["step"] += 1
+            step = steps.pop() + 1               # st['step'] moves only after the launch below was accepted
             grads = [p.grad.contiguous() for p in ps]
             dev = ps[0].device
             b1, b2 = group["betas"]
@@ -85,15 +83,21 @@ class FusedAdamW(torch.optim.Optimizer):
                         self._vit._h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
                         ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
                         len(ps), *hyper, C.c_void_p(_stream_ptr(dev))))
-                    # parameter versions did not move and the handle's copies are those of the new values: no re-ingest
+                    # raw-pointer update: bump the versions (autograd's in-place check, caches keyed on (data_ptr, _version)),
+                    # then record the new versions as the ones the handle's copies belong to, so that the re-ingest is still skipped
+                    torch._C._increment_version(ps)
+                    sd = dict(self._vit.named_parameters())
+                    self._vit._ver = tuple((p.data_ptr(), p._version) for p in sd.values())
                 elif fused_model:
                     eng = m.engine()        # weights already ingested (versions unchanged since the forward)
                     check(lib.prego_miniroad_adamw_step(
                         eng.h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
                         ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
                         *hyper, C.c_void_p(_stream_ptr(dev))))
-                    # the engine's operand copies are now those of the NEW values; parameter versions did not move, so
-                    # model.engine() will not re-ingest them
+                    # the engine's operand copies are now those of the NEW values: bump the parameter versions (raw-pointer
+                    # update) and record them as ingested, so model.engine() does not re-ingest
+                    torch._C._increment_version(ps)
+                    m._w_versions = tuple((p.data_ptr(), p._version) for p in m.parameters())
                 else:
                     numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
                     check(lib.prego_adamw_step(
@@ -101,4 +105,6 @@ class FusedAdamW(torch.optim.Optimizer):
                         ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
                         numel, *hyper, C.c_void_p(_stream_ptr(dev))))
                     torch._C._increment_version(ps)      # raw-pointer update: tell autograd / the weight caches the values moved
+            for st in states:
+                st["step"] += 1
         return loss

@@ -175,13 +175,18 @@ class _ViTTrainFn(torch.autograd.Function):
             check(lib.prego_vit_forward_train(model._h, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
                                               C.c_void_p(out.data_ptr()), 1 if model.causal else 0,
                                               C.c_void_p(model._ws_train.data_ptr()), model._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))
-        ctx.model, ctx.B, ctx.keep = model, B, (rgb, flow)
+        # activations and mask seeds live in the model's one training workspace / handle: generation-checked in backward
+        model._train_gen = getattr(model, "_train_gen", 0) + 1
+        ctx.model, ctx.B, ctx.keep, ctx.gen = model, B, (rgb, flow), model._train_gen
         ctx.shapes = [tuple(p.shape) for p in params]
         return out
 
     @staticmethod
     def backward(ctx, dout):
         model, B = ctx.model, ctx.B
+        if getattr(model, "_train_gen", 0) != ctx.gen:
+            raise PregoError("ViTEnc backward: another training forward ran on this model since the forward of this graph; its kept "
+                             "activations and dropout seeds were overwritten (run backward before the next forward)")
         lib = _lib.load()
         dev = dout.device
         dout = dout.float().contiguous()
