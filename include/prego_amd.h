@@ -39,8 +39,10 @@ enum {
   PREGO_ETIMEOUT = -4      /* the persistent recurrence kernel gave up waiting (reported by _check) */
 };
 
-/* arithmetic type of the MFMA operands; accumulation, GRU state, LayerNorm and softmax are always fp32 */
-enum { PREGO_F32 = 0, PREGO_BF16 = 1 };
+/* MFMA operand type of a handle.  Accumulators, GRU state, gate math, LayerNorm statistics and softmax are fp32 in every mode.
+ * PREGO_F16: IEEE fp16 operands and 16-bit intermediates - the same matrix rate and bytes as bf16 with 8x less operand rounding
+ * (values beyond +-65504 saturate); inference entry points only (forward without PREGO_FWD_KEEP, step). */
+enum { PREGO_F32 = 0, PREGO_BF16 = 1, PREGO_F16 = 2 };
 
 /* forward() flags */
 enum {

@@ -12,7 +12,7 @@ from .engine import _PARAM_ORDER, oad_loss
 class _MiniRoadTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, rgb, flow, *params):
-        eng = model.engine()
+        eng = model.engine(train=True)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if model.layer1[3].p > 0 else 0   # torch RNG drives the mask seed
         eng.set_dropout(model.layer1[3].p, seed)
         out = eng.forward_train(rgb, flow)

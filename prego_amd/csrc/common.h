@@ -31,6 +31,47 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_v_){lo, hi}, bf16x2_v_));
 }
 
+// ---- 16-bit MFMA operand types ---------------------------------------------------------------------------------------
+// bf16 (8 mantissa bits, fp32 range) or IEEE fp16 (11 mantissa bits, |x| <= 65504): the matrix pipe runs both at the same rate
+// and every kernel accumulates in fp32, so fp16 operands cut the operand rounding error 8x at no cost in time (profiles/
+// precision_study_r03.json: bf16 operands flip 9 argmaxes above a 1e-3 margin on the fixtures, fp16 operands none).  Memory is raw
+// 16-bit words either way (bf16_t pointers); the tag type OT only selects conversions and the MFMA opcode.
+typedef _Float16 f16_t;                                       // fp16 operand tag (distinct from bf16_t = unsigned short)
+typedef _Float16 f16x8_v_ __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_v_ __attribute__((ext_vector_type(2)));
+#define PREGO_F16_MAX 65504.0f
+template <typename OT> struct op16;
+template <> struct op16<bf16_t> {
+  static constexpr bool is_f16 = false;
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+  static __device__ __forceinline__ unsigned pack2_sat(float lo, float hi) { return pack_bf16x2(lo, hi); }   // fp32 range: nothing to saturate
+  static __device__ __forceinline__ bf16_t cvt(float x) { return f2bf(x); }
+  static __device__ __forceinline__ bf16_t cvt_sat(float x) { return f2bf(x); }
+  static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xFFFF0000u); }
+  static __device__ __forceinline__ float up(bf16_t b) { return bf2f(b); }
+  static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct op16<f16_t> {
+  static constexpr bool is_f16 = true;
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) {        // one v_cvt_pk_f16_f32 (RNE); caller guarantees the range
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_v_){lo, hi}, f16x2_v_));
+  }
+  static __device__ __forceinline__ unsigned pack2_sat(float lo, float hi) {    // saturate instead of overflowing to inf
+    return pack2(__builtin_amdgcn_fmed3f(lo, -PREGO_F16_MAX, PREGO_F16_MAX), __builtin_amdgcn_fmed3f(hi, -PREGO_F16_MAX, PREGO_F16_MAX));
+  }
+  static __device__ __forceinline__ bf16_t cvt(float x) { return __builtin_bit_cast(bf16_t, (_Float16)x); }
+  static __device__ __forceinline__ bf16_t cvt_sat(float x) { return cvt(__builtin_amdgcn_fmed3f(x, -PREGO_F16_MAX, PREGO_F16_MAX)); }
+  static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2_v_, w)[0]; }
+  static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2_v_, w)[1]; }
+  static __device__ __forceinline__ float up(bf16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+  static __device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v_, a), __builtin_bit_cast(f16x8_v_, b), c, 0, 0, 0);
+  }
+};
+// operand tag of an output element type: float stays float, 16-bit types name themselves
+template <typename T> struct is_op16 { static constexpr bool value = sizeof(T) == 2; };
+
 // streaming (read-once) 16-byte load
 __device__ __forceinline__ float4 nt_load4(const float* p) {
   const f32x4 v = __builtin_nontemporal_load((const f32x4*)p);

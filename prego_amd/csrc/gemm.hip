@@ -27,7 +27,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 // exact (erf) GELU = nn.GELU() default (Transformer.py:40)
 
-template <typename OutT, int EPI>
+template <typename OutT, int EPI, typename OT = bf16_t>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
     OutT* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = op16<OT>::mfma(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
         if (m < M) {
           float v = acc[i][j][e] + bv;
           if constexpr (EPI == EPI_STORE) {
-            if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = f2bf(v);
+            if constexpr (sizeof(OutT) == 2) C[(size_t)m * ldc + n] = op16<OT>::cvt_sat(v);
             else C[(size_t)m * ldc + n] = v;
           } else if constexpr (EPI == EPI_RESIDUAL) {                 // x += v  (fp32 residual stream, in place)
             if (epi.drop_thresh) v = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? v * epi.drop_scale : 0.f;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
             ((float*)C)[(size_t)(m + b) * ldc + n] = v + epi.pe[(size_t)t * ldc + n];
           } else if constexpr (EPI == EPI_STORE_BF16) {
-            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(v);
+            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = op16<OT>::cvt_sat(v);
           } else {                                               // EPI_QKV: split into Q, K, V [B,h,Ntok,dh]
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
             const int blk = n / epi.emb, r = n - blk * epi.emb, which = blk + epi.which0;
@@ -355,6 +355,18 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
     if (launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, cdst, ldc, M, N, K, epi, s) == 0) return;
   }
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
+  if (epi.f16) {                 // fp16 operands (MiniROAD inference projections): plain and 16-bit stores only
+    static DeviceOnce once16;
+    once16.run([] {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, EPI_STORE, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, EPI_STORE_BF16, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    });
+    if (epi.mode == EPI_STORE_BF16)
+      gemm_bf16_nt_kernel<float, EPI_STORE_BF16, f16_t><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi);
+    else
+      gemm_bf16_nt_kernel<float, EPI_STORE, f16_t><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi);
+    return;
+  }
 #define GL(E)                                                                                                   \
   do {                                                                                                          \
     static DeviceOnce once;                                                                                     \

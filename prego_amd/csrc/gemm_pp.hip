@@ -50,7 +50,8 @@ __device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >>
 // layer1 and W_ih projections in bf16 between the kernels), and the Transformer path's fused epilogues EPI_RESIDUAL (fp32
 // x += .), EPI_GELU_BF16 (bf16(gelu(.))), EPI_QKV (head split into Q, K [B,h,N,dh] and V^T [B,h,dh,Npad]).  A lane holds 8
 // consecutive columns of a row, so every epilogue but V^T's is 16-byte vector accesses.
-template <int EPI>
+// OT = operand type tag (common.h: bf16_t or f16_t): selects the MFMA opcode and the 16-bit output conversion only.
+template <int EPI, typename OT = bf16_t>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][j], af[ks][i], c[i][j], 0, 0, 0);   // D^T: see epilogue
+        for (int j = 0; j < 2; ++j) c[i][j] = op16<OT>::mfma(bf[ks][j], af[ks][i], c[i][j]);   // D^T: see epilogue
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
               }
             }
             uint4 pk;
-            pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+            pk.x = op16<OT>::pack2_sat(o[0], o[1]); pk.y = op16<OT>::pack2_sat(o[2], o[3]); pk.z = op16<OT>::pack2_sat(o[4], o[5]); pk.w = op16<OT>::pack2_sat(o[6], o[7]);
             bf16_t* ob = EPI == EPI_GELU_BF16 ? (bf16_t*)epi.out_b : (bf16_t*)Cv;
             *(uint4*)(ob + (size_t)m * ldc + n) = pk;
           } else if constexpr (EPI == EPI_RESIDUAL) {                  // fp32 residual stream, in place
@@ -334,6 +335,8 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_GELU_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     int d = 0;
     (void)hipGetDevice(&d);
     if (d >= 0 && d < 64) (void)hipGetSymbolAddress((void**)&zero_bias[d], HIP_SYMBOL(g_pp_zero_bias));
@@ -342,6 +345,12 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
   if (!bias) return -1;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
 #define PPL(E) gemm_bf16_nt_pingpong_kernel<E><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi)
+  if (epi.f16) {                 // fp16 operands: the MiniROAD projections only (fp32 or fp16 C)
+    if (epi.mode == EPI_STORE) gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
+    else if (epi.mode == EPI_STORE_BF16) gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
+    else return -1;
+    return 0;
+  }
   switch (epi.mode) {
     case EPI_STORE: PPL(EPI_STORE); break;
     case EPI_STORE_BF16: PPL(EPI_STORE_BF16); break;
@@ -356,10 +365,11 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
 
 // fp32 or bf16 C with the bias epilogue (the MiniROAD projections); bias must not be NULL here
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
-                                   int M, int N, int K, bool out_bf16, hipStream_t s) {
+                                   int M, int N, int K, bool out_bf16, hipStream_t s, bool f16) {
   (void)mode;
   if (bias == nullptr) return -1;
   GemmEpi epi{};
+  epi.f16 = f16 ? 1 : 0;
   epi.mode = out_bf16 ? EPI_STORE_BF16 : EPI_STORE;
   return launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, epi, s);
 }

@@ -48,17 +48,17 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 
-// two floats -> packed bf16x2 (one v_cvt_pk_bf16_f32)
-__device__ __forceinline__ unsigned cvt_pk_bf16(f32x2 v) {
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
+// operand tag of the weight type: the 16-bit types name themselves, fp32 weights never reach the 16-bit conversions
+template <typename WT> struct gru_ot { typedef bf16_t type; };
+template <> struct gru_ot<f16_t> { typedef f16_t type; };
 
 // TRAIN: also store the gate activations / raw state BPTT needs (a.keep_*, a.h_raw_out); the inference instantiation
 // carries none of that code or its registers.
 // GI16: the input projection rows (a.gi) are bf16 (inference path with bf16 intermediates)
 template <typename WT, int HID, int UT, int NCT, bool TRAIN, bool GI16 = false>
 __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
-  constexpr bool BF = (sizeof(WT) == 2);
+  constexpr bool BF = (sizeof(WT) == 2);          // 16-bit operands: bf16_t or f16_t (same layout, same tag bit 14: |h| < 2 in both)
+  typedef typename gru_ot<WT>::type OT;
   constexpr int UNITS = 16 * UT;              // hidden units owned by this workgroup
   constexpr int KQ = HID / 4;                 // K range per wave
   constexpr int OWN_R = UT == 2 ? 2 : 1;      // accumulator registers a lane owns per clip tile (4 waves share UT tiles)
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
       f32x2 hv = {zero ? 0.f : hreg[ct][0], zero ? 0.f : hreg[ct][1]};
       hv[0] = __builtin_amdgcn_fmed3f(hv[0], -1.9921875f, 1.9921875f);
       hv[1] = __builtin_amdgcn_fmed3f(hv[1], -1.9921875f, 1.9921875f);
-      const unsigned v = (cvt_pk_bf16(hv) & 0xBFFFBFFFu) | (tag ? 0x40004000u : 0u);
+      const unsigned v = (op16<OT>::pack2(hv[0], hv[1]) & 0xBFFFBFFFu) | (tag ? 0x40004000u : 0u);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
     } else {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
                 for (int ut = 0; ut < UT; ++ut)
-                  acc[gate][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut], 0, 0, 0);
+                  acc[gate][ut] = op16<OT>::mfma(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut]);
             } else {
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               f32x2 gr, gz, gn;
               if constexpr (GI16) {          // one dword = the bf16 pair of my two units
                 const unsigned ur = __float_as_uint(gir[ct][0][0]), uz = __float_as_uint(gir[ct][1][0]), un = __float_as_uint(gir[ct][2][0]);
-                gr = (f32x2){__uint_as_float(ur << 16), __uint_as_float(ur & 0xFFFF0000u)};
-                gz = (f32x2){__uint_as_float(uz << 16), __uint_as_float(uz & 0xFFFF0000u)};
-                gn = (f32x2){__uint_as_float(un << 16), __uint_as_float(un & 0xFFFF0000u)};
+                gr = (f32x2){op16<OT>::lo(ur), op16<OT>::hi(ur)};
+                gz = (f32x2){op16<OT>::lo(uz), op16<OT>::hi(uz)};
+                gn = (f32x2){op16<OT>::lo(un), op16<OT>::hi(un)};
               } else {
                 gr = (f32x2){gir[ct][0][0], gir[ct][0][1]}; gz = (f32x2){gir[ct][1][0], gir[ct][1][1]}; gn = (f32x2){gir[ct][2][0], gir[ct][2][1]};
               }
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             if (sidx[ct] < na) {
 #pragma unroll
               for (int e = 0; e < OWN_R; ++e) {
-                const float g_r = GI16 ? __uint_as_float(__float_as_uint(gir[ct][0][e]) << 16) : gir[ct][0][e];
-                const float g_z = GI16 ? __uint_as_float(__float_as_uint(gir[ct][1][e]) << 16) : gir[ct][1][e];
-                const float g_n = GI16 ? __uint_as_float(__float_as_uint(gir[ct][2][e]) << 16) : gir[ct][2][e];
+                const float g_r = GI16 ? op16<OT>::lo(__float_as_uint(gir[ct][0][e])) : gir[ct][0][e];
+                const float g_z = GI16 ? op16<OT>::lo(__float_as_uint(gir[ct][1][e])) : gir[ct][1][e];
+                const float g_n = GI16 ? op16<OT>::lo(__float_as_uint(gir[ct][2][e])) : gir[ct][2][e];
                 const float r = sigmoidf_(g_r + gh[0][e]);
                 const float z = sigmoidf_(g_z + gh[1][e]);
                 const float ghn = gh[2][e] + bhn[e];
@@ -470,8 +470,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           if (a.h_relu_out) {
             if constexpr (BF) {
               bf16_t* p = (bf16_t*)a.h_relu_out + o;
-              if constexpr (OWN_R == 2) *(unsigned*)p = cvt_pk_bf16((f32x2){fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f)});
-              else p[0] = f2bf(fmaxf(hreg[ct][0], 0.f));
+              if constexpr (OWN_R == 2) *(unsigned*)p = op16<OT>::pack2(fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f));
+              else p[0] = op16<OT>::cvt(fmaxf(hreg[ct][0], 0.f));
             } else {
               float* p = (float*)a.h_relu_out + o;
 #pragma unroll
@@ -552,7 +552,13 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
     else if (a.gi_bf16) gru_recurrence_kernel<WT, 1024, UT, NCT, false, true><<<grid, 256, lds, s>>>(a); \
     else gru_recurrence_kernel<WT, 1024, UT, NCT, false><<<grid, 256, lds, s>>>(a);                    \
   } while (0)
-  if (bf16) {
+  if (bf16 && a.f16) {
+    if (train) return -1;                    // fp16 operands: inference only (training runs on bf16 / fp32 handles)
+    if (nct == 1) LAUNCH(f16_t, 2, 1);
+    else if (nct == 2) LAUNCH(f16_t, 2, 2);
+    else if (nct <= 4) LAUNCH(f16_t, 2, 4);
+    else return -1;
+  } else if (bf16) {
     if (nct == 1) LAUNCH(bf16_t, 2, 1);
     else if (nct == 2) LAUNCH(bf16_t, 2, 2);
     else if (nct <= 4) LAUNCH(bf16_t, 2, 4);

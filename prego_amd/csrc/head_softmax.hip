@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
       for (int j = 0; j < NTC; ++j) {
         const bf16x8 bfr = *(const bf16x8*)(bp + (size_t)j * 16 * HID + k);
 #pragma unroll
-        for (int m = 0; m < HM; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr, acc[m][j], 0, 0, 0);
+        for (int m = 0; m < HM; ++m) acc[m][j] = op16<WT>::mfma(af[m], bfr, acc[m][j]);
       }
     }
   } else {
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(
 // registers and the frame on the lane, softmax / argmax are in-register over 4 NTC values + two shuffles, and the
 // probabilities leave as 16-byte stores of four consecutive classes.  The partials are added in K order (bit-reproducible).
 // ------------------------------------------------------------------------------------------------------
-template <int NTC>
+template <int NTC, typename OT = bf16_t>
 __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
     const bf16_t* __restrict__ Hrelu, const bf16_t* __restrict__ Wc, const float* __restrict__ bc, SlotPlan plan, int row0,
     int nrows, int C, int apply_softmax, float* const* __restrict__ out_ptrs, int* const* __restrict__ argmax_ptrs,
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < NTC; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[j][ks], cur[t][ks], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < NTC; ++j) acc[t][j] = op16<OT>::mfma(wc[j][ks], cur[t][ks], acc[t][j]);
     // K-quarter partials -> LDS (a wave keeps the partial of the frame tile it finishes itself)
     f32x4* pw = part + parity * PSTRIDE;
     if (q != 0) {
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
 
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
                         int row0, int nrows, int hid, int C, int apply_softmax,
-                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap) {
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap, bool f16) {
   if (nrows <= 0) return 0;
   const int ntc = (C + 15) / 16;
   static const bool no_v2 = getenv("PREGO_HEAD_V1") != nullptr;                // A/B knob
@@ -339,8 +339,11 @@ int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const floa
   case N: {                                                                                                         \
     const size_t lds = (size_t)2 * 4 * 2 * N * 64 * 16;                                                             \
     static DeviceOnce once;                                                                                         \
-    once.run([&] { (void)hipFuncSetAttribute((const void*)head_softmax_v2_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-    head_softmax_v2_kernel<N><<<grid2, 256, lds, s>>>((const bf16_t*)Hrelu, (const bf16_t*)Wc, bc, plan, row0, nrows, C,  \
+    once.run([&] { (void)hipFuncSetAttribute((const void*)head_softmax_v2_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+                   (void)hipFuncSetAttribute((const void*)head_softmax_v2_kernel<N, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+    if (f16) head_softmax_v2_kernel<N, f16_t><<<grid2, 256, lds, s>>>((const bf16_t*)Hrelu, (const bf16_t*)Wc, bc, plan, row0, nrows, C,  \
+                                                                     apply_softmax, out_ptrs, argmax_ptrs, (const int2*)rowmap);    \
+    else head_softmax_v2_kernel<N><<<grid2, 256, lds, s>>>((const bf16_t*)Hrelu, (const bf16_t*)Wc, bc, plan, row0, nrows, C,  \
                                                       apply_softmax, out_ptrs, argmax_ptrs, (const int2*)rowmap);    \
     return 0;                                                                                                       \
   }
@@ -353,7 +356,8 @@ int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const floa
                                                   hid, C, apply_softmax, out_ptrs, argmax_ptrs)
 #define HD(N)                          \
   case N:                              \
-    if (bf16) HL(bf16_t, N);           \
+    if (bf16 && f16) HL(f16_t, N);     \
+    else if (bf16) HL(bf16_t, N);      \
     else HL(float, N);                 \
     break
   switch (ntc) {

@@ -51,6 +51,7 @@ struct GruArgs {
   unsigned* sync;              // [16] placement rendezvous words (8 per-XCD tickets + total), zeroed per launch; nullable
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
   int gi_bf16;                 // gi rows are bf16 (inference path with bf16 intermediates)
+  int f16;                     // 16-bit operands / intermediates are IEEE fp16 instead of bf16 (launch_gru_recurrence picks the instantiation)
 };
 
 // persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward
@@ -89,22 +90,24 @@ struct GemmEpi {
   // EPI_TOKENS (ViT.py:125-129 in the encoding GEMM's epilogue): GEMM row m = b n_tok + t goes to row m + b of C (one cls row per
   // window is left for the caller) with the learned positional row pe[t] added: x[b, t] = W_enc f + b_enc + pe[t]
   const float* pe;
+  int f16;                     // operands (and a 16-bit output) are IEEE fp16 instead of bf16 (EPI_STORE / EPI_STORE_BF16 only)
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
 
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
                       int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0,
-                      void* rowmap = nullptr /* int2 [nrows]: (clip, frame) of every packed row, for the head kernel */);
+                      void* rowmap = nullptr /* int2 [nrows]: (clip, frame) of every packed row, for the head kernel */,
+                      bool f16 = false /* with bf16 = true: the 16-bit operand type is IEEE fp16 */);
 void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
-                    bool in_bf16 = false);
+                    bool in_bf16 = false, bool f16 = false);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
-                        int cols_dst, hipStream_t s);
+                        int cols_dst, hipStream_t s, bool f16 = false);
 // 256x256x64 ping-pong (8-phase) kernel, csrc/gemm_pp.hip; -1 = shape not supported (N % 256, K % 64, K >= 128)
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
-                                   int M, int N, int K, bool out_bf16, hipStream_t s);
+                                   int M, int N, int K, bool out_bf16, hipStream_t s, bool f16 = false);
 int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
                                   int K, GemmEpi epi, hipStream_t s);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
@@ -118,7 +121,7 @@ size_t gru_hx_bytes(bool bf16, int hid, int G);
 int gru_max_tiles();
 int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const float* bc, const SlotPlan& plan,
                         int row0, int nrows, int hid, int C, int apply_softmax,
-                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap = nullptr);
+                        float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap = nullptr, bool f16 = false);
 void launch_permute_rows(const float* src, float* dst, const int* sorted_clip, int n, int width, int to_sorted,
                          hipStream_t s);
 void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s);
@@ -194,6 +197,6 @@ struct StreamGemv {
   const float* ln_b = nullptr;
   float ln_eps = 1e-5f;
 };
-int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s);
+int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s, bool f16 = false);
 int launch_stream_gates_head(const float* gi, const float* gh, const float* b_hn, float* h_state, const void* wc, const float* bc, int n,
-                              int H, int C, int softmax, float* out, int* argmax, hipStream_t s);
+                              int H, int C, int softmax, float* out, int* argmax, hipStream_t s, bool f16 = false);

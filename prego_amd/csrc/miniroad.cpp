@@ -53,7 +53,8 @@ struct EventPair { hipEvent_t a, b; };
 
 struct prego_miniroad {
   int d_rgb, d_flow, emb, hid, ncls, ncls_pad;
-  bool bf16;
+  bool bf16;                    // 16-bit MFMA operands (bf16, or IEEE fp16 when f16 is set as well); false = exact-fp32 MFMA
+  bool f16 = false;             // PREGO_F16: the 16-bit operand / intermediate type is fp16 (inference entry points only)
   int n_cu;
   int G, P;                     // recurrence groups / workgroups per group
   // ingested weights (device, handle-owned)
@@ -133,7 +134,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
                                      int compute_dtype) {
   if (!out) return fail(PREGO_EINVAL, "out is NULL");
   *out = nullptr;
-  if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16) return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
+  if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16) return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
   if (hid != 1024) return fail(PREGO_EINVAL, "hidden_dim %d unsupported: the register-resident recurrence is built for 1024", hid);
   if (emb <= 0 || emb % 512 || emb > 4096) return fail(PREGO_EINVAL, "embedding_dim %d must be a multiple of 512, <= 4096", emb);
   if (d_rgb < 0 || d_flow < 0 || d_rgb + d_flow <= 0 || (d_rgb % 64) || (d_flow % 64))
@@ -146,7 +147,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   prego_miniroad* h = new prego_miniroad();
   h->d_rgb = d_rgb; h->d_flow = d_flow; h->emb = emb; h->hid = hid; h->ncls = n_classes;
   h->ncls_pad = (n_classes + 15) / 16 * 16;
-  h->bf16 = compute_dtype == PREGO_BF16;
+  h->bf16 = compute_dtype != PREGO_F32;
+  h->f16 = compute_dtype == PREGO_F16;
   h->n_cu = prop.multiProcessorCount;
   h->P = h->bf16 ? 32 : 64;
   h->G = std::min(h->bf16 ? 8 : 4, h->n_cu / h->P);
@@ -220,10 +222,10 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
     return fail(PREGO_EINVAL, "set_weights: NULL tensor");
   hipStream_t s = (hipStream_t)stream;
   const int din = h->d_rgb + h->d_flow, E = h->emb, H = h->hid;
-  launch_pad_convert(h->bf16, layer1_w, E, din, din, h->w1, E, din, s);
-  launch_pad_convert(h->bf16, w_ih, 3 * H, E, E, h->w_ih, 3 * H, E, s);
-  launch_pad_convert(h->bf16, w_hh, 3 * H, H, H, h->w_hh, 3 * H, H, s);
-  launch_pad_convert(h->bf16, fc_w, h->ncls, H, H, h->w_c, h->ncls_pad, H, s);
+  launch_pad_convert(h->bf16, layer1_w, E, din, din, h->w1, E, din, s, h->f16);
+  launch_pad_convert(h->bf16, w_ih, 3 * H, E, E, h->w_ih, 3 * H, E, s, h->f16);
+  launch_pad_convert(h->bf16, w_hh, 3 * H, H, H, h->w_hh, 3 * H, H, s, h->f16);
+  launch_pad_convert(h->bf16, fc_w, h->ncls, H, H, h->w_c, h->ncls_pad, H, s, h->f16);
   launch_pad_convert(false, fc_b, 1, h->ncls, h->ncls, h->b_c, 1, h->ncls_pad, s);
   HIPCHK(hipMemcpyAsync(h->b1, layer1_b, E * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->ln_g, ln_w, E * 4, hipMemcpyDeviceToDevice, s));
@@ -474,6 +476,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "rgb pointer array is NULL");
   if (!workspace) return fail(PREGO_EINVAL, "workspace is NULL");
   hipStream_t s = (hipStream_t)stream;
+  if (h->f16 && (flags & PREGO_FWD_KEEP))
+    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) on an fp16-operand handle: training runs on bf16 / fp32 handles");
   const bool want_single = h0 != nullptr || h_last != nullptr || (flags & PREGO_FWD_KEEP) != 0;
   int rc = build_plan(h, n_clips, lens, want_single);
   if (rc) return rc;
@@ -523,11 +527,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   // projection with fp32 or bf16 output: ping-pong kernel for whole-chip shapes, the 128x128 kernel with a bf16-store epilogue below
   auto proj = [&](const void* A, int lda, const void* Wt, int ldb, const float* bias, void* Cout, int ldc, int M, int N, int K) {
     if (!h->bf16) { launch_gemm_f32_nt((const float*)A, lda, (const float*)Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
-    if (!i16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
-    if (M >= 4096 && launch_gemm_bf16_pingpong_mode(0, A, lda, Wt, ldb, bias, Cout, ldc, M, N, K, true, s) == 0) return;
+    if (!i16 && !h->f16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
+    if (M >= 4096 && launch_gemm_bf16_pingpong_mode(0, A, lda, Wt, ldb, bias, Cout, ldc, M, N, K, i16, s, h->f16) == 0) return;
     GemmEpi epi{};
-    epi.mode = EPI_STORE_BF16; epi.out_b = Cout;
-    launch_gemm_bf16_nt_epi(A, lda, Wt, ldb, bias, nullptr, ldc, M, N, K, epi, s);
+    epi.f16 = h->f16 ? 1 : 0;
+    if (i16) { epi.mode = EPI_STORE_BF16; epi.out_b = Cout; } else epi.mode = EPI_STORE;
+    launch_gemm_bf16_nt_epi(A, lda, Wt, ldb, bias, i16 ? nullptr : (float*)Cout, ldc, M, N, K, epi, s);
   };
   float* KR = nullptr; float* KZ = nullptr; float* KN = nullptr; float* KG = nullptr; float* STATS = nullptr;
   const bool keep = (flags & PREGO_FWD_KEEP) != 0;
@@ -562,7 +567,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
     EventPair* evp = ev_begin(h, 2, st);
     launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
-                     st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8);
+                     st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8, h->f16);
     ev_end(evp, st);
     if (h->timing) h->pack_bytes += (double)rows_ * (kx * 4.0 + rb.x);
   };
@@ -586,14 +591,14 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ev = ev_begin(h, 0, s);
     proj(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx);
     ev_end(ev, s);
-    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16);
+    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16);
     ev = ev_begin(h, 0, s);
     proj(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E);
     ev_end(ev, s);
     if (h->timing) h->gemm_flop += 2.0 * rows * ((double)E * kx + 3.0 * H * E);
 
     GruArgs ga;
-    ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = i16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
+    ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = i16 ? 1 : 0; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
     ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
     ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;
@@ -618,7 +623,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
 
     if (out || argmax) {
       if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, plan, base, rows, H, h->ncls,
-                              (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s, RM + (size_t)(ci & 1) * cap_rows * 8))
+                              (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s, RM + (size_t)(ci & 1) * cap_rows * 8, h->f16))
         return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
     }
     if (packed) { HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0)); side_join.pending = false; }
@@ -636,7 +641,7 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "step before set_weights");
-  if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 handles (fp32 operands: use forward() with h0 / h_last)");
+  if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 / fp16 handles (fp32 operands: use forward() with h0 / h_last)");
   if (n_streams < 1 || n_streams > 16) return fail(PREGO_EINVAL, "step: %d streams (1..16 per call)", n_streams);
   if (!h_state) return fail(PREGO_EINVAL, "step: h_state is NULL");
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "step: rgb is NULL");
@@ -650,17 +655,17 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   const bool with_flow = flow != nullptr && h->d_flow > 0;
   // layer1: K = the columns actually present (a zero flow half drops its half of K, as in forward())
   StreamGemv l1{h->w1, rgb, with_flow ? flow : nullptr, h->b1, Y, E, din, h->d_rgb, h->d_rgb, h->d_flow, 0};
-  if (launch_stream_gemv(1, &l1, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported layer1 shape %d x %d", E, din);
+  if (launch_stream_gemv(1, &l1, n_streams, s, h->f16)) return fail(PREGO_EINVAL, "step: unsupported layer1 shape %d x %d", E, din);
   // LayerNorm + ReLU: inside the W_ih product for <= 4 streams (three launches per frame), the batched kernel otherwise
   static const bool no_fuse = getenv("PREGO_STEP_NO_LN_FUSE") != nullptr;
   const bool fuse_ln = n_streams <= 4 && E % 2048 == 0 && !no_fuse;
-  if (!fuse_ln) launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false);
+  if (!fuse_ln) launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false, h->f16);
   StreamGemv g2[2] = {{h->w_ih, fuse_ln ? (const void*)Y : (const void*)Eb, nullptr, h->bias2, GI, 3 * H, E, E, E, 0, fuse_ln ? 0 : 1},
                       {h->w_hh, h_state, nullptr, nullptr, GH, 3 * H, H, H, H, 0, 0}};
   if (fuse_ln) { g2[0].ln_g = h->ln_g; g2[0].ln_b = h->ln_b; g2[0].ln_eps = 1e-5f; }
-  if (launch_stream_gemv(2, g2, n_streams, s)) return fail(PREGO_EINVAL, "step: unsupported GRU shape %d / %d", E, H);
+  if (launch_stream_gemv(2, g2, n_streams, s, h->f16)) return fail(PREGO_EINVAL, "step: unsupported GRU shape %d / %d", E, H);
   if (launch_stream_gates_head(GI, GH, h->b_hn, h_state, h->w_c, h->b_c, n_streams, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, out,
-                               (int*)argmax, s)) return fail(PREGO_EINVAL, "step: unsupported head shape %d x %d", h->ncls, H);
+                               (int*)argmax, s, h->f16)) return fail(PREGO_EINVAL, "step: unsupported head shape %d x %d", h->ncls, H);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
@@ -833,6 +838,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   if (!h || !lens || !dlogits || !fwd_workspace || !bwd_workspace) return fail(PREGO_EINVAL, "backward: NULL argument");
   if (!g_layer1_w || !g_layer1_b || !g_ln_w || !g_ln_b || !g_w_ih || !g_w_hh || !g_b_ih || !g_b_hh || !g_fc_w || !g_fc_b)
     return fail(PREGO_EINVAL, "backward: NULL gradient tensor");
+  if (h->f16) return fail(PREGO_EINVAL, "backward on an fp16-operand handle: training runs on bf16 / fp32 handles");
   if ((int)h->plan_lens.size() != n_clips || !std::equal(lens, lens + n_clips, h->plan_lens.begin()) || h->kept_rows == 0)
     return fail(PREGO_EINVAL, "backward must follow a forward(PREGO_FWD_KEEP) of the same clips");
   hipStream_t s = (hipStream_t)stream;
@@ -981,6 +987,7 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
   HandleScope scope_(h);
   if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return fail(PREGO_EINVAL, "adamw: NULL argument");
   if (!h->have_weights) return fail(PREGO_EINVAL, "adamw step before set_weights");
+  if (h->f16) return fail(PREGO_EINVAL, "adamw step on an fp16-operand handle: training runs on bf16 / fp32 handles");
   hipStream_t s = (hipStream_t)stream;
   const long long din = h->d_rgb + h->d_flow, E = h->emb, H = h->hid, C = h->ncls;
   // set_weights order: layer1.0.weight, layer1.0.bias, layer1.1.weight, layer1.1.bias, w_ih, w_hh, b_ih, b_hh, fc.weight, fc.bias

@@ -37,8 +37,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
       }
       if constexpr (sizeof(OutT) == 2) {
         uint4 o;
-        o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
-        o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+        o.x = op16<OutT>::pack2_sat(a.x, a.y); o.y = op16<OutT>::pack2_sat(a.z, a.w);
+        o.z = op16<OutT>::pack2_sat(b.x, b.y); o.w = op16<OutT>::pack2_sat(b.z, b.w);
         *(uint4*)(dst + c) = o;
       } else {
         *(float4*)(dst + c) = a;
@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
         float4 a, b;
         if constexpr (sizeof(InT) == 2) {          // bf16 rows (inference path with bf16 intermediates): 8 elements = one 16-byte load
           const u32x4 w = __builtin_nontemporal_load((const u32x4*)(y + (i * 64 + lane) * 8));
-          a = make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u));
-          b = make_float4(__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xFFFF0000u), __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xFFFF0000u));
+          a = make_float4(op16<InT>::lo(w[0]), op16<InT>::hi(w[0]), op16<InT>::lo(w[1]), op16<InT>::hi(w[1]));
+          b = make_float4(op16<InT>::lo(w[2]), op16<InT>::hi(w[2]), op16<InT>::lo(w[3]), op16<InT>::hi(w[3]));
         } else {
           a = nt_load4((const float*)y + (i * 64 + lane) * 8);
           b = nt_load4((const float*)y + (i * 64 + lane) * 8 + 4);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
         }
         if constexpr (sizeof(OutT) == 2) {
           uint4 w;
-          w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]); w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
+          w.x = op16<OutT>::pack2_sat(o[0], o[1]); w.y = op16<OutT>::pack2_sat(o[2], o[3]); w.z = op16<OutT>::pack2_sat(o[4], o[5]); w.w = op16<OutT>::pack2_sat(o[6], o[7]);
           *(uint4*)(out + (size_t)r * E + c) = w;
         } else {
           *(float4*)(out + (size_t)r * E + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -135,7 +135,7 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     int r = (int)(i / cols_dst), c = (int)(i % cols_dst);
     float v = (r < rows_src && c < cols_src) ? src[(size_t)r * ld_src + c] : 0.f;
-    if constexpr (sizeof(OutT) == 2) dst[i] = f2bf(v); else dst[i] = v;
+    if constexpr (sizeof(OutT) == 2) ((bf16_t*)dst)[i] = op16<OutT>::cvt_sat(v); else dst[i] = v;
   }
 }
 
@@ -145,22 +145,34 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
 // grid_limit > 0: at most that many workgroups (each walks rows at a stride): a THROTTLED stream for the copy that runs beside
 // the latency-bound recurrence (fewer loads in flight per CU = less queueing in front of the recurrence's gather)
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap) {
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap, bool f16) {
   if (nrows <= 0) return;
   int grid = nrows < 65536 ? nrows : 65536;
   if (grid_limit > 0 && grid > grid_limit) grid = grid_limit;
-  if (bf16)
+  if (bf16 && f16)
+    pack_rows_kernel<f16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (f16_t*)X, (int2*)rowmap);
+  else if (bf16)
     pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X, (int2*)rowmap);
   else
     pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X, (int2*)rowmap);
 }
 
 void launch_ln_relu(bool bf16, const void* Yv, const float* gamma, const float* beta, int nrows, int E, float eps, void* out,
-                    float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu, bool in_bf16) {
+                    float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu, bool in_bf16, bool f16) {
   if (nrows <= 0) return;
   int grid = (nrows + 3) / 4;
   if (grid > 16384) grid = 16384;
   const float* Y = (const float*)Yv;
+  if (f16) {            // fp16 operand mode (inference): fp16 or fp32 rows in, fp16 out
+    if (in_bf16) {
+      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+      else ln_relu_rows_kernel<f16_t, 8, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    } else {
+      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+      else ln_relu_rows_kernel<f16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    }
+    return;
+  }
   if (in_bf16) {        // bf16 in, bf16 out (inference path)
     const bf16_t* Yb = (const bf16_t*)Yv;
     if (E <= 2048) ln_relu_rows_kernel<bf16_t, 4, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
@@ -183,11 +195,12 @@ void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s) {
 }
 
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
-                        int cols_dst, hipStream_t s) {
+                        int cols_dst, hipStream_t s, bool f16) {
   size_t n = (size_t)rows_dst * cols_dst;
   int grid = (int)((n + 255) / 256);
   if (grid > 8192) grid = 8192;
-  if (bf16) pad_convert_kernel<bf16_t><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (bf16_t*)dst, rows_dst, cols_dst);
+  if (bf16 && f16) pad_convert_kernel<f16_t><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (f16_t*)dst, rows_dst, cols_dst);
+  else if (bf16) pad_convert_kernel<bf16_t><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (bf16_t*)dst, rows_dst, cols_dst);
   else pad_convert_kernel<float><<<grid, 256, 0, s>>>(src, rows_src, cols_src, ld_src, (float*)dst, rows_dst, cols_dst);
 }
 

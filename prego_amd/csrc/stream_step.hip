@@ -40,7 +40,8 @@ struct GemvArgs { GemvProb p[2]; int nprob, n, rows; };
 // the <= 4 pre-LayerNorm rows (requests issued BEFORE the weight requests, so that waiting for them leaves the weights in
 // flight), computes the two-pass statistics with two block reductions, and reads its input fragments from the normalised bf16
 // rows in LDS.  384 workgroups repeat the same 8 KB row: cheaper than the extra launch of a LayerNorm kernel (5.9 us).
-template <int MAXKS, bool LNX>
+// OT: 16-bit operand type tag (bf16_t / f16_t, common.h)
+template <int MAXKS, bool LNX, typename OT = bf16_t>
 __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(GemvArgs a) {
   __shared__ f32x4 red[4][64];
   __shared__ __attribute__((aligned(16))) bf16_t xs[LNX ? 4 : 1][LNX ? MAXKS * 128 : 8];
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
           if (c < epl) {
             const float o0 = fmaxf((yv[r][c] - mu[r]) * rstd[r] * gv[c] + bv[c], 0.f);
             const float o1 = fmaxf((yv[r][c + 1] - mu[r]) * rstd[r] * gv[c + 1] + bv[c + 1], 0.f);
-            *(unsigned*)(&xs[r][tid * epl + c]) = pack_bf16x2(o0, o1);
+            *(unsigned*)(&xs[r][tid * epl + c]) = op16<OT>::pack2_sat(o0, o1);
           }
       }
       __syncthreads();
@@ -160,11 +161,11 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
       if (!p.x_bf16 && !(LNX && ln)) {
         const f32x4 f0 = __builtin_bit_cast(f32x4, xr[pr][0]), f1 = __builtin_bit_cast(f32x4, xr[pr][1]);
         const f32x4 f2 = __builtin_bit_cast(f32x4, xr[pr][2]), f3 = __builtin_bit_cast(f32x4, xr[pr][3]);
-        x0 = (u32x4){pack_bf16x2(f0[0], f0[1]), pack_bf16x2(f0[2], f0[3]), pack_bf16x2(f1[0], f1[1]), pack_bf16x2(f1[2], f1[3])};
-        x1 = (u32x4){pack_bf16x2(f2[0], f2[1]), pack_bf16x2(f2[2], f2[3]), pack_bf16x2(f3[0], f3[1]), pack_bf16x2(f3[2], f3[3])};
+        x0 = (u32x4){op16<OT>::pack2_sat(f0[0], f0[1]), op16<OT>::pack2_sat(f0[2], f0[3]), op16<OT>::pack2_sat(f1[0], f1[1]), op16<OT>::pack2_sat(f1[2], f1[3])};
+        x1 = (u32x4){op16<OT>::pack2_sat(f2[0], f2[1]), op16<OT>::pack2_sat(f2[2], f2[3]), op16<OT>::pack2_sat(f3[0], f3[1]), op16<OT>::pack2_sat(f3[2], f3[3])};
       }
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[pr][0]), __builtin_bit_cast(bf16x8, x0), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[pr][1]), __builtin_bit_cast(bf16x8, x1), acc, 0, 0, 0);
+      acc = op16<OT>::mfma(__builtin_bit_cast(bf16x8, wa[pr][0]), __builtin_bit_cast(bf16x8, x0), acc);
+      acc = op16<OT>::mfma(__builtin_bit_cast(bf16x8, wa[pr][1]), __builtin_bit_cast(bf16x8, x1), acc);
     }
   red[q][lane] = acc;
   __syncthreads();
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256, MAXKS > 16 ? 1 : 2) void stream_gemv_kernel(Ge
 // One workgroup per stream.  The classifier is the batched head's arithmetic for one frame: logits^T = W_c relu(h)^T on the MFMA
 // with the frame in column 0, wave q the K-quarter of every class tile (all NT x 8 weight fragments requested at once), the four
 // partials added in K order.
-template <int NT>
+template <int NT, typename OT = bf16_t>
 __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
                                                                    const float* __restrict__ b_hn, float* __restrict__ h_state,
                                                                    const bf16_t* __restrict__ wc, const float* __restrict__ bc, int C,
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* 
       hnew[e] = (1.0f - z) * n + z * hp[e];
     }
     *(f32x4*)(h_state + (size_t)s * H + u) = hnew;
-    u32x2 w; w[0] = pack_bf16x2(fmaxf(hnew[0], 0.f), fmaxf(hnew[1], 0.f)); w[1] = pack_bf16x2(fmaxf(hnew[2], 0.f), fmaxf(hnew[3], 0.f));
+    u32x2 w; w[0] = op16<OT>::pack2(fmaxf(hnew[0], 0.f), fmaxf(hnew[1], 0.f)); w[1] = op16<OT>::pack2(fmaxf(hnew[2], 0.f), fmaxf(hnew[3], 0.f));
     *(u32x2*)(shb + u) = w;
   }
   __syncthreads();
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* 
     u32x4 hb = *(const u32x4*)(shb + q * 256 + ks * 32 + 8 * g);
     if (l15 != 0) hb = (u32x4){0u, 0u, 0u, 0u};              // the frame is column 0 of the N dimension
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ct][ks], __builtin_bit_cast(bf16x8, hb), acc[ct], 0, 0, 0);
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = op16<OT>::mfma(wa[ct][ks], __builtin_bit_cast(bf16x8, hb), acc[ct]);
   }
   if (l15 == 0) {
 #pragma unroll
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void stream_gates_head_kernel(const float* 
 }
 
 // y[n][Nout] = x[n][K] W^T + bias for one or two problems in one launch.  Returns -1 on an unsupported shape.
-int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s) {
+int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s, bool f16) {
   if (nprob < 1 || nprob > 2 || n < 1 || n > 16) return -1;
   GemvArgs a{};
   a.nprob = nprob; a.n = n;
@@ -286,6 +287,11 @@ int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s) {
       if (n > 4 || pr[i].K % 2048 || pr[i].kx1 != pr[i].K || pr[i].x_bf16 || !pr[i].ln_b) return -1;
       any_ln = true;
     }
+  if (f16) {
+    if (kmax > 2048) { if (any_ln) stream_gemv_kernel<32, true, f16_t><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<32, false, f16_t><<<blocks, 256, 0, s>>>(a); }
+    else { if (any_ln) stream_gemv_kernel<16, true, f16_t><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<16, false, f16_t><<<blocks, 256, 0, s>>>(a); }
+    return 0;
+  }
   if (kmax > 2048) { if (any_ln) stream_gemv_kernel<32, true><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<32, false><<<blocks, 256, 0, s>>>(a); }
   else { if (any_ln) stream_gemv_kernel<16, true><<<blocks, 256, 0, s>>>(a); else stream_gemv_kernel<16, false><<<blocks, 256, 0, s>>>(a); }
   return 0;
@@ -293,9 +299,13 @@ int launch_stream_gemv(int nprob, const StreamGemv* pr, int n, hipStream_t s) {
 
 // H == 1024 (the handle's hidden size); C <= 128, wc holds ceil(C / 16) * 16 rows
 int launch_stream_gates_head(const float* gi, const float* gh, const float* b_hn, float* h_state, const void* wc, const float* bc, int n,
-                             int H, int C, int softmax, float* out, int* argmax, hipStream_t s) {
+                             int H, int C, int softmax, float* out, int* argmax, hipStream_t s, bool f16) {
   if (H != 1024 || C < 1 || C > 128) return -1;
-#define SGH(NT) stream_gates_head_kernel<NT><<<n, 256, 0, s>>>(gi, gh, b_hn, h_state, (const bf16_t*)wc, bc, C, softmax, out, argmax)
+#define SGH(NT)                                                                                                                              \
+  do {                                                                                                                                       \
+    if (f16) stream_gates_head_kernel<NT, f16_t><<<n, 256, 0, s>>>(gi, gh, b_hn, h_state, (const bf16_t*)wc, bc, C, softmax, out, argmax);   \
+    else stream_gates_head_kernel<NT><<<n, 256, 0, s>>>(gi, gh, b_hn, h_state, (const bf16_t*)wc, bc, C, softmax, out, argmax);              \
+  } while (0)
   switch ((C + 15) / 16) {
     case 1: SGH(1); break; case 2: SGH(2); break; case 3: SGH(3); break; case 4: SGH(4); break;
     case 5: SGH(5); break; case 6: SGH(6); break; case 7: SGH(7); break; default: SGH(8); break;

@@ -34,7 +34,8 @@ def _stream_ptr(device) -> int:
 
 
 class MiniRoadEngine:
-    """One handle per (device, model).  compute_dtype: 'bf16' (product path) or 'fp32' (parity mode)."""
+    """One handle per (device, model, compute_dtype).  compute_dtype: 'fp16' / 'bf16' (16-bit MFMA operands, fp32 accumulation; fp16 =
+    same speed, 8x less operand rounding, inference only) or 'fp32' (exact-fp32 MFMA, the parity mode)."""
 
     def __init__(self, d_rgb: int, d_flow: int, emb: int, hid: int, n_classes: int, device,
                  compute_dtype: str = "bf16"):
@@ -45,9 +46,11 @@ class MiniRoadEngine:
         self.dims = (d_rgb, d_flow, emb, hid, n_classes)
         self.compute_dtype = compute_dtype
         h = C.c_void_p()
+        codes = {"bf16": _lib.PREGO_BF16, "fp16": _lib.PREGO_F16, "fp32": _lib.PREGO_F32}
+        if compute_dtype not in codes:
+            raise PregoError(f"compute_dtype {compute_dtype!r}: expected one of {sorted(codes)}")
         with torch.cuda.device(self.device):
-            check(self.lib.prego_miniroad_create(C.byref(h), d_rgb, d_flow, emb, hid, n_classes,
-                                                 _lib.PREGO_BF16 if compute_dtype == "bf16" else _lib.PREGO_F32))
+            check(self.lib.prego_miniroad_create(C.byref(h), d_rgb, d_flow, emb, hid, n_classes, codes[compute_dtype]))
         self.h = h
         self.max_clips = self.lib.prego_miniroad_max_clips(self.h)
         self._ws: Optional[torch.Tensor] = None
@@ -103,7 +106,7 @@ class MiniRoadEngine:
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
         lens = [int(r.shape[0]) for r in src_list]
         single = h0 is not None or want_h_last
-        for idx in plan_passes(lens, self.max_clips, single, 512 if self.compute_dtype == "bf16" else 256):
+        for idx in plan_passes(lens, self.max_clips, single, 256 if self.compute_dtype == "fp32" else 512):
             sub_h0 = None if h0 is None else h0[idx].contiguous()
             sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
             sub_out, sub_arg = [None] * len(idx), [None] * len(idx)
@@ -167,7 +170,7 @@ class MiniRoadEngine:
              out: Optional[torch.Tensor] = None, argmax: Optional[torch.Tensor] = None):
         """One new frame for each of n <= 16 independent streams: rgb [n, d_rgb] / flow [n, d_flow] (None = zero flow) fp32 cuda
         contiguous, h [n, hid] fp32 cuda = the GRU state, UPDATED IN PLACE (zeros before a stream's first frame).
-        Returns (probabilities or logits [n, C], argmax int32 [n]); pass `out` / `argmax` to reuse buffers.  bf16 engines run
+        Returns (probabilities or logits [n, C], argmax int32 [n]); pass `out` / `argmax` to reuse buffers.  bf16 / fp16 engines run
         the three / four-launch fast path (prego_miniroad_step); fp32 engines the general forward with h0 / h_last."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
         src = rgb if d_rgb > 0 else flow
@@ -181,7 +184,7 @@ class MiniRoadEngine:
             out = torch.empty((n, ncls), dtype=torch.float32, device=self.device)
         if argmax is None:
             argmax = torch.empty((n,), dtype=torch.int32, device=self.device)
-        if self.compute_dtype != "bf16":
+        if self.compute_dtype == "fp32":
             rl = [rgb[i:i + 1] for i in range(n)] if d_rgb > 0 else None
             fl = [flow[i:i + 1] for i in range(n)] if flow is not None else None
             o, a, hl = self.forward_ragged(rl, fl, softmax=softmax, want_out=True, want_argmax=True, h0=h, want_h_last=True)

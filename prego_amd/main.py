@@ -59,7 +59,7 @@ def main(argv=None):
     parser.add_argument("--lr_scheduler", action="store_true")
     parser.add_argument("--no_rgb", action="store_true")
     parser.add_argument("--no_flow", action="store_true")
-    parser.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
+    parser.add_argument("--compute_dtype", default="fp16", choices=["fp16", "bf16", "fp32"])
     args = parser.parse_args(argv)
     cfg = yaml.load(open(args.config), Loader=yaml.FullLoader)
     cfg.update(vars(args))                                           # main.py:28-30

@@ -44,26 +44,44 @@ class MROAD(nn.Module):
         )
         self.f_classification = nn.Sequential(nn.Linear(self.hidden_dim, self.out_dim))
         # build-specific knobs (not reference keys)
-        self.compute_dtype = cfg.get("compute_dtype", "bf16")          # 'bf16' | 'fp32'
+        self.compute_dtype = cfg.get("compute_dtype", "fp16")          # 'fp16' | 'bf16' | 'fp32'
         self.assume_zero_flow = bool(cfg.get("assume_zero_flow", False))  # dataset.py:69 zeroes the flow half
-        self._engine = None
-        self._engine_key = None
-        self._w_versions = None
+        self._engines = {}            # (device, operand dtype) -> [MiniRoadEngine, parameter versions its copies belong to]
 
     # -- engine plumbing -------------------------------------------------------------------
-    def engine(self) -> MiniRoadEngine:
+    def _engine_dtype(self, train: bool) -> str:
+        # fp16 operands are an inference mode (same speed as bf16, 8x less operand rounding); the training kernels (kept
+        # activations, BPTT, wgrads, fused AdamW copies) take bf16 / fp32 handles
+        return "bf16" if (train and self.compute_dtype == "fp16") else self.compute_dtype
+
+    @property
+    def _engine(self):
+        """the training-side engine if one exists (trainer: gradient bucket, timeout check), else the eval engine"""
         dev = self.layer1[0].weight.device
-        key = (dev, self.compute_dtype)
-        if self._engine is None or self._engine_key != key:
-            self._engine = MiniRoadEngine(self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim, self.out_dim,
-                                          dev, self.compute_dtype)
-            self._engine_key = key
-            self._w_versions = None
+        for train in (True, False):
+            ent = self._engines.get((dev, self._engine_dtype(train)))
+            if ent is not None:
+                return ent[0]
+        return None
+
+    def engine(self, train: bool = False) -> MiniRoadEngine:
+        dev = self.layer1[0].weight.device
+        key = (dev, self._engine_dtype(train))
+        ent = self._engines.get(key)
+        if ent is None:
+            ent = [MiniRoadEngine(self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim, self.out_dim, dev, key[1]), None]
+            self._engines[key] = ent
         vers = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        if vers != self._w_versions:
-            self._engine.set_weights(dict(self.named_parameters()))
-            self._w_versions = vers
-        return self._engine
+        if vers != ent[1]:
+            ent[0].set_weights(dict(self.named_parameters()))
+            ent[1] = vers
+        return ent[0]
+
+    def _mark_ingested(self, train: bool = True):
+        """the engine's operand copies were refreshed in place (fused AdamW): record the current parameter versions as theirs"""
+        ent = self._engines.get((self.layer1[0].weight.device, self._engine_dtype(train)))
+        if ent is not None:
+            ent[1] = tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def forward(self, rgb_input, flow_input):
         if self.training:

@@ -89,7 +89,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     sd = dict(self._vit.named_parameters())
                     self._vit._ver = tuple((p.data_ptr(), p._version) for p in sd.values())
                 elif fused_model:
-                    eng = m.engine()        # weights already ingested (versions unchanged since the forward)
+                    eng = m.engine(train=True)        # weights already ingested (versions unchanged since the forward)
                     check(lib.prego_miniroad_adamw_step(
                         eng.h, ptr_array([p.data_ptr() for p in ps]), ptr_array([g.data_ptr() for g in grads]),
                         ptr_array([st["exp_avg"].data_ptr() for st in states]), ptr_array([st["exp_avg_sq"].data_ptr() for st in states]),
@@ -97,7 +97,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     # the engine's operand copies are now those of the NEW values: bump the parameter versions (raw-pointer
                     # update) and record them as ingested, so model.engine() does not re-ingest
                     torch._C._increment_version(ps)
-                    m._w_versions = tuple((p.data_ptr(), p._version) for p in m.parameters())
+                    m._mark_ingested(train=True)
                 else:
                     numel = (C.c_int64 * len(ps))(*[p.numel() for p in ps])
                     check(lib.prego_adamw_step(

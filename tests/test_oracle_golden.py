@@ -36,6 +36,17 @@ def test_g1_miniroad_eval_cfg1(tag, gain):
     assert np.abs(out2["logits"] - out["logits"]).max() < 1e-12
 
 
+def test_g1c_trained_like_head_gain32():
+    """head gain 32 (top-1 probabilities near 1): the oracle against the reference's output, 1024 frames, rgb + flow"""
+    g = _ld("g1c_miniroad_eval_gain32.npz")
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=32.0)
+    out = O.miniroad_forward(sd, W.tsn_features((1, 1024, 2048), 20, "g1c.rgb"), W.tsn_features((1, 1024, 2048), 20, "g1c.flow"))
+    assert np.abs(out["logits"][0] - g["probs"]).max() < 2e-5       # fp64 oracle vs torch fp32 at logit scale ~30
+    safe = g["margin"] > 1e-4
+    assert np.array_equal(out["logits"][0].argmax(1)[safe], g["argmax"][safe])
+
+
 def test_g2_long_T_4096_nonzero_flow():
     g = _ld("g2_miniroad_longT_4096.npz")
     cfg = assembly101_cfg()
