@@ -30,6 +30,7 @@ SYMBOLS = [
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
+    "prego_perframe_ap_workspace_bytes", "prego_perframe_ap",
 ]
 
 
@@ -80,6 +81,9 @@ def load() -> C.CDLL:
     lib.prego_miniroad_backward_workspace_bytes.restype = sz
     lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]
     lib.prego_window_vote.argtypes = [vp, i64, i32, i32, vp, vp]
+    lib.prego_perframe_ap_workspace_bytes.argtypes = [i64, i32]
+    lib.prego_perframe_ap_workspace_bytes.restype = sz
+    lib.prego_perframe_ap.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]
     f32 = C.c_float
     lib.prego_adamw_step.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i64, f32, f32, f32, f32, f32, vp]
     lib.prego_miniroad_adamw_step.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, f32, f32, f32, f32, f32, vp]

@@ -150,6 +150,11 @@ int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, cons
 // post-processing (postproc.hip)
 int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, hipStream_t s);
 
+// per-frame average precision (metrics.hip): segmented radix sort + scan, one segment per class
+size_t perframe_ap_workspace_bytes(long long n_frames, int n_classes);
+int launch_perframe_ap(const float* scores, const float* target, long long n_frames, int n_classes, double* ap, long long* n_pos,
+                       double* score_sum, void* workspace, hipStream_t s);
+
 // fused multi-tensor AdamW (optim.hip)
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,

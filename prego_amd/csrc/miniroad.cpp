@@ -965,6 +965,26 @@ extern "C" int prego_window_vote(const int32_t* argmax, int64_t n_frames, int wi
 }
 
 // ================================================================================================
+// metric: utils/metrics.py:25-62 (per-class average precision of the per-frame scores) on the device
+// ================================================================================================
+extern "C" size_t prego_perframe_ap_workspace_bytes(int64_t n_frames, int n_classes) {
+  if (n_frames <= 0 || n_classes <= 0) return 0;
+  return perframe_ap_workspace_bytes(n_frames, n_classes);
+}
+extern "C" int prego_perframe_ap(const float* scores, const float* target, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
+                                 double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!scores || !target || !ap || !workspace) return fail(PREGO_EINVAL, "perframe_ap: NULL argument");
+  if (n_frames <= 0 || n_frames >= (1ll << 31) || n_classes <= 0 || n_classes > 65535)
+    return fail(PREGO_EINVAL, "perframe_ap: n_frames %lld, n_classes %d", (long long)n_frames, n_classes);
+  if (workspace_bytes < perframe_ap_workspace_bytes(n_frames, n_classes))
+    return fail(PREGO_EWORKSPACE, "perframe_ap: workspace %zu < %zu", workspace_bytes, perframe_ap_workspace_bytes(n_frames, n_classes));
+  if (launch_perframe_ap(scores, target, n_frames, n_classes, ap, (long long*)n_pos, score_sum, workspace, (hipStream_t)stream))
+    return fail(PREGO_EINVAL, "perframe_ap: bad arguments");
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ================================================================================================
 // optimizer: torch.optim.AdamW of main.py:62-67 on the ABI
 // ================================================================================================
 extern "C" int prego_adamw_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,

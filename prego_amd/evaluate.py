@@ -19,7 +19,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .metrics import perframe_average_precision_torch
+from .metrics import perframe_average_precision, perframe_average_precision_device
 from .registry import EVAL
 
 
@@ -31,7 +31,6 @@ class Evaluate(nn.Module):
         if "THUMOS" in cfg["data_name"]:
             raise NotImplementedError("THUMOS post-processing is outside the PREGO datasets")
         self.metric = cfg["metric"]
-        self.eval_method = perframe_average_precision_torch      # same definition as the reference's sklearn path, on the device
         self.cfg = cfg
         self.all_class_names = json.load(open(cfg["video_list_path"]))[cfg["data_name"].split("_")[0]]["class_index"]
         self.max_frames_per_batch = int(cfg.get("eval_frames_per_batch", 4_000_000))
@@ -126,7 +125,13 @@ class Evaluate(nn.Module):
             pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
             gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
             num_frames = int(gt_all.shape[0])
-            result = self.eval_method(pred_all, gt_all, self.all_class_names, self.data_processing, self.metric)
+            if torch.device(device).type == "cuda":
+                # sort + scan per class in libprego_amd.so (prego_perframe_ap); after a multi-rank gather the matrices are host
+                # tensors on rank 0 and go back to its GPU first
+                result = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
+                                                           self.data_processing, self.metric)
+            else:       # only reachable with a stand-in model on a CPU box (the gloo tests of the sharding logic)
+                result = perframe_average_precision(pred_all.numpy(), gt_all.numpy(), self.all_class_names, self.data_processing, self.metric)
             time_taken = max(t_end - t_begin, 1e-9)
             self.last_fps = num_frames / time_taken
             logger.info(f"Processed {num_frames} frames in {time_taken:.1f} seconds ({self.last_fps:.1f} FPS)")

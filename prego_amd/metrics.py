@@ -1,13 +1,17 @@
-"""Per-frame average precision (step_recognition/utils/metrics.py:25-62), SURVEY.md section 8 f3.
+"""Per-frame average precision, the metric behind `metric: 'AP'` of both shipped configs (the reference computes it in
+step_recognition/utils/metrics.py:25-62 with one sklearn call per class), SURVEY.md section 8 row f3.
 
-Two implementations of the same definition, including the reference's quirk of always ignoring class index 0 as
-"background" (metrics.py:48):
-  * `perframe_average_precision`        - host side, sklearn, exactly like the reference (numpy inputs);
-  * `perframe_average_precision_torch`  - the same arithmetic restated on torch tensors (sort + scans per class, float64),
-    used by `Evaluate` so that the [frames x classes] score matrix of an eval pass never leaves the device: at the
-    Assembly101-O test split's size (2.3 M frames x 86 classes) the sklearn path takes tens of seconds after a 0.13 s
-    forward pass.  It follows sklearn's `average_precision_score` = sum over DISTINCT thresholds of (R_k - R_{k-1}) P_k
-    (ties in the scores share one threshold), so it agrees with the host version to float64 rounding."""
+The definition is sklearn's `average_precision_score`: per class, thresholds at the DISTINCT score values in descending order
+(ties share a threshold), AP = sum_k (R_k - R_{k-1}) P_k; classes without a positive are skipped and so is class 0, which the
+reference always treats as background (metrics.py:44-48).  Two routes to the same numbers:
+
+  * `perframe_average_precision`         - numpy on the host, all classes at once (one argsort of the score matrix); the CPU
+                                           tests hold it to sklearn.
+  * `perframe_average_precision_device`  - the HIP path: `prego_perframe_ap` (csrc/metrics.hip: segmented radix sort + scan, one
+                                           segment per class), used by `Evaluate` so that the [frames x classes] score matrix of
+                                           an eval pass never leaves the device.  No CPU fallback.
+
+Only `metric: 'AP'` exists here: the reference's calibrated variant (cAP) is unreachable from the shipped configs."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -15,104 +19,77 @@ from collections import OrderedDict
 import numpy as np
 
 
-def calibrated_average_precision_score(y_true, y_score):
-    """cAP (metrics.py:10-22)."""
-    y_true_sorted = y_true[np.argsort(-y_score)]
-    tp = y_true_sorted.astype(float)
-    fp = np.abs(y_true_sorted.astype(float) - 1)
-    tps, fps = np.cumsum(tp), np.cumsum(fp)
-    ratio = np.sum(tp == 0) / np.sum(tp)
-    cprec = tps / (tps + fps / (ratio + np.finfo(float).eps) + np.finfo(float).eps)
-    return np.sum(cprec[tp == 1]) / np.sum(tp)
+def average_precision_columns(scores: np.ndarray, positive: np.ndarray) -> np.ndarray:
+    """AP of every column: scores [frames, classes] (any float dtype), positive [frames, classes] bool -> float64 [classes],
+    NaN where a column has no positive."""
+    scores = np.asarray(scores)
+    positive = np.asarray(positive, dtype=bool)
+    n = scores.shape[0]
+    order = np.argsort(-scores, axis=0, kind="stable")
+    ranked = np.take_along_axis(scores, order, axis=0)
+    hits = np.cumsum(np.take_along_axis(positive, order, axis=0), axis=0, dtype=np.int64)      # positives at or above each rank
+    closes = np.ones_like(positive)                                                            # rank closes a run of equal scores
+    closes[:-1] = ranked[:-1] != ranked[1:]
+    # positives at the previous threshold: the running maximum of `hits` over the earlier run ends (hits is monotone)
+    at_end = np.where(closes, hits, 0)
+    before = np.zeros_like(hits)
+    before[1:] = np.maximum.accumulate(at_end, axis=0)[:-1]
+    seen = np.arange(1, n + 1, dtype=np.float64)[:, None]
+    total = hits[-1].astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ap = np.where(closes, (hits - before) * (hits / seen), 0.0).sum(axis=0) / total
+    return np.where(total > 0, ap, np.nan)
+
+
+def _report(ap, n_true, score_sum, class_names):
+    """the reference's result dict: per-class AP (classes 1.. that have a positive), its log strings, and their mean"""
+    res = OrderedDict(per_class_AP=OrderedDict(), num=OrderedDict())
+    for c in range(1, len(class_names)):                    # class 0 = background, never scored (metrics.py:44-48)
+        if n_true[c] > 0:
+            name = class_names[c]
+            res["per_class_AP"][name] = float(ap[c])
+            res["num"][name] = f"[true: {int(n_true[c])}, pred:{int(score_sum[c])}, AP:{ap[c] * 100:.1f}]"
+    res["mean_AP"] = np.mean(list(res["per_class_AP"].values()))
+    return res
 
 
 def perframe_average_precision(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
-    from sklearn.metrics import average_precision_score
-
-    result = OrderedDict()
-    ground_truth = np.asarray(ground_truth)
-    prediction = np.asarray(prediction)
+    """Host path: prediction / ground_truth [frames, classes] (lists of rows or arrays, as trainer/eval.py collects them)."""
+    if metrics != "AP":
+        raise RuntimeError(f"Unknown metrics: {metrics} (prego_amd implements 'AP', the metric of the shipped configs)")
+    truth = np.asarray(ground_truth)
+    pred = np.asarray(prediction)
     if postprocessing is not None:
-        ground_truth, prediction = postprocessing(ground_truth, prediction)
-    if metrics == "AP":
-        compute_score = average_precision_score
-    elif metrics == "cAP":
-        compute_score = calibrated_average_precision_score
-    else:
-        raise RuntimeError("Unknown metrics: {}".format(metrics))
-    ignore_index = {0}
-    result["per_class_AP"] = OrderedDict()
-    result["num"] = OrderedDict()
-    for idx, class_name in enumerate(class_names):
-        if idx not in ignore_index and np.any(ground_truth[:, idx]):
-            ap = compute_score(ground_truth[:, idx], prediction[:, idx])
-            result["per_class_AP"][class_name] = ap
-            result["num"][class_name] = (f"[true: {int(np.sum(ground_truth[:, idx]))}, "
-                                         f"pred:{int(np.sum(prediction[:, idx]))}, AP:{ap * 100:.1f}]")
-    result["mean_AP"] = np.mean(list(result["per_class_AP"].values()))
-    return result
+        truth, pred = postprocessing(truth, pred)
+    return _report(average_precision_columns(pred, truth != 0), (truth != 0).sum(0), pred.sum(0, dtype=np.float64), class_names)
 
 
-def average_precision_torch(y_true, y_score):
-    """sklearn.metrics.average_precision_score for one class on torch tensors (any device), float64."""
+def perframe_average_precision_device(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
+    """Device path: prediction / ground_truth fp32 CUDA tensors [frames, classes]; the sort and the scan run in
+    libprego_amd.so (`prego_perframe_ap`), one small device -> host transfer brings back AP, positives and score mass."""
+    import ctypes as C
+
     import torch
-    y_score = y_score.to(torch.float64)
-    s, idx = torch.sort(y_score, descending=True, stable=True)
-    y = y_true[idx].to(torch.float64)
-    n = y.numel()
-    tps_all = torch.cumsum(y, 0)
-    last = torch.ones(n, dtype=torch.bool, device=y.device)
-    if n > 1:
-        last[:-1] = s[:-1] != s[1:]                       # end of every run of equal scores = one threshold
-    tps = tps_all[last]
-    cnt = torch.arange(1, n + 1, device=y.device, dtype=torch.float64)[last]
-    precision = tps / cnt
-    recall = tps / tps_all[-1]
-    prev = torch.cat([torch.zeros(1, dtype=torch.float64, device=y.device), recall[:-1]])
-    return float(((recall - prev) * precision).sum())
 
-
-def average_precision_columns_torch(y_true, y_score):
-    """sklearn.metrics.average_precision_score for EVERY class at once: y_true (bool) and y_score [frames, classes] on any
-    device -> float64 [classes] (NaN where a class has no positive).  One stable sort along the frame axis, cumulative sums and
-    a running maximum: no per-class Python loop and a single host transfer for the whole metric.  Thresholds are the ends of
-    runs of equal scores (ties share one threshold), exactly as sklearn's precision_recall_curve builds them."""
-    import torch
-    s, idx = torch.sort(y_score.to(torch.float64), dim=0, descending=True, stable=True)
-    y = torch.gather(y_true.to(torch.float64), 0, idx)
-    n = y.shape[0]
-    tps = torch.cumsum(y, 0)
-    last = torch.ones_like(y, dtype=torch.bool)
-    if n > 1:
-        last[:-1] = s[:-1] != s[1:]
-    cnt = torch.arange(1, n + 1, device=y.device, dtype=torch.float64)[:, None]
-    total = tps[-1:].clamp(min=1e-300)
-    recall = tps / total
-    precision = tps / cnt
-    zero = torch.zeros((), dtype=torch.float64, device=y.device)
-    r_last = torch.where(last, recall, zero)
-    prev = torch.cummax(r_last, 0).values                      # recall at the most recent threshold at or before i (recall is monotone)
-    prev = torch.cat([torch.zeros_like(prev[:1]), prev[:-1]], 0)
-    ap = torch.where(last, (recall - prev) * precision, zero).sum(0)
-    return torch.where(tps[-1] > 0, ap, torch.full_like(ap, float("nan")))
-
-
-def perframe_average_precision_torch(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
-    """`perframe_average_precision` on torch tensors [frames, classes] (prediction: scores, ground_truth: one/multi-hot)."""
-    import torch
+    from . import _lib
+    from ._lib import PregoError, check
     if postprocessing is not None or metrics != "AP":
-        return perframe_average_precision(prediction.cpu().numpy(), ground_truth.cpu().numpy(), class_names, postprocessing, metrics)
-    result = OrderedDict()
-    result["per_class_AP"] = OrderedDict()
-    result["num"] = OrderedDict()
-    truth = ground_truth != 0
-    # everything the report needs in ONE device -> host transfer: AP, positives and score mass per class
-    stats = torch.stack([average_precision_columns_torch(truth, prediction), truth.sum(0).to(torch.float64),
-                         prediction.to(torch.float64).sum(0), ground_truth.to(torch.float64).sum(0)]).cpu().numpy()
-    for idx, class_name in enumerate(class_names):
-        if idx != 0 and stats[1, idx] > 0:                        # class 0 is skipped as "background" (utils/metrics.py:48)
-            ap = float(stats[0, idx])
-            result["per_class_AP"][class_name] = ap
-            result["num"][class_name] = (f"[true: {int(stats[3, idx])}, pred:{int(stats[2, idx])}, AP:{ap * 100:.1f}]")
-    result["mean_AP"] = np.mean(list(result["per_class_AP"].values()))
-    return result
+        raise PregoError("perframe_average_precision_device: metric 'AP' without postprocessing only (what both shipped configs use)")
+    if not (prediction.is_cuda and ground_truth.is_cuda):
+        raise PregoError("perframe_average_precision_device needs CUDA tensors; there is no CPU fallback "
+                         "(host arrays: perframe_average_precision)")
+    pred = prediction.detach().to(torch.float32).contiguous()
+    truth = ground_truth.detach().to(torch.float32).contiguous()
+    if pred.dim() != 2 or pred.shape != truth.shape or pred.shape[1] != len(class_names):
+        raise PregoError(f"perframe_average_precision_device: shapes {tuple(pred.shape)} / {tuple(truth.shape)} for {len(class_names)} classes")
+    n, ncls = pred.shape
+    lib = _lib.load()
+    dev = pred.device
+    ws = torch.empty(lib.prego_perframe_ap_workspace_bytes(n, ncls), dtype=torch.uint8, device=dev)
+    out = torch.empty((3, ncls), dtype=torch.float64, device=dev)          # AP | positives (int64 bits) | score sums
+    with torch.cuda.device(dev):
+        check(lib.prego_perframe_ap(C.c_void_p(pred.data_ptr()), C.c_void_p(truth.data_ptr()), n, ncls, C.c_void_p(out[0].data_ptr()),
+                                    C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    host = out.cpu().numpy()
+    return _report(host[0], host[1].view(np.int64), host[2], class_names)

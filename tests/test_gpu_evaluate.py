@@ -65,3 +65,45 @@ def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     assert abs(mAP - g["mAP"]) < 5e-3
     assert ev.last_fps and ev.last_fps > 0
     print(f"evaluate {dtype}: mAP {mAP:.5f} (ref {g['mAP']:.5f}), argmax mismatches {total_mism} of {sum(g['lens'])}")
+
+
+@pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86)])
+def test_device_average_precision_kernel_vs_sklearn(n, C):
+    """prego_perframe_ap (csrc/metrics.hip: segmented radix sort + scan per class) against sklearn's average_precision_score and the
+    host implementation: random scores, heavy ties, a constant column, negative scores (raw logits), -0.0 vs +0.0, a class
+    without positives, tile edges (n = 1, 63, 4097)."""
+    from sklearn.metrics import average_precision_score
+    from prego_amd.metrics import average_precision_columns, perframe_average_precision, perframe_average_precision_device
+    rng = np.random.default_rng(n + C)
+    pr = rng.random((n, C)).astype(np.float32)
+    if C > 2:
+        pr[:, 2] = np.round(pr[:, 2], 1)                 # heavy ties
+    if C > 4:
+        pr[:, 4] = 0.5                                   # one threshold
+        pr[:, 3] = rng.standard_normal(n).astype(np.float32) * 30          # negative scores too
+    if C > 5:
+        pr[:, 5] = np.where(rng.random(n) < 0.5, 0.0, -0.0).astype(np.float32)     # signed zeros tie
+    gt = np.zeros((n, C), np.float32)
+    gt[np.arange(n), rng.integers(0, C, n)] = 1
+    if C > 6:
+        gt[:, 6] = 0                                     # class without positives
+    names = [f"c{i}" for i in range(C)]
+    dev = perframe_average_precision_device(torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda(), names)
+    host = perframe_average_precision(pr, gt, names)
+    assert list(dev["per_class_AP"]) == list(host["per_class_AP"])
+    for c in range(1, C):
+        if gt[:, c].any():
+            want = average_precision_score(gt[:, c], pr[:, c])
+            assert abs(dev["per_class_AP"][names[c]] - want) < 1e-12, (c, dev["per_class_AP"][names[c]], want)
+    if dev["per_class_AP"]:
+        assert abs(dev["mean_AP"] - host["mean_AP"]) < 1e-12
+    assert dev["num"] == host["num"] or n > 4000          # the "pred:" figure is int(sum of scores): fp64 device sum vs numpy's
+    ap = average_precision_columns(pr, gt != 0)
+    assert np.isnan(ap[6]) if C > 6 else True
+
+
+def test_device_average_precision_rejects_host_tensors():
+    from prego_amd._lib import PregoError
+    from prego_amd.metrics import perframe_average_precision_device
+    with pytest.raises(PregoError):
+        perframe_average_precision_device(torch.zeros(4, 3), torch.zeros(4, 3), ["a", "b", "c"])

@@ -126,10 +126,11 @@ def test_metrics_ignore_class_zero_and_match_sklearn():
     assert abs(res["mean_AP"] - want) < 1e-12
 
 
-def test_torch_average_precision_matches_sklearn_with_ties():
-    """the device-side restatement used by Evaluate (metrics.perframe_average_precision_torch) against the sklearn path"""
-    import torch
-    from prego_amd.metrics import perframe_average_precision, perframe_average_precision_torch
+def test_host_average_precision_matches_sklearn_with_ties():
+    """the vectorised host AP (metrics.average_precision_columns) against sklearn, incl. heavy ties, a constant column and a
+    class without positives"""
+    from prego_amd.metrics import average_precision_columns, perframe_average_precision
+    from sklearn.metrics import average_precision_score
     rng = np.random.default_rng(3)
     T, Cn = 4000, 9
     pr = rng.random((T, Cn)).astype(np.float32)
@@ -137,14 +138,18 @@ def test_torch_average_precision_matches_sklearn_with_ties():
     pr[:, 4] = 0.5                                   # all equal
     gt = np.zeros((T, Cn), np.float32)
     gt[np.arange(T), rng.integers(0, Cn, T)] = 1
-    gt[:, 6] = 0                                     # class without positives: skipped by both
+    gt[:, 6] = 0                                     # class without positives
+    ap = average_precision_columns(pr, gt != 0)
+    for c in range(Cn):
+        if c == 6:
+            assert np.isnan(ap[c])
+        else:
+            assert abs(ap[c] - average_precision_score(gt[:, c], pr[:, c])) < 1e-12, c
     names = [f"c{i}" for i in range(Cn)]
-    a = perframe_average_precision(pr, gt, names)
-    b = perframe_average_precision_torch(torch.from_numpy(pr), torch.from_numpy(gt), names)
-    assert list(a["per_class_AP"]) == list(b["per_class_AP"]) and "c0" not in b["per_class_AP"] and "c6" not in b["per_class_AP"]
-    for k in a["per_class_AP"]:
-        assert abs(a["per_class_AP"][k] - b["per_class_AP"][k]) < 1e-12, k
-    assert abs(a["mean_AP"] - b["mean_AP"]) < 1e-12 and a["num"] == b["num"]
+    res = perframe_average_precision(pr, gt, names)
+    assert "c0" not in res["per_class_AP"] and "c6" not in res["per_class_AP"] and len(res["per_class_AP"]) == Cn - 2
+    with pytest.raises(RuntimeError):
+        perframe_average_precision(pr, gt, names, metrics="cAP")
 
 
 def test_bench_gpus_n_spawns_n_ranks_dry_run():
