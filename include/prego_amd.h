@@ -210,6 +210,17 @@ size_t prego_vit_workspace_bytes(const prego_vit* h, int batch);
 int prego_vit_forward(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
                       void* workspace, size_t workspace_bytes, prego_stream_t stream);
 
+/* Per-frame inference of the `Transformer` entry over ONE whole video - what trainer/eval.py:36-56 needs from a model whose forward
+ * emits one logit vector per window (ViT.py:136-141) and requires T == window_size: out_logits[t] = ViTEnc(window ending at frame
+ * t), zero feature rows in front of the video (the training loader's windows, datasets/dataset.py:53-55,96-103, at stride 1).
+ * linear_encoding (ViT.py:124) runs once per frame, not once per (window, position); windows go through the encoder
+ * `windows_per_batch` at a time.  rgb / flow: device fp32 [n_frames][d_rgb | d_flow] (flow NULL = zeros); out_logits: device fp32
+ * [n_frames][n_classes] raw logits (ViTEnc applies no softmax); out_argmax (nullable): device int32 [n_frames], np.argmax of each
+ * row (trainer/eval.py:53).  flags bit 0: causal attention.  Workspace: prego_vit_frames_workspace_bytes. */
+size_t prego_vit_frames_workspace_bytes(const prego_vit* h, int n_frames, int windows_per_batch);
+int prego_vit_forward_frames(prego_vit* h, int n_frames, const float* rgb, const float* flow, float* out_logits, int32_t* out_argmax,
+                             int windows_per_batch, int flags, void* workspace, size_t workspace_bytes, prego_stream_t stream);
+
 /* Training of the "Transformer" registry entry: trainer/train.py:20-24 (fwd, loss, backward) over ViTEnc (ViT.py:117-143,
  * Transformer.py:5-82, Attention.py:21-41).  forward_train is ViTEnc.forward in training mode with every dropout rate 0
  * (cfg['dropout'] == cfg['attn_dropout_rate'] == 0; non-zero rates are rejected by the host module) and keeps the activations

@@ -187,7 +187,10 @@ void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int 
                        unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
 void launch_vit_cls_rows(const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
-                     const float* hb, int C, float* out, hipStream_t s);
+                     const float* hb, int C, float* out, hipStream_t s, int* argmax = nullptr);
+// sliding windows over one video: token rows of windows ending at frames t0 .. t0 + B - 1 from the per-frame encoding (vit.hip)
+void launch_vit_sliding_tokens(const float* enc, const float* enc_b, const float* cls, const float* pe, int t0, int B, int T, int E,
+                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);
 
 // streaming step (stream_step.hip): skinny products for n <= 16 rows, one frame per stream

@@ -37,11 +37,68 @@ __global__ void vit_cls_rows_kernel(const float* __restrict__ cls, const float* 
   for (int c = threadIdx.x; c < E; c += blockDim.x) xr[c] = cls[c] + pe[(size_t)T * E + c];
 }
 
+// Sliding windows over one video (the per-frame eval runner of the `Transformer` entry, prego_vit_forward_frames): window b of a
+// batch ends at frame t0 + b and holds frames [t - T + 1, t], zero feature rows in front of the video (the windowing the training
+// loader uses, datasets/dataset.py:53-55,96-103).  The linear encoding was computed ONCE per frame (enc [n_frames][E], bias
+// included); the positional row is added per (window, position) here: token j of window b = enc[t - T + 1 + j] + pe[j] (a zero
+// feature row encodes to the bias alone), token T = cls + pe[T] (ViT.py:124-129).  One wave per token row.  Outputs, all
+// optional: x (fp32 residual stream [B][T+1][E]), xn (bf16 LayerNorm(ln_w, ln_b) of the row: the first block's pre-norm fused in,
+// so a one-layer model never materialises x), x0 (fp32 [B][E]: token 0 of every window, the only residual row its last block reads).
+template <int MAXV>
+__global__ __launch_bounds__(256) void vit_sliding_tokens_kernel(const float* __restrict__ enc, const float* __restrict__ enc_b,
+                                                                 const float* __restrict__ cls, const float* __restrict__ pe, int t0,
+                                                                 int B, int T, int E, float* __restrict__ x,
+                                                                 const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                                 bf16_t* __restrict__ xn, float* __restrict__ x0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int N = T + 1, nv = E / 256;                      // 4-column groups per lane
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < (long long)B * N; row += (long long)gridDim.x * 4) {
+    const int b = (int)(row / N), j = (int)(row - (long long)b * N);
+    const int f = t0 + b - T + 1 + j;                     // frame of token j (j < T)
+    const float* src = j == T ? cls : (f >= 0 ? enc + (size_t)f * E : enc_b);
+    const float* per = pe + (size_t)j * E;
+    float v[MAXV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 a = *(const float4*)(src + c), p = *(const float4*)(per + c);
+        v[i][0] = a.x + p.x; v[i][1] = a.y + p.y; v[i][2] = a.z + p.z; v[i][3] = a.w + p.w;
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        if (x) *(float4*)(x + (size_t)row * E + c) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+        if (x0 && j == 0) *(float4*)(x0 + (size_t)b * E + c) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+      }
+    if (xn == nullptr) continue;
+    const float mu = wave_sum(s) / (float)E;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mu; q += d * d; }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 g = *(const float4*)(ln_w + c), bb = *(const float4*)(ln_b + c);
+        uint2 o;
+        o.x = pack_bf16x2((v[i][0] - mu) * rstd * g.x + bb.x, (v[i][1] - mu) * rstd * g.y + bb.y);
+        o.y = pack_bf16x2((v[i][2] - mu) * rstd * g.z + bb.z, (v[i][3] - mu) * rstd * g.w + bb.w);
+        *(uint2*)(xn + (size_t)row * E + c) = o;
+      }
+  }
+}
+
 __global__ __launch_bounds__(256) void vit_head_kernel(const float* __restrict__ x, int N, int E, const float* __restrict__ lnw,
                                                        const float* __restrict__ lnb, const float* __restrict__ hw,
-                                                       const float* __restrict__ hb, int C, float* __restrict__ out) {
-  extern __shared__ float sx[];                    // [E] normalised token + 8 reduction slots
+                                                       const float* __restrict__ hb, int C, float* __restrict__ out,
+                                                       int* __restrict__ argmax /*nullable: np.argmax of the C logits, first max wins*/) {
+  extern __shared__ float sx[];                    // [E] normalised token + 8 reduction slots + C logits (argmax)
   float* red = sx + E;
+  float* slog = red + 8;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xr = x + (size_t)b * N * E;         // token 0 of clip b
   float s = 0.f;
@@ -75,8 +132,20 @@ __global__ __launch_bounds__(256) void vit_head_kernel(const float* __restrict__
     for (int j = 0; j < 4; ++j) a[j] = wave_sum(a[j]);
     if (lane == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (k0 + j < C) out[(size_t)b * C + k0 + j] = a[j] + hb[k0 + j];
+      for (int j = 0; j < 4; ++j) if (k0 + j < C) { const float lg = a[j] + hb[k0 + j]; out[(size_t)b * C + k0 + j] = lg; slog[k0 + j] = lg; }
     }
+  }
+  if (argmax == nullptr) return;                   // block-uniform
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY; int mi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) if (slog[c] > mx) { mx = slog[c]; mi = c; }      // ascending c inside a lane: first max wins
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float omx = __shfl_xor(mx, o, 64); const int omi = __shfl_xor(mi, o, 64);
+      if (omx > mx || (omx == mx && omi < mi)) { mx = omx; mi = omi; }
+    }
+    if (lane == 0) argmax[b] = mi;
   }
 }
 
@@ -92,6 +161,13 @@ void launch_vit_cls_rows(const float* cls, const float* pe, int B, int T, int E,
   vit_cls_rows_kernel<<<B, 256, 0, s>>>(cls, pe, T, E, x);
 }
 void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, const float* lnb, const float* hw,
-                     const float* hb, int C, float* out, hipStream_t s) {
-  vit_head_kernel<<<B, 256, (E + 8) * sizeof(float), s>>>(x, N, E, lnw, lnb, hw, hb, C, out);
+                     const float* hb, int C, float* out, hipStream_t s, int* argmax) {
+  vit_head_kernel<<<B, 256, (E + 8 + C) * sizeof(float), s>>>(x, N, E, lnw, lnb, hw, hb, C, out, argmax);
+}
+void launch_vit_sliding_tokens(const float* enc, const float* enc_b, const float* cls, const float* pe, int t0, int B, int T, int E,
+                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s) {
+  long long rows = (long long)B * (T + 1);
+  int grid = (int)((rows + 3) / 4 < 32768 ? (rows + 3) / 4 : 32768);
+  if (E <= 2048) vit_sliding_tokens_kernel<8><<<grid, 256, 0, s>>>(enc, enc_b, cls, pe, t0, B, T, E, x, ln_w, ln_b, (bf16_t*)xn, x0);
+  else vit_sliding_tokens_kernel<16><<<grid, 256, 0, s>>>(enc, enc_b, cls, pe, t0, B, T, E, x, ln_w, ln_b, (bf16_t*)xn, x0);
 }

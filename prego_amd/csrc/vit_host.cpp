@@ -198,10 +198,12 @@ static int encoder_block(const prego_vit* h, const VitLayer& l, float* x, char* 
 // values are needed for every token, but the query, the attention output, the projection, the residual stream and the whole FFN
 // only for token 0 of each window - B rows instead of B*N.  Exact (the skipped rows never reach the logits); with num_layers = 1
 // it removes 44 % of a window's FLOPs.  Leaves the block's token-0 output in x0 [B, E].
+// have_xn: the caller already wrote LayerNorm1(x) to w.xn and token 0 of every window to w.x0 (the sliding-window token kernel
+// does both): x is not read at all.
 static int encoder_block_token0(const prego_vit* h, const VitLayer& l, const float* x, char* ws, const VitWs& w, int B, int N,
-                                int causal, hipStream_t s) {
+                                int causal, hipStream_t s, bool have_xn = false) {
   const int E = h->emb, M = B * N, dh = E / h->heads;
-  launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
+  if (!have_xn) launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
   GemmEpi e{};
   e.mode = EPI_QKV; e.q = ws + w.q0; e.k = ws + w.k; e.vn = ws + w.vn; e.n_tok = N; e.heads = h->heads; e.dh = dh; e.emb = E;
   e.q_scale = 1.0f / sqrtf((float)dh);
@@ -211,7 +213,7 @@ static int encoder_block_token0(const prego_vit* h, const VitLayer& l, const flo
   launch_gemm_bf16_nt_epi(ws + w.xn, N * E, l.qkv_w, E, nullptr, nullptr, 0, B, E, E, e, s);
   if (launch_flash_attention_v2(ws + w.q0, ws + w.k, ws + w.vn, ws + w.ao0, B, 1, N, h->heads, dh, causal, s)) return -1;
   float* x0 = (float*)(ws + w.x0);
-  if (hipMemcpy2DAsync(x0, (size_t)E * 4, x, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  if (!have_xn && hipMemcpy2DAsync(x0, (size_t)E * 4, x, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
   GemmEpi r{}; r.mode = EPI_RESIDUAL;
   launch_gemm_bf16_nt_epi(ws + w.ao0, E, l.proj_w, E, l.proj_b, x0, E, B, E, E, r, s);
   launch_ln_relu(true, x0, l.ln2_w, l.ln2_b, B, E, 1e-5f, ws + w.xn0, nullptr, 0.f, 0, 0, s, 0);
@@ -255,6 +257,67 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   }
   if (all_rows) launch_vit_head((const float*)(ws + w.x), B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
   else launch_vit_head((const float*)(ws + w.x0), B, 1, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ================================================================================================
+// per-frame inference over a whole video (the eval loop of trainer/eval.py:36-56 for model: 'Transformer')
+// ================================================================================================
+// ViTEnc emits one logit vector per window (ViT.py:136-141) and needs T == window_size; the per-frame output the eval loop
+// collects is the window ENDING at every frame, zero feature rows in front of the video - the windows the training loader cuts
+// (dataset.py:53-55,96-103) at stride 1.  Frame f sits in up to `window` windows, and linear_encoding (ViT.py:124, half of a
+// window's FLOPs at one layer) does not depend on the position inside the window (the positional table is added afterwards,
+// ViT.py:129): it runs ONCE per frame here.  Windows are processed `wb` at a time through the same blocks as prego_vit_forward.
+struct VitFramesWs { size_t xb, enc, win; VitWs w; size_t total; };
+static VitFramesWs vit_frames_ws(const prego_vit* h, int n_frames, int wb) {
+  VitFramesWs f{};
+  const size_t E = h->emb, din = h->d_rgb + h->d_flow;
+  size_t off = 0;
+  auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  f.xb = put((size_t)n_frames * din * 2); f.enc = put((size_t)n_frames * E * 4);
+  f.w = vit_ws(h, wb);
+  f.win = put(f.w.total);
+  f.total = off;
+  return f;
+}
+extern "C" size_t prego_vit_frames_workspace_bytes(const prego_vit* h, int n_frames, int windows_per_batch) {
+  return (h && n_frames > 0 && windows_per_batch > 0) ? vit_frames_ws(h, n_frames, windows_per_batch).total : 0;
+}
+extern "C" int prego_vit_forward_frames(prego_vit* h, int n_frames, const float* rgb, const float* flow, float* out_logits,
+                                        int32_t* out_argmax, int windows_per_batch, int flags, void* workspace, size_t workspace_bytes,
+                                        prego_stream_t stream) {
+  if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
+  if (n_frames <= 0 || windows_per_batch <= 0) return prego_fail_(PREGO_EINVAL, "n_frames %d, windows_per_batch %d", n_frames, windows_per_batch);
+  if ((h->d_rgb > 0 && !rgb) || (h->d_rgb == 0 && !flow)) return prego_fail_(PREGO_EINVAL, "missing input");
+  const int wb = windows_per_batch;
+  const VitFramesWs f = vit_frames_ws(h, n_frames, wb);
+  if (workspace_bytes < f.total) return prego_fail_(PREGO_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, f.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  char* ws = base + f.win;                      // the per-batch arena, laid out as prego_vit_forward's
+  const VitWs& w = f.w;
+  const int T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow;
+  const int causal = (flags & 1) ? 1 : 0;
+  float* enc = (float*)(base + f.enc);
+  launch_cat_convert(rgb, flow, n_frames, h->d_rgb, h->d_flow, base + f.xb, s);
+  launch_gemm_bf16_nt(base + f.xb, din, h->enc_w, din, h->enc_b, enc, E, n_frames, E, din, s);       // ViT.py:124, once per frame
+  const bool fused = h->layers == 1;            // one layer: the token kernel writes LayerNorm1(x) and x0; x is never materialised
+  for (int t0 = 0; t0 < n_frames; t0 += wb) {
+    const int B = std::min(wb, n_frames - t0);
+    const VitLayer& l0 = h->L[0];
+    launch_vit_sliding_tokens(enc, h->enc_b, h->cls, h->pe, t0, B, T, E, fused ? nullptr : (float*)(ws + w.x), l0.ln1_w, l0.ln1_b,
+                              fused ? ws + w.xn : nullptr, fused ? (float*)(ws + w.x0) : nullptr, s);
+    for (int li = 0; li < h->layers; ++li) {
+      const bool last = li + 1 == h->layers;
+      const int rc = last ? encoder_block_token0(h, h->L[li], (const float*)(ws + w.x), ws, w, B, N, causal, s, fused)
+                          : encoder_block(h, h->L[li], (float*)(ws + w.x), ws, w, B, N, causal, s);
+      if (rc) return prego_fail_(PREGO_EINVAL, "encoder block launch failed");
+    }
+    launch_vit_head((const float*)(ws + w.x0), B, 1, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls,
+                    out_logits + (size_t)t0 * h->ncls, s, out_argmax ? (int*)out_argmax + t0 : nullptr);
+  }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

@@ -75,7 +75,7 @@ class Evaluate(nn.Module):
         model.eval()
         output = {}
         self.last_device_argmax = {}
-        max_clips = model.engine().max_clips
+        max_clips = model.max_clips          # MROAD: the engine's clip capacity; ViTEnc (`model: 'Transformer'`): its own bound
         # data-parallel eval: videos are independent, so under torch.distributed rank r takes every world-th video of
         # the loader's order (no data-path collective); rank 0 gathers the per-video results once at the end
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -101,7 +101,7 @@ class Evaluate(nn.Module):
                     self._flush(model, batch, pred_scores, gt_targets, output, device)
                     frames = 0
             self._flush(model, batch, pred_scores, gt_targets, output, device)
-            model.engine().check()
+            model.check()
             if world > 1:
                 gathered = [None] * world if rank == 0 else None
                 dist.gather_object((per_video, [p.cpu().numpy() for p in pred_scores], [g.cpu().numpy() for g in gt_targets], output),

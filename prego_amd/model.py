@@ -104,6 +104,15 @@ class MROAD(nn.Module):
         eng = self.engine()
         return eng.forward_ragged(rgb_list, flow_list, softmax=True, want_out=want_probs, want_argmax=want_argmax)
 
+    @property
+    def max_clips(self) -> int:
+        """videos `Evaluate` may hand to one forward_clips call"""
+        return self.engine().max_clips
+
+    def check(self):
+        """surface a recurrence spin timeout of the eval engine (PregoError, PREGO_ETIMEOUT); synchronises the stream"""
+        self.engine().check()
+
     @torch.no_grad()
     def step(self, rgb, flow, h):
         """Online inference (not exposed by the reference, whose eval loop runs whole videos): one new frame per stream.

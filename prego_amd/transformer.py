@@ -148,6 +148,53 @@ class ViTEnc(nn.Module):
                                         self._ws.numel(), C.c_void_p(_stream_ptr(dev))))
         return {"logits": out.unsqueeze(1)}
 
+    # -- per-frame inference over whole videos (the eval loop, trainer/eval.py:36-56) ------------------------------------------
+    windows_per_batch = 256          # windows that go through the encoder together (one ViTEnc forward of that batch size)
+    max_clips = 64                   # Evaluate batches this many videos per call (each runs on its own: no cross-video batching)
+
+    @torch.no_grad()
+    def forward_frames(self, rgb, flow=None, want_argmax=True):
+        """One whole video: rgb [T, d_rgb] / flow [T, d_flow] fp32 cuda (flow None = zeros) -> (logits [T, C], argmax int32 [T]).
+        logits[t] = the reference forward on the `window_size` frames ending at t, zero feature rows in front of the video - the
+        windows the training loader cuts (dataset.py:53-55,96-103) at stride 1; linear_encoding runs once per frame
+        (prego_vit_forward_frames).  ViTEnc's output is raw logits in both modes (ViT.py:138-141)."""
+        lib, dev = self._handle()
+        rgb = rgb.float().contiguous() if self.use_rgb else None
+        flow = flow.float().contiguous() if (self.use_flow and flow is not None) else None
+        src = rgb if rgb is not None else flow
+        if src is None:
+            raise PregoError("forward_frames: a --no_rgb model needs the flow tensor")
+        T = int(src.shape[0])
+        wb = min(self.windows_per_batch, T)
+        need = lib.prego_vit_frames_workspace_bytes(self._h, T, wb)
+        if getattr(self, "_ws_frames", None) is None or self._ws_frames.numel() < need:
+            self._ws_frames = None
+            self._ws_frames = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((T, self.out_dim), dtype=torch.float32, device=dev)
+        arg = torch.empty((T,), dtype=torch.int32, device=dev) if want_argmax else None
+        with torch.cuda.device(dev):
+            check(lib.prego_vit_forward_frames(self._h, T, None if rgb is None else C.c_void_p(rgb.data_ptr()),
+                                               None if flow is None else C.c_void_p(flow.data_ptr()), C.c_void_p(out.data_ptr()),
+                                               None if arg is None else C.c_void_p(arg.data_ptr()), wb, 1 if self.causal else 0,
+                                               C.c_void_p(self._ws_frames.data_ptr()), self._ws_frames.numel(), C.c_void_p(_stream_ptr(dev))))
+        return out, arg
+
+    @torch.no_grad()
+    def forward_clips(self, rgb_list, flow_list=None, want_probs=True, want_argmax=True):
+        """the batched-eval interface `Evaluate` drives (same shape as MROAD.forward_clips): per video the per-frame score matrix
+        [T, C] (raw logits here) and int32 argmax [T]"""
+        outs, args = [], []
+        n = len(rgb_list) if rgb_list is not None else len(flow_list)
+        for i in range(n):
+            o, a = self.forward_frames(None if rgb_list is None else rgb_list[i], None if flow_list is None else flow_list[i], want_argmax)
+            outs.append(o)
+            args.append(a)
+        return (outs if want_probs else None), (args if want_argmax else None), None
+
+    def check(self):
+        """ViTEnc kernels have no bounded spins: nothing to poll (MROAD.check surfaces a recurrence timeout)"""
+        torch.cuda.synchronize(self.mlp_head.weight.device)
+
     def __del__(self):
         try:
             if self._h is not None:

@@ -70,16 +70,10 @@ def test_sharded_predict_and_grad_average_world2():
         assert out[i] == m.forward(x[None], torch.zeros_like(x)[None])[0].argmax(1).tolist()
 
 
-class _FakeEngine:
-    max_clips = 4
-
-    def check(self):
-        pass
-
-
 class _FakeModel:
-    """stands in for the HIP MROAD in the CPU test: same forward_clips contract, oracle port underneath"""
+    """stands in for the HIP MROAD in the CPU test: same forward_clips / max_clips / check contract, oracle port underneath"""
     assume_zero_flow = True
+    max_clips = 4
 
     def __init__(self, port):
         self.port = port
@@ -87,8 +81,8 @@ class _FakeModel:
     def eval(self):
         return self
 
-    def engine(self):
-        return _FakeEngine()
+    def check(self):
+        pass
 
     def forward_clips(self, rgb, flow, want_probs=True, want_argmax=True):
         probs = [self.port.forward(r[None].cpu(), torch.zeros_like(r)[None].cpu())[0] for r in rgb]

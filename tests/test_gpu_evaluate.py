@@ -35,7 +35,7 @@ class _Loader:
         return iter(self.items)
 
 
-@pytest.mark.parametrize("dtype,assume_zero", [("bf16", False), ("bf16", True), ("fp32", False)])
+@pytest.mark.parametrize("dtype,assume_zero", [("fp16", False), ("bf16", False), ("bf16", True), ("fp32", False)])
 def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     from prego_amd.registry import build_model, build_eval
     import prego_amd.model, prego_amd.evaluate  # noqa: F401
@@ -51,7 +51,7 @@ def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     mAP = ev(model, _Loader(g["lens"], 12, 20), logging.getLogger("t"), "cuda:0")
     js = json.load(open(tmp_path / "output_miniRoad" / "output_miniROAD.json"))
     assert set(js.keys()) == set(g["output"].keys())
-    tol = 1e-2 if dtype == "bf16" else 1e-3
+    tol = {"bf16": 1e-2, "fp16": 3e-3, "fp32": 1e-3}[dtype]
     total_mism = 0
     for i, T in enumerate(g["lens"]):
         vid = f"synth_video_{i}"
@@ -107,3 +107,31 @@ def test_device_average_precision_rejects_host_tensors():
     from prego_amd.metrics import perframe_average_precision_device
     with pytest.raises(PregoError):
         perframe_average_precision_device(torch.zeros(4, 3), torch.zeros(4, 3), ["a", "b", "c"])
+
+
+def test_evaluate_runs_the_transformer_entry_per_frame(tmp_path):
+    """`model: 'Transformer'` + --eval: EVAL["OAD"] drives ViTEnc through its sliding-window runner (one logit row per frame =
+    the window ending there), writes the reference's JSON schema, and scores the raw logits with the device AP kernel."""
+    from prego_amd.metrics import perframe_average_precision
+    from prego_amd.registry import build_model, build_eval
+    import prego_amd.transformer, prego_amd.evaluate  # noqa: F401
+    vl = os.path.join(tmp_path, "video_list.json")
+    json.dump({"EPIC-TENT-O": {"class_index": [f"c{i}" for i in range(12)]}}, open(vl, "w"))
+    cfg = epic_tent_cfg(model="Transformer", window_size=32, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0,
+                        eval="dummy.pth", video_list_path=vl, eval_output_dir=str(tmp_path / "output_miniRoad"))
+    model = build_model(cfg, "cuda:0")
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.vit_state_dict(cfg, 20).items()})
+    lens = [90, 33, 150]
+    loader = _Loader(lens, 12, 20)
+    ev = build_eval(cfg)
+    mAP = ev(model, loader, logging.getLogger("t"), "cuda:0")
+    js = json.load(open(tmp_path / "output_miniRoad" / "output_miniROAD.json"))
+    scores, gts = [], []
+    for i, item in enumerate(loader.items):
+        logits, arg = model.forward_frames(item[0][0].cuda(), item[1][0].cuda())
+        assert js[f"synth_video_{i}"]["pred"] == arg.cpu().numpy().tolist()
+        assert js[f"synth_video_{i}"]["gt"] == item[2][0].numpy().argmax(1).tolist()
+        scores.append(logits.cpu().numpy())
+        gts.append(item[2][0].numpy())
+    want = perframe_average_precision(np.concatenate(scores), np.concatenate(gts), [f"c{i}" for i in range(12)])["mean_AP"]
+    assert abs(mAP - want) < 1e-12

@@ -244,3 +244,41 @@ def test_attention_forward_kernel_vs_fp64(Nq, N, dh, causal):
     assert lib.prego_debug_attention_fwd(B, Nq, N, h, dh, causal, tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), out2.data_ptr(),
                                          None, None) == 0
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("window,T,layers", [(32, 300, 1), (128, 40, 1), (32, 70, 2)])
+def test_vit_per_frame_eval_runner_vs_oracle_windows(window, T, layers):
+    """prego_vit_forward_frames (ViTEnc.forward_frames): logits[t] = the reference forward on the `window` frames ending at t
+    with zero feature rows in front of the video (dataset.py:53-55,96-103 at stride 1) - checked against oracle_np.vit_forward
+    window by window, and against the batched prego_vit_forward on the same windows (same kernels behind the encoding: tight).
+    linear_encoding runs once per frame inside the runner; one-layer models never materialise the residual stream."""
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    cfg = assembly101_cfg(model="Transformer", window_size=window, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0,
+                          num_layers=layers)
+    sd = W.vit_state_dict(cfg, 20)
+    m = build_model(cfg, "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    m.windows_per_batch = 64                     # several batches, a ragged last one
+    rgb = W.tsn_features((T, 2048), 41, "vf.rgb")
+    flow = W.tsn_features((T, 2048), 41, "vf.flow")
+    got, arg = m.forward_frames(torch.from_numpy(rgb).cuda(), torch.from_numpy(flow).cuda())
+    got, arg = got.cpu().numpy(), arg.cpu().numpy()
+    assert got.shape == (T, 86) and np.array_equal(arg, got.argmax(1))
+    # the windows, as the training loader would cut them
+    pr = np.concatenate([np.zeros((window - 1, 2048), np.float32), rgb])
+    pf = np.concatenate([np.zeros((window - 1, 2048), np.float32), flow])
+    wr = np.stack([pr[t:t + window] for t in range(T)])
+    wf = np.stack([pf[t:t + window] for t in range(T)])
+    idx = np.unique(np.concatenate([np.arange(0, min(T, 6)), np.linspace(0, T - 1, 24).astype(int), [window - 2, window - 1, window] if T > window else []]).astype(int))
+    ref = O.vit_forward(sd, wr[idx], wf[idx], 8, num_layers=layers)["logits"][:, 0]
+    scale = np.abs(ref).max()
+    assert np.abs(got[idx] - ref).max() < 1e-2 * max(1.0, scale), np.abs(got[idx] - ref).max()
+    with torch.no_grad():
+        bat = torch.cat([m(torch.from_numpy(wr[i:i + 64]).cuda(), torch.from_numpy(wf[i:i + 64]).cuda())["logits"][:, 0] for i in range(0, T, 64)]).cpu().numpy()
+    assert np.abs(got - bat).max() < 2e-3 * max(1.0, scale), np.abs(got - bat).max()
+    # the batched-eval interface Evaluate drives
+    outs, args, _ = m.forward_clips([torch.from_numpy(rgb).cuda()], [torch.from_numpy(flow).cuda()])
+    assert np.array_equal(outs[0].cpu().numpy(), got) and np.array_equal(args[0].cpu().numpy(), arg)
