@@ -34,6 +34,11 @@ def parse():
     ap.add_argument("--workload", default="assembly101", choices=["assembly101", "synth512"],
                     help="assembly101 = BASELINE configs[1] (the metric's config); synth512 = configs[4] per-GPU share "
                          "(512 clips x 512 frames, zero flow)")
+    ap.add_argument("--mode", default="eval", choices=["eval", "train"],
+                    help="eval = the headline metric (per-frame inference); train = BASELINE configs[2]: data-parallel training steps "
+                         "(fwd + OadLoss + BPTT + bucketed gradient all-reduce over RCCL + fused AdamW), global batch fixed (strong scaling)")
+    ap.add_argument("--global-batch", type=int, default=16, help="--mode train: windows per step over all ranks (configs/miniroad_assembly101-O.yaml: 16)")
+    ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="--mode train: all-reduce the gradient bucket in bf16")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (train step, ViTEnc, causal attention, fp32 mode)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU work): checks the N-rank launch path on a CPU box")
     ap.add_argument("--steps", type=int, default=10)      # >= 10 timed runs
@@ -66,8 +71,12 @@ def spawn_ranks(args) -> int:
     return subprocess.call(cmd)
 
 
+GRAD_BUCKET_ELEMS = 2048 * 4096 + 3 * 2048 + 3072 * 2048 + 3072 * 1024 + 2 * 3072 + 86 * 1024 + 86      # 17 926 230 fp32 = 71.7 MB
+
+
 def dry_run(args, rank, world):
-    """launch-path check without a GPU: gloo rendezvous, barrier, max-over-ranks reduction, one JSON line from rank 0"""
+    """launch-path check without a GPU: gloo rendezvous, barrier, max-over-ranks reduction, one JSON line from rank 0.
+    --mode train also pushes a gradient bucket of the real size through the trainer's bucketed all-reduce."""
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -77,10 +86,89 @@ def dry_run(args, rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     print(f"[bench] rank {rank}: dist.get_world_size() = {dist.get_world_size()}", file=sys.stderr, flush=True)
     assert dist.get_world_size() == world == args.gpus and float(t.item()) == world
+    line = {"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "dry_run": True, "mode": args.mode}
+    if args.mode == "train":
+        from prego_amd.distributed import allreduce_mean_buckets_
+        n = GRAD_BUCKET_ELEMS
+        flat = torch.full((n,), float(rank + 1))
+        third = n // 3
+        allreduce_mean_buckets_(flat, [(2 * third, n), (third, 2 * third), (0, third)], world, None, args.grad_compress)
+        want = (world + 1) / 2.0
+        assert abs(float(flat[0]) - want) < 1e-2 and abs(float(flat[-1]) - want) < 1e-2
+        line.update(global_batch=args.global_batch, local_batch=max(1, args.global_batch // world), grad_bucket_bytes=4 * n,
+                    grad_compress=args.grad_compress)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "dry_run": True}), flush=True)
+        print(json.dumps(line), flush=True)
     dist.destroy_process_group()
+
+
+def train_mode(args, rank, world, dev, dist):
+    """BASELINE configs[2]: MiniROAD training steps, data parallel over the ranks.  One step = what trainer/train.py:20-26 does for one
+    batch through TRAINER["OAD"] (forward, OadLoss, zero_grad, BPTT backward, gradient all-reduce in three sub-buckets that start
+    under the backward, fused AdamW, loss.item()), on `global_batch / N` windows of 128 frames per rank (the reference's batch of
+    16 split over the GPUs: strong scaling).  Rank 0 prints one JSON line."""
+    from prego_amd import weights as W
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.optim import FusedAdamW
+    from prego_amd.registry import TRAINER, build_criterion, build_model
+    import prego_amd.loss, prego_amd.model, prego_amd.trainer  # noqa: F401,E401
+    if args.global_batch % world:
+        raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} ranks")
+    Bl, T = args.global_batch // world, 128
+    cfg = assembly101_cfg(compute_dtype="bf16", grad_compress=args.grad_compress)
+    model = build_model(cfg, dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.miniroad_state_dict(cfg, 20).items()})
+    crit = build_criterion(cfg, dev)
+    opt = FusedAdamW([{"params": list(model.parameters()), "initial_lr": 1e-4}], lr=1e-4, weight_decay=0.05, model=model)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77 + rank)
+    rgb = torch.randn((Bl, T, 2048), device=dev, generator=gen).clamp_(min=0)
+    flow = torch.randn((Bl, T, 2048), device=dev, generator=gen).clamp_(min=0)
+    tgt = torch.zeros((Bl, T, 86), device=dev)
+    tgt[:, :, 3 + rank] = 1
+    item = (rgb, flow, tgt, ("v",) * Bl, torch.zeros(Bl), torch.zeros(Bl))
+    train = TRAINER["OAD"]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    train([item] * max(1, args.warmup), model, crit, opt, None, 0, dev)
+    barrier()
+    t0 = time.perf_counter()
+    loss = train([item] * args.steps, model, crit, opt, None, 1, dev)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        step_ms = dt / args.steps * 1e3
+        frames = args.global_batch * T
+        fl = 3.0 * frames * FLOP_PER_FRAME
+        bucket = 4 * GRAD_BUCKET_ELEMS
+        wire = bucket // 2 if args.grad_compress == "bf16" else bucket
+        print(json.dumps({
+            "metric": "training frames/sec (MiniROAD, windows of 128 frames, OadLoss + AdamW), data parallel", "value": frames / (dt / args.steps),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "mode": "train",
+            "config": {"workload": "BASELINE configs[2]: Assembly101-O training step, global batch %d windows x 128 frames x (2048 rgb + 2048 "
+                                   "flow), dropout 0.2, AdamW lr 1e-4 wd 0.05" % args.global_batch,
+                       "local_batch": Bl, "parallelism": f"window-sharded dp{world}, one gradient all-reduce per step in 3 sub-buckets (RCCL)",
+                       "weights": "random init, seed 20"},
+            "grad_bucket_bytes": bucket, "grad_wire_bytes": wire, "grad_compress": args.grad_compress,
+            "ring_allreduce_floor_ms": (2.0 * (world - 1) / world * wire / 153e9 * 1e3) if world > 1 else 0.0,
+            "roofline": {"bound": "mfma", "achieved": fl / step_ms / 1e9 / world, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": fl / step_ms / 1e9 / world / PEAK_BF16_TFLOPS,
+                         "note": "per GPU; 3 x forward FLOPs over the whole step; 128 sequential BPTT steps: latency-bound", "traffic": None},
+            "final_loss_sum": float(loss)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -108,6 +196,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.mode == "train":
+        return train_mode(args, rank, world, dev, dist)
 
     from prego_amd import weights as W
     from prego_amd.config import assembly101_cfg

@@ -143,6 +143,11 @@ int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits,
  * workspace is passed back as fwd_workspace (untouched in between).  dlogits[i]: device fp32 [lens[i], n_classes]
  * (any values: all frames are honoured).  The ten gradient tensors have the shapes of set_weights' arguments and are
  * OVERWRITTEN.  All column sums are fixed-order (deterministic). */
+/* Data-parallel training (trainer/train.py:20-24 under clip sharding): hipEvent_t handles (NULL = none) that every following
+ * prego_miniroad_backward records on its stream at two milestones - f_classification gradients final; all four GRU gradients
+ * final - so the caller can all-reduce those buckets on another stream under the rest of the backward (layer1's weight gradient,
+ * 47 % of the bytes, is final only when backward returns).  The events stay owned by the caller. */
+int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_done, void* ev_gru_done);
 size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens);
 int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* dlogits,
                             float* g_layer1_w, float* g_layer1_b, float* g_ln_w, float* g_ln_b, float* g_w_ih,

@@ -30,7 +30,7 @@ SYMBOLS = [
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
-    "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames",
+    "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events",
 ]
 
 
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
     lib.prego_miniroad_backward_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32)]
     lib.prego_miniroad_backward_workspace_bytes.restype = sz
     lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]
+    lib.prego_miniroad_backward_events.argtypes = [vp, vp, vp]
     lib.prego_window_vote.argtypes = [vp, i64, i32, i32, vp, vp]
     lib.prego_perframe_ap_workspace_bytes.argtypes = [i64, i32]
     lib.prego_perframe_ap_workspace_bytes.restype = sz

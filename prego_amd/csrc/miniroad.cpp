@@ -82,6 +82,9 @@ struct prego_miniroad {
   unsigned long long drop_seed = 0;
   int kept_kx = 0;              // K of layer1 actually multiplied by the last PREGO_FWD_KEEP forward
   int kept_rows = 0;
+  // data-parallel training: events the NEXT backward records when a group of gradient tensors is final (prego_miniroad_backward_events),
+  // so that the caller can start reducing that bucket on another stream while the rest of the backward runs
+  hipEvent_t bwd_ev[2] = {nullptr, nullptr};
   // plan cache
   std::vector<int32_t> plan_lens;
   std::vector<int> h_rowoff, h_nact, h_sorted;      // h_sorted: first clip of each slot (slot order)
@@ -816,6 +819,14 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   return L;
 }
 
+extern "C" int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_done, void* ev_gru_done) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  h->bwd_ev[0] = (hipEvent_t)ev_head_done;
+  h->bwd_ev[1] = (hipEvent_t)ev_gru_done;
+  return PREGO_OK;
+}
+
 extern "C" size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens) {
   if (!h || n_clips <= 0 || !lens) return 0;
   long long total = 0;
@@ -883,6 +894,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   launch_transpose_convert(bf, bf, HR, R, H, H, bw + L.HRt, Rp, s);                       // [H][Rp]
   gemm_nt(h, bw + L.dLt, Rp, bw + L.HRt, Rp, nullptr, (float*)(bw + L.dWc), H, Cp, H, Rp, s);   // dWc[Cp][H]
   HIPCHK(hipMemcpyAsync(g_fc_w, bw + L.dWc, (size_t)C * H * 4, hipMemcpyDeviceToDevice, s));
+  if (h->bwd_ev[0]) HIPCHK(hipEventRecord(h->bwd_ev[0], s));            // f_classification gradients are final
   launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
   gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
   launch_relu_mask((const float*)(bw + L.dHR), HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);
@@ -931,6 +943,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   launch_transpose_convert(bf, bf, bw + L.dGHop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
   launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
   gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
+  if (h->bwd_ev[1]) HIPCHK(hipEventRecord(h->bwd_ev[1], s));            // all four GRU gradients are final (layer1 / LayerNorm follow)
   // d e = dGI . W_ih
   launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
   gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);

@@ -67,3 +67,49 @@ def allreduce_mean_(flat: torch.Tensor, world: int):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
     return flat
+
+
+_COMM_STREAMS = {}
+
+
+def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None, compress: str | None = None):
+    """Gradient averaging of the flat bucket in sub-buckets `bounds` = [(lo, hi), ...] given in the order the backward finishes
+    them.  On a GPU every sub-bucket is reduced on a side stream as soon as its event (events[i]; None = "final in stream order")
+    has fired, i.e. under the rest of the backward; the caller's stream waits for the side stream at the end.  compress='bf16'
+    sends bf16 (half the bytes over the xGMI ring; the sum runs in bf16 on the wire, the average and everything after it in fp32).
+    On CPU tensors (gloo tests) the same sub-buckets are reduced one after the other."""
+    if world <= 1:
+        return flat
+    if compress not in (None, "bf16"):
+        raise ValueError(f"compress {compress!r}: expected None or 'bf16'")
+
+    def one(lo, hi):
+        view = flat[lo:hi]
+        if compress == "bf16":
+            buf = view.to(torch.bfloat16)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            view.copy_(buf)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        view.div_(world)
+
+    if not flat.is_cuda:
+        for lo, hi in bounds:
+            one(lo, hi)
+        return flat
+    dev = flat.device
+    comm = _COMM_STREAMS.get(dev)
+    if comm is None:
+        comm = _COMM_STREAMS[dev] = torch.cuda.Stream(dev)
+    cur = torch.cuda.current_stream(dev)
+    flat.record_stream(comm)
+    for i, (lo, hi) in enumerate(bounds):
+        ev = events[i] if events is not None else None
+        if ev is not None:
+            comm.wait_event(ev)          # recorded inside prego_miniroad_backward when this sub-bucket became final
+        else:
+            comm.wait_stream(cur)        # final once everything enqueued so far has run
+        with torch.cuda.stream(comm):
+            one(lo, hi)
+    cur.wait_stream(comm)
+    return flat

@@ -252,6 +252,20 @@ class MiniRoadEngine:
             total += (n + 63) // 64 * 64            # 256-byte aligned views
         self._grad_flat = torch.empty(total, dtype=torch.float32, device=self.device)   # every gradient tensor is overwritten by backward
         grads = {k: self._grad_flat[o:o + n].view(shapes[k]) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}
+        # buckets of the flat tensor in the order the backward finishes them (csrc/miniroad.cpp: head, GRU, then LayerNorm / layer1):
+        # the first two are announced by events recorded inside the backward, the last one is final when backward returns
+        o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
+        self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]
+        self._grad_events = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            if getattr(self, "_bwd_events", None) is None:
+                evs = [torch.cuda.Event(), torch.cuda.Event()]
+                with torch.cuda.device(self.device):
+                    for e in evs:
+                        e.record()                  # creates the hipEvent_t behind the torch object
+                    check(self.lib.prego_miniroad_backward_events(self.h, C.c_void_p(evs[0].cuda_event), C.c_void_p(evs[1].cuda_event)))
+                self._bwd_events = evs
+            self._grad_events = [self._bwd_events[0], self._bwd_events[1], None]
         dl_p = ptr_array([dlogits.data_ptr() + b * T * ncls * 4 for b in range(B)])
         with torch.cuda.device(self.device):
             check(self.lib.prego_miniroad_backward(

@@ -46,6 +46,7 @@ class MROAD(nn.Module):
         # build-specific knobs (not reference keys)
         self.compute_dtype = cfg.get("compute_dtype", "fp16")          # 'fp16' | 'bf16' | 'fp32'
         self.assume_zero_flow = bool(cfg.get("assume_zero_flow", False))  # dataset.py:69 zeroes the flow half
+        self.grad_compress = cfg.get("grad_compress")                    # None | 'bf16': data-parallel gradient all-reduce on bf16 (half the bytes)
         self._engines = {}            # (device, operand dtype) -> [MiniRoadEngine, parameter versions its copies belong to]
 
     # -- engine plumbing -------------------------------------------------------------------

@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .distributed import allreduce_mean_
+from .distributed import allreduce_mean_, allreduce_mean_buckets_
 from .registry import TRAINER
 
 
@@ -19,7 +19,13 @@ def _allreduce_grads(model):
     eng = getattr(model, "_engine", None)
     flat = getattr(eng, "_grad_flat", None) if eng is not None else None
     if flat is not None and all(p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in ps):
-        allreduce_mean_(flat, world)        # the HIP backward wrote every gradient into one bucket: reduce it in place
+        # the HIP backward wrote every gradient into one flat bucket: reduce it in place, in the three sub-buckets the backward
+        # finishes one after the other (head, GRU, layer1 + LayerNorm) - the first two start under the rest of the backward
+        bounds = getattr(eng, "_grad_bounds", None)
+        if bounds:
+            allreduce_mean_buckets_(flat, bounds, world, getattr(eng, "_grad_events", None), getattr(model, "grad_compress", None))
+        else:
+            allreduce_mean_(flat, world)
         return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])        # generic modules: gather, reduce, scatter
     allreduce_mean_(flat, world)

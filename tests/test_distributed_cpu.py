@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -154,6 +155,35 @@ class _TinyMROAD(torch.nn.Module):
         return {"logits": self.fc(torch.relu(h))}
 
 
+class _BucketMROAD(_TinyMROAD):
+    """+ the gradient layout of the HIP engine (engine.backward): every gradient is a view of ONE flat tensor, cut into
+    sub-buckets listed in the order the backward finishes them; the trainer reduces those in place (allreduce_mean_buckets_)"""
+
+    def __init__(self, compress=None):
+        super().__init__()
+        ps = list(self.parameters())
+        offs = [0]
+        for p in ps:
+            offs.append(offs[-1] + p.numel())
+        flat = torch.zeros(offs[-1])
+
+        class _E:
+            def check(self):
+                pass
+        self._engine = _E()
+        self._engine._grad_flat = flat
+        mid = offs[len(ps) // 2]
+        self._engine._grad_bounds = [(mid, offs[-1]), (0, mid)]          # later tensors first, as the backward finishes them
+        self._engine._grad_events = None
+        self.grad_compress = compress
+        for p, o in zip(ps, offs):
+            def hook(param, o=o):
+                v = flat[o:o + param.numel()].view_as(param)
+                v.copy_(param.grad)
+                param.grad = v
+            p.register_post_accumulate_grad_hook(hook)
+
+
 def _oad_loss_torch(out, target):          # criterions/loss.py:15-34
     lg, tg = out["logits"][:, -1, :], target[:, -1, :]
     return torch.mean(torch.sum(-torch.nn.functional.normalize(tg) * torch.log_softmax(lg, -1), dim=1))
@@ -167,7 +197,7 @@ def _train_batches():
     return rgb, flow, tgt
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, kind="tiny"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
     from prego_amd import distributed as D
@@ -187,7 +217,7 @@ def _train_worker(rank, world, port, q):
         sampler = _S()
 
     loader = _Loader([(rgb[sl], flow[sl], tgt[sl], ("v",) * per, torch.zeros(per), torch.zeros(per))])
-    model = _TinyMROAD()
+    model = _TinyMROAD() if kind == "tiny" else _BucketMROAD("bf16" if kind == "bucket_bf16" else None)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     loss = train_one_epoch(loader, model, _oad_loss_torch, opt, None, 3, "cpu")
     assert loader.sampler.epoch == 3                  # DistributedSampler-style samplers get the epoch
@@ -217,6 +247,32 @@ def test_train_one_epoch_allreduces_grads_like_the_global_batch():
         a, b = torch.tensor(a), torch.tensor(b)
         assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
     assert not torch.allclose(torch.tensor(res[1][1][0]), _TinyMROAD().l1.weight)      # the step did move the weights
+
+
+@pytest.mark.parametrize("kind", ["bucket", "bucket_bf16"])
+def test_train_one_epoch_bucketed_allreduce_matches_global_batch(kind):
+    """the flat-bucket path of _allreduce_grads (what the HIP engine's backward feeds): sub-buckets reduced in place, in fp32
+    (exactly the global-batch step) and bf16-compressed (within bf16 rounding of it)"""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, kind)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    init = [p.detach() for p in _TinyMROAD().parameters()]
+    for a, b, p0 in zip(res[1][1], res[2][1], init):
+        a, b = torch.tensor(a), torch.tensor(b)
+        if kind == "bucket":
+            assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+        else:       # the update (lr * mean gradient) carries bf16 rounding: 2^-8 relative on the step, not on the weight
+            step = (a - p0).abs().max().item()
+            assert (a - b).abs().max().item() <= 1e-2 * step + 1e-7, ((a - b).abs().max().item(), step)
 
 
 def test_epoch_window_sampler_partitions_and_reshuffles():

@@ -170,6 +170,21 @@ def test_bench_gpus_n_spawns_n_ranks_dry_run():
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
+def test_bench_train_mode_dry_run_reduces_a_real_size_bucket():
+    """`bench.py --mode train --gpus 2 --dry-run`: two ranks over gloo push a 71.7 MB gradient bucket through the trainer's
+    bucketed all-reduce (fp32 and bf16-compressed) and rank 0 reports the batch split"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--grad-compress", "bf16"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--mode", "train"] + extra,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["mode"] == "train" and line["local_batch"] == 8 and line["grad_bucket_bytes"] == 71704920
+        assert line["grad_compress"] == (extra[1] if extra else None)
+
+
 def _g9_tree(tmp_path):
     from prego_amd import weights as W
     lens = {"vidA": 300, "vidB": 157}
