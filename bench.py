@@ -285,6 +285,8 @@ def main():
         pack_gbs = kt["pack_bytes"] / (kt["pack_ms"] * 1e-3) / 1e9 if kt["pack_ms"] > 0 else 0.0
         gru_flop = 2.0 * 1024 * 3072 * frames * args.steps                  # recurrent product, algorithmic
         gru_tflops = gru_flop / (kt["gru_ms"] * 1e-3) / 1e12 if kt["gru_ms"] > 0 else 0.0
+        # HBM traffic per launch is NOT measured in this run (PMC counters need their own rocprofv3 passes): the figures come from
+        # the committed PMC summary, and the line says which file / workload / tree they belong to
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -292,6 +294,9 @@ def main():
                 traffic = json.load(open(tpath))
             except Exception:
                 traffic = {}
+        traffic_source = {"file": traffic.get("source"), "collected_at_git": traffic.get("git"), "operand_dtype": traffic.get("dtype"),
+                          "workload": traffic.get("workload", "64 clips x 0.25 length of the bench workload: identical per-launch shapes (49 152-row chunks)"),
+                          "measured_in_this_run": False} if traffic else None
         step_ms = dt / args.steps * 1e3
         gemm_name = {"bf16": "gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, bf16>", "fp16": "gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16>",
                      "fp32": "gemm_f32_nt_kernel"}[args.dtype] + " (layer1 + W_ih projections)"
@@ -325,7 +330,7 @@ def main():
                         "flow": "non-zero (full K=4096 layer1 GEMM)", "parallelism": f"clip-sharded dp{world}, no collective",
                         "weights": "random init, seed 20"}),
             # the kernel with the largest share of the timed region; every kernel's own roofline is under "rooflines"
-            "roofline": dominant,
+            "roofline": dict(dominant, traffic_source=traffic_source),
             "rooflines": {"gemm": rl_gemm, "gru_recurrence": rl_gru, "pack": rl_pack},
             "model_flop_per_frame": FLOP_PER_FRAME, "model_tflops": value * FLOP_PER_FRAME / 1e12,
             "output_sane": ok,
@@ -334,8 +339,10 @@ def main():
         if not args.no_secondary and world == 1 and not synth and args.dtype in ("bf16", "fp16"):
             del rgb, flow, out
             torch.cuda.empty_cache()
-            line["secondary"] = secondary(dev, lens, sd)
+            line["secondary"] = secondary(dev, lens, sd, args.dtype)
             line["value_fp32"] = line["secondary"].get("value_fp32")
+            other = "bf16" if args.dtype == "fp16" else "fp16"
+            line[f"value_{other}"] = line["secondary"].get(f"value_{other}")
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(sd, lens, args.cpu_budget)
         print(json.dumps(line), flush=True)
@@ -360,7 +367,7 @@ def _time_ms(fn, n=10, warm=3, reps=3):
     return best
 
 
-def secondary(dev, lens, sd):
+def secondary(dev, lens, sd, head_dtype="fp16"):
     """Secondary paths of SURVEY section 8, measured in the same run (rank 0, N = 1; not the headline metric):
     BASELINE configs[2] shape on one GPU (train step 16 x 128: fwd + OadLoss + BPTT + AdamW), the `Transformer` (ViTEnc)
     forward at 256 windows of 128 frames, BASELINE configs[3]'s long-window causal AttentionLayer (B = 16, L = 1024), and the
@@ -463,7 +470,16 @@ def secondary(dev, lens, sd):
     with torch.no_grad():
         ms = _time_ms(lambda: vm(x1r, x1f), n=20)
     res["vit_window1_us"] = ms * 1e3
-    del xr, xf, x1r, x1f
+    # per-frame eval runner of the Transformer entry (prego_vit_forward_frames): one 8 192-frame video, a window ending at every frame,
+    # linear_encoding once per frame
+    Tv = 8192
+    vr = torch.randn(Tv, 2048, device=dev).clamp_(min=0)
+    vf = torch.randn(Tv, 2048, device=dev).clamp_(min=0)
+    ms = _time_ms(lambda: vm.forward_frames(vr, vf), n=3, warm=1, reps=2)
+    res["vit_frames_per_s"] = Tv / ms * 1e3
+    res["vit_frames"] = {"shape": "one video of 8 192 frames, window 128, stride 1, heads 8, 1 layer (256 windows per encoder batch)", "ms": ms,
+                         "note": "sliding-window runner: per frame one window's attention + token-0 tail; the encoding GEMM runs per frame, not per (window, position)"}
+    del xr, xf, x1r, x1f, vr, vf
     # ---- ViTEnc training step (the row the round-1 verdict added: trainer forward/backward through the Transformer entry)
     vcrit = build_criterion(vcfg, dev)
     vopt = FusedAdamW([{"params": list(vm.parameters()), "initial_lr": 1e-4}], lr=1e-4, weight_decay=0.05, model=vm)
@@ -494,21 +510,87 @@ def secondary(dev, lens, sd):
                                        "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "4 projections + causal QK^T/AV (half the square)"}}
     del x
     torch.cuda.empty_cache()
-    # ---- the headline pass with fp32 operands (exact-fp32 MFMA: 157 TFLOP/s peak), one warm-up + two timed passes
-    cfg32 = assembly101_cfg(compute_dtype="fp32")
-    m32 = build_model(cfg32, dev)
-    m32.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
-    m32.eval()
-    eng = m32.engine()
+    # ---- `main.py --eval` end to end (trainer/eval.py:30-84 through EVAL["OAD"]): features in pinned HOST memory -> H2D on a side
+    # stream, batched forward, argmax on the device, the reference's output JSON, per-frame mAP by the device AP kernel
+    res.update(e2e_eval(dev, lens, sd))
+    # ---- the headline pass with the OTHER 16-bit operand type (same kernels, same bytes) and with fp32 operands (exact-fp32 MFMA:
+    # 157 TFLOP/s peak; one warm-up + two timed passes)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234)
     rgb = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
     flow = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
-    ms = _time_ms(lambda: eng.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True), n=2, warm=1, reps=1)
-    eng.check()
-    res["value_fp32"] = sum(lens) / ms * 1e3
-    res["fp32_pass_ms"] = ms
+    other = "bf16" if head_dtype == "fp16" else "fp16"
+    for dt_, n_, warm_ in ((other, 5, 2), ("fp32", 2, 1)):
+        mx = build_model(assembly101_cfg(compute_dtype=dt_), dev)
+        mx.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        mx.eval()
+        eng = mx.engine()
+        ms = _time_ms(lambda: eng.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True), n=n_, warm=warm_, reps=1)
+        eng.check()
+        res[f"value_{dt_}"] = sum(lens) / ms * 1e3
+        res[f"{dt_}_pass_ms"] = ms
+        del mx, eng
+        torch.cuda.empty_cache()
     return res
+
+
+def e2e_eval(dev, lens, sd, n_videos=60):
+    """secondary.e2e_eval_*: Evaluate over `n_videos` of the bench's clip lengths held in pinned host memory (what a DataLoader with
+    pin_memory=True hands the loop), the flow half identically zero as the shipped configs' loader makes it (dataset.py:63-69, never
+    shipped).  Two feeders: fp32 features (the reference's) and fp16 features (cfg['feature_dtype'], the model's operand type: half
+    the bytes per frame).  The PCIe floor of each is measured in the same run (one 1 GiB pinned -> device copy)."""
+    import logging
+    import tempfile
+    from prego_amd.config import assembly101_cfg
+    from prego_amd.registry import build_eval, build_model
+    import prego_amd.evaluate  # noqa: F401
+    tmp = tempfile.mkdtemp()
+    vl = os.path.join(tmp, "vl.json")
+    json.dump({"ASSEMBLY101-O": {"class_index": [f"c{i}" for i in range(86)]}}, open(vl, "w"))
+    cfg = assembly101_cfg(eval="ckpt.pth", video_list_path=vl, eval_output_dir=os.path.join(tmp, "out"))
+    model = build_model(cfg, dev)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    model.eval()
+    lens = lens[:n_videos]
+    frames = int(sum(lens))
+    g = torch.Generator().manual_seed(5)
+    base = [torch.randn((1, T, 2048), generator=g).clamp_(min=0) for T in lens]
+    tgts = []
+    for i, T in enumerate(lens):
+        t = torch.zeros(1, T, 86)
+        t[0, torch.arange(T), (torch.arange(T) // 97 + i) % 86] = 1
+        tgts.append(t.pin_memory())
+    zero = torch.zeros(1, 1, 2048)
+    probe = torch.empty(1 << 28, dtype=torch.float32).pin_memory()
+    dst = torch.empty_like(probe, device=dev)
+    dst.copy_(probe, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    dst.copy_(probe, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    h2d_gbs = probe.numel() * 4 / (time.perf_counter() - t0) / 1e9
+    del probe, dst
+    out = {"e2e_eval": {"videos": len(lens), "frames": frames, "h2d_pinned_GBps": h2d_gbs,
+                        "path": "pinned host features -> H2D (side stream) -> batched forward -> argmax -> output_miniROAD.json -> device per-frame mAP"}}
+    ev = build_eval(cfg)
+    log = logging.getLogger("bench.e2e")
+    for name, dt_ in (("fp32", torch.float32), ("fp16", torch.float16)):
+        items = [(b.to(dt_).pin_memory(), zero.expand(1, b.shape[1], 2048), t, (f"v{i}",), torch.tensor([0]), torch.tensor([b.shape[1]]))
+                 for i, (b, t) in enumerate(zip(base, tgts))]
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            ev(model, items, log, dev)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        bytes_per_frame = 2048 * (4 if dt_ == torch.float32 else 2) + 86 * 4
+        out["e2e_eval"][name] = {"frames_per_s": frames / best, "seconds": best, "pcie_bytes_per_frame": bytes_per_frame,
+                                 "pcie_floor_frames_per_s": h2d_gbs * 1e9 / bytes_per_frame}
+        del items
+    out["e2e_eval_frames_per_s"] = out["e2e_eval"]["fp16"]["frames_per_s"]
+    out["e2e_eval_frames_per_s_fp32_features"] = out["e2e_eval"]["fp32"]["frames_per_s"]
+    return out
 
 
 def cpu_baseline(sd, lens, budget_s):
@@ -556,16 +638,19 @@ def cpu_baseline(sd, lens, budget_s):
     bat_fps, bat_thr = 0.0, best_thr
     for thr in sorted({best_thr, min(cores, 32), min(cores, 64), min(cores, 128)}):
         torch.set_num_threads(thr)
-        port.forward(rb[:2], fb[:2])
-        t0 = time.perf_counter()
-        port.forward(rb, fb)
-        f = Bb * Tb / (time.perf_counter() - t0)
+        port.forward(rb, fb)                                  # warm-up at the timed shape and thread count
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            port.forward(rb, fb)
+            ts.append(time.perf_counter() - t0)
+        f = Bb * Tb / sorted(ts)[1]                           # median of three
         if f > bat_fps:
             bat_fps, bat_thr = f, thr
     torch.set_num_threads(best_thr)
     return {"value": frames / secs, "unit": "frames/s", "cores": best_thr, "kind": "port", "host_logical_cpus": cores,
             "batched": {"value": bat_fps, "unit": "frames/s", "cores": bat_thr,
-                        "sample": f"one forward of {Bb} windows x {Tb} frames (the GPU run's many-clips-per-forward batching)"},
+                        "sample": f"median of 3 forwards of {Bb} windows x {Tb} frames after a warm-up at that shape (the GPU run's many-clips-per-forward batching)"},
             "sample": f"{frames} frames = whole videos of {T} frames (median clip length), batch 1 per forward (reference eval "
                       f"batching, trainer/eval.py:36-45), {secs:.1f} s of CPU time, fp32, torch {torch.__version__} CPU ops, "
                       f"best of a 4..64-thread sweep = {best_thr} threads"}

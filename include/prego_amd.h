@@ -47,7 +47,9 @@ enum { PREGO_F32 = 0, PREGO_BF16 = 1, PREGO_F16 = 2 };
 /* forward() flags */
 enum {
   PREGO_FWD_SOFTMAX = 1,   /* eval branch of MROAD.forward: out = softmax(logits) (rnn.py:66-70); else raw logits */
-  PREGO_FWD_KEEP = 2       /* keep activations for backward() in the training workspace */
+  PREGO_FWD_KEEP = 2,      /* keep activations for backward() in the training workspace */
+  PREGO_FWD_IN16 = 4       /* rgb[i] / flow[i] hold the handle's 16-bit operand type (bf16 or IEEE fp16 bits) instead of fp32: a feeder that
+                            * keeps 16-bit features in pinned host memory ships half the bytes per frame; bf16 / fp16 handles, inference only */
 };
 
 typedef void* prego_stream_t;

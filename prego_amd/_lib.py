@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PREGO_AMD_LIB") or os.path.join(_HERE, "lib", "libprego_amd.so")   # override: A/B builds
 
 PREGO_F32, PREGO_BF16, PREGO_F16 = 0, 1, 2
-FWD_SOFTMAX, FWD_KEEP = 1, 2
+FWD_SOFTMAX, FWD_KEEP, FWD_IN16 = 1, 2, 4
 E_TIMEOUT = -4
 
 # every symbol include/prego_amd.h declares (tests check the .so exports all of them)

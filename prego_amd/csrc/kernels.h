@@ -98,7 +98,8 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
                       int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0,
                       void* rowmap = nullptr /* int2 [nrows]: (clip, frame) of every packed row, for the head kernel */,
-                      bool f16 = false /* with bf16 = true: the 16-bit operand type is IEEE fp16 */);
+                      bool f16 = false /* with bf16 = true: the 16-bit operand type is IEEE fp16 */,
+                      bool in16 = false /* the feature arrays hold the 16-bit operand type already (PREGO_FWD_IN16) */);
 void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
                     bool in_bf16 = false, bool f16 = false);

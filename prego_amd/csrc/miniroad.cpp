@@ -481,6 +481,9 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   hipStream_t s = (hipStream_t)stream;
   if (h->f16 && (flags & PREGO_FWD_KEEP))
     return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) on an fp16-operand handle: training runs on bf16 / fp32 handles");
+  const bool in16 = (flags & PREGO_FWD_IN16) != 0;
+  if (in16 && !h->bf16) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 on an fp32-operand handle (16-bit features go with bf16 / fp16 handles)");
+  if (in16 && (flags & PREGO_FWD_KEEP)) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 with PREGO_FWD_KEEP: training takes fp32 features");
   const bool want_single = h0 != nullptr || h_last != nullptr || (flags & PREGO_FWD_KEEP) != 0;
   int rc = build_plan(h, n_clips, lens, want_single);
   if (rc) return rc;
@@ -570,9 +573,9 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
     EventPair* evp = ev_begin(h, 2, st);
     launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
-                     st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8, h->f16);
+                     st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8, h->f16, in16);
     ev_end(evp, st);
-    if (h->timing) h->pack_bytes += (double)rows_ * (kx * 4.0 + rb.x);
+    if (h->timing) h->pack_bytes += (double)rows_ * (kx * (in16 ? 2.0 : 4.0) + rb.x);
   };
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)

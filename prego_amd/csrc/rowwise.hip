@@ -9,7 +9,9 @@
 
 // One 256-thread block per packed row.  D_rgb, D_flow multiples of 8.
 // OutT = bf16_t (MFMA operand) or float (fp32 parity mode).
-template <typename OutT>
+// IN16: the per-clip feature arrays already hold the operand type (PREGO_FWD_IN16: a feeder that keeps 16-bit features in pinned
+// host memory ships half the bytes over PCIe; the rounding fp32 -> bf16 / fp16 then happened on the host, same RNE): plain copy.
+template <typename OutT, bool IN16 = false>
 __global__ __launch_bounds__(256) void pack_rows_kernel(
     const float* const* __restrict__ rgb_ptrs, const float* const* __restrict__ flow_ptrs, SlotPlan plan,
     int row0, int nrows, int d_rgb, int d_flow, OutT* __restrict__ X, int2* __restrict__ rowmap /*nullable: [nrows] (clip, frame)*/) {
@@ -24,6 +26,17 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
     const float* rgb = rgb_ptrs ? rgb_ptrs[clip] : nullptr;
     const float* flow = flow_ptrs ? flow_ptrs[clip] : nullptr;   // nullptr = all-zero flow half
     OutT* dst = X + (size_t)r * din;
+    if constexpr (IN16) {
+      const bf16_t* rgb16 = (const bf16_t*)rgb;
+      const bf16_t* flow16 = (const bf16_t*)flow;
+      for (int c = threadIdx.x * 8; c < din; c += 256 * 8) {
+        const bf16_t* src = (c < d_rgb) ? (rgb16 ? rgb16 + (size_t)t * d_rgb + c : nullptr)
+                                        : (flow16 ? flow16 + (size_t)t * d_flow + (c - d_rgb) : nullptr);
+        const u32x4 v = src ? __builtin_nontemporal_load((const u32x4*)src) : (u32x4){0u, 0u, 0u, 0u};
+        *(u32x4*)(dst + c) = v;
+      }
+      continue;
+    }
     for (int c = threadIdx.x * 8; c < din; c += 256 * 8) {
       float4 a, b;
       const float* src = (c < d_rgb) ? (rgb ? rgb + (size_t)t * d_rgb + c : nullptr)
@@ -145,11 +158,13 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
 // grid_limit > 0: at most that many workgroups (each walks rows at a stride): a THROTTLED stream for the copy that runs beside
 // the latency-bound recurrence (fewer loads in flight per CU = less queueing in front of the recurrence's gather)
 void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan,
-                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap, bool f16) {
+                      int row0, int nrows, int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap, bool f16, bool in16) {
   if (nrows <= 0) return;
   int grid = nrows < 65536 ? nrows : 65536;
   if (grid_limit > 0 && grid > grid_limit) grid = grid_limit;
-  if (bf16 && f16)
+  if (bf16 && in16)        // 16-bit features in the operand type already: the same copy kernel for bf16 and fp16
+    pack_rows_kernel<bf16_t, true><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X, (int2*)rowmap);
+  else if (bf16 && f16)
     pack_rows_kernel<f16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (f16_t*)X, (int2*)rowmap);
   else if (bf16)
     pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X, (int2*)rowmap);

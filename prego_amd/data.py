@@ -9,7 +9,12 @@ Differences on purpose: no `ipdb` breakpoints (dataset.py:108,112), a missing vi
 mutating the list being iterated (dataset.py:87-94 skips the element after each failure), pads are float32
 (the reference's np.zeros pads are float64 and get re-cast per item), and when flow_type is
 'flow_anet_resnet50' the flow half - which the reference overwrites with zeros (dataset.py:63-69) - is a
-stride-0 zero tensor instead of a materialised [T,2048] array."""
+stride-0 zero tensor instead of a materialised [T,2048] array.
+
+cfg['feature_dtype'] (not a reference key; default 'fp32'): 'fp16' / 'bf16' keep the TEST-mode features in that 16-bit type
+in host memory - converted once at load, round to nearest even, the conversion the pack kernel would do on the device - so the
+eval loop ships half the bytes per frame over PCIe to a model whose operand type it is (PREGO_FWD_IN16).  Training items stay
+fp32 (the training kernels take fp32 features)."""
 from __future__ import annotations
 
 import json
@@ -39,6 +44,10 @@ class StepRecognitionDataset(data.Dataset):
         self.rgb_type = cfg["rgb_type"]
         self.flow_type = cfg["flow_type"]
         self.zero_flow = cfg["flow_type"] == "flow_anet_resnet50"      # dataset.py:63-69
+        fd = cfg.get("feature_dtype", "fp32")
+        if fd not in ("fp32", "fp16", "bf16"):
+            raise ValueError(f"feature_dtype {fd!r}: expected fp32, fp16 or bf16")
+        self.feature_dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[fd if not self.training else "fp32"]
         vids = json.load(open(cfg["video_list_path"]))[cfg["data_name"]][mode + "_session_set"]
         self.excluded = tuple(cfg.get("exclude_videos", REFERENCE_EXCLUDED_VIDEOS))
         self.vids, self.removed = [], 0
@@ -66,8 +75,11 @@ class StepRecognitionDataset(data.Dataset):
             if vid in self.excluded:       # dataset.py:100-107 (loaded, then dropped from the item list)
                 continue
             self.vids.append(vid)
+            if self.feature_dtype != torch.float32:          # once per video, at load: torch's CPU casts round to nearest even
+                rgb = torch.from_numpy(rgb).to(self.feature_dtype)
+                flow = None if flow is None else torch.from_numpy(flow).to(self.feature_dtype)
             self.target_all[vid], self.rgb_inputs[vid], self.flow_inputs[vid] = target, rgb, flow
-        self._zero_row = torch.zeros(1, d_flow)
+        self._zero_row = torch.zeros(1, d_flow, dtype=self.feature_dtype)
         self._init_features()
 
     def _init_features(self):
@@ -84,9 +96,10 @@ class StepRecognitionDataset(data.Dataset):
 
     def __getitem__(self, index):
         vid, start, end = self.inputs[index]
-        rgb = torch.from_numpy(self.rgb_inputs[vid][start:end])
+        as_t = (lambda a: a) if self.feature_dtype != torch.float32 else torch.from_numpy
+        rgb = as_t(self.rgb_inputs[vid][start:end])
         flow = self.flow_inputs[vid]
-        flow = self._zero_row.expand(end - start, -1) if flow is None else torch.from_numpy(flow[start:end])
+        flow = self._zero_row.expand(end - start, -1) if flow is None else as_t(flow[start:end])
         target = torch.from_numpy(self.target_all[vid][start:end])
         return rgb, flow, target, vid, start, end
 

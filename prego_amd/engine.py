@@ -122,19 +122,26 @@ class MiniRoadEngine:
         d_rgb, d_flow, emb, hid, ncls = self.dims
         n = len(rgb) if rgb is not None else len(flow)
         lens = []
+        # features: fp32, or - for a bf16 / fp16 engine - tensors that already hold its operand type (PREGO_FWD_IN16: a feeder that
+        # keeps 16-bit features in pinned memory ships half the bytes; every clip of the call in the same dtype)
+        first = (rgb if rgb is not None else flow)[0]
+        dt = first.dtype
+        op_dt = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(self.compute_dtype)
+        if dt != torch.float32 and dt != op_dt:
+            raise PregoError(f"features are {dt}: a {self.compute_dtype} engine takes fp32" + (f" or {op_dt}" if op_dt else "") + " tensors")
         for i, r in enumerate(rgb if rgb is not None else flow):
             want = d_rgb if rgb is not None else d_flow
-            if r.dtype != torch.float32 or not r.is_cuda or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != want:
-                raise PregoError(f"{'rgb' if rgb is not None else 'flow'}[{i}] must be a contiguous fp32 cuda tensor [T, {want}], got {tuple(r.shape)} {r.dtype}")
+            if r.dtype != dt or not r.is_cuda or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != want:
+                raise PregoError(f"{'rgb' if rgb is not None else 'flow'}[{i}] must be a contiguous {dt} cuda tensor [T, {want}], got {tuple(r.shape)} {r.dtype}")
             lens.append(r.shape[0])
         if flow is not None:
             for i, f in enumerate(flow):
                 if f is None:
                     continue
-                if f.dtype != torch.float32 or not f.is_cuda or not f.is_contiguous() or tuple(f.shape) != (lens[i], d_flow):
-                    raise PregoError(f"flow[{i}] must be a contiguous fp32 cuda tensor [{lens[i]}, {d_flow}]")
+                if f.dtype != dt or not f.is_cuda or not f.is_contiguous() or tuple(f.shape) != (lens[i], d_flow):
+                    raise PregoError(f"flow[{i}] must be a contiguous {dt} cuda tensor [{lens[i]}, {d_flow}]")
         lens_arr = (C.c_int32 * n)(*lens)
-        flags = _lib.FWD_SOFTMAX if softmax else 0
+        flags = (_lib.FWD_SOFTMAX if softmax else 0) | (_lib.FWD_IN16 if dt != torch.float32 else 0)
         ws = self._workspace(n, lens_arr, flags)
         rgb_p = None if rgb is None else ptr_array([r.data_ptr() for r in rgb])
         flow_p = None if flow is None else ptr_array([None if f is None else f.data_ptr() for f in flow])

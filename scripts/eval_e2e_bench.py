@@ -23,7 +23,7 @@ g = torch.Generator().manual_seed(5)
 items = []
 for i, T in enumerate(lens):
     tgt = torch.zeros(T, 86); tgt[torch.arange(T), (torch.arange(T) // 97 + i) % 86] = 1
-    items.append((torch.randn((1, T, 2048), generator=g).clamp_(min=0).pin_memory(), torch.zeros(1, T, 2048), tgt[None], (f"v{i}",),
+    items.append((torch.randn((1, T, 2048), generator=g).clamp_(min=0).pin_memory(), torch.zeros(1, 1, 2048).expand(1, T, 2048), tgt[None].pin_memory(), (f"v{i}",),
                   torch.tensor([0]), torch.tensor([T])))
 frames = sum(lens)
 ev = build_eval(cfg)

@@ -189,6 +189,34 @@ def test_g2_long_T_31114_fp16_argmax_above_1e3_margin():
     print(f"g2 T=31114 fp16: argmax mismatches {int(mism.sum())} of {T}, largest violated margin {float(g['margin'][mism].max()) if mism.any() else 0.0:.2e}")
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_16_bit_features_in_are_bit_identical_to_fp32_features(dtype):
+    """PREGO_FWD_IN16: features that already hold the engine's operand type (a feeder with cfg['feature_dtype']) give bit-identical
+    results to the fp32 features they were rounded from (the pack kernel's own conversion is the same round-to-nearest-even);
+    an fp32 engine and a mismatching 16-bit type are rejected"""
+    from prego_amd._lib import PregoError
+    cfg = epic_tent_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    m = _model(cfg, sd, dtype)
+    tdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    lens = [130, 17, 301]
+    rgb = [torch.from_numpy(W.tsn_features((T, 2048), 13, f"in16.r{i}")).cuda() for i, T in enumerate(lens)]
+    flow = [torch.from_numpy(W.tsn_features((T, 2048), 13, f"in16.f{i}")).cuda() for i, T in enumerate(lens)]
+    eng = m.engine()
+    for fl32, fl16 in ((None, None), (flow, [f.to(tdt) for f in flow])):
+        o32, a32, _ = eng.forward_ragged(rgb, fl32, want_argmax=True)
+        o16, a16, _ = eng.forward_ragged([r.to(tdt) for r in rgb], fl16, want_argmax=True)
+        eng.check()
+        for x, y, p, q in zip(o32, o16, a32, a16):
+            assert torch.equal(x, y) and torch.equal(p, q)
+    other = torch.bfloat16 if dtype == "fp16" else torch.float16
+    with pytest.raises(PregoError):
+        eng.forward_ragged([r.to(other) for r in rgb], None)
+    m32 = _model(cfg, sd, "fp32")
+    with pytest.raises(PregoError):
+        m32.engine().forward_ragged([r.half() for r in rgb], None)
+
+
 def test_default_compute_dtype_is_fp16_and_training_uses_bf16_engine():
     from prego_amd.registry import build_model
     import prego_amd.model  # noqa: F401

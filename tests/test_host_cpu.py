@@ -242,3 +242,24 @@ def test_feeder_drops_the_video_the_reference_drops(tmp_path):
     assert ds.vids == ["v0", "v1"] and [w[0] for w in ds.inputs] == ["v0", "v1"]
     ds = StepRecognitionDataset(assembly101_cfg(root_path=str(tmp_path), video_list_path=vl, exclude_videos=()), "test")
     assert ds.vids == vids
+
+
+def test_feeder_feature_dtype_holds_16_bit_test_features(tmp_path):
+    """cfg['feature_dtype'] = 'fp16' / 'bf16': test-mode items carry that dtype (converted once at load, round to nearest even:
+    what the pack kernel would do on the device), training items stay fp32"""
+    from prego_amd.config import epic_tent_cfg
+    from prego_amd.data import StepRecognitionDataset
+    vl = _g9_tree(str(tmp_path))
+    ref = StepRecognitionDataset(epic_tent_cfg(root_path=str(tmp_path), video_list_path=vl), "test")
+    for name, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        cfg = epic_tent_cfg(root_path=str(tmp_path), video_list_path=vl, feature_dtype=name)
+        ds = StepRecognitionDataset(cfg, "test")
+        rgb, flow, tgt, vid, s, e = ds[0]
+        r0 = ref[0][0]
+        assert rgb.dtype == dt and flow.dtype == dt and tgt.dtype == torch.float32 and rgb.shape == r0.shape
+        assert torch.equal(rgb, r0.to(dt)) and float(flow.abs().sum()) == 0.0
+        np.random.seed(1)
+        tr = StepRecognitionDataset(cfg, "train")
+        assert tr[0][0].dtype == torch.float32
+    with pytest.raises(ValueError):
+        StepRecognitionDataset(epic_tent_cfg(root_path=str(tmp_path), video_list_path=vl, feature_dtype="int8"), "test")
