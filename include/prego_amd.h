@@ -208,6 +208,11 @@ int prego_vit_num_tensors(const prego_vit* h);
  *   pre_head_ln.{weight,bias}, mlp_head.{weight [n_classes, emb], bias} */
 int prego_vit_set_weights(prego_vit* h, const float* const* tensors, int n_tensors, prego_stream_t stream);
 size_t prego_vit_workspace_bytes(const prego_vit* h, int batch);
+/* MFMA operand type of the handle: PREGO_BF16 (default) or PREGO_F16 (IEEE fp16 operands and 16-bit activations: the same rate
+ * and bytes, 8x less operand rounding - logits within 1e-3 of the fp32 reference where bf16 gives 2.5e-3; inference entry points
+ * only: forward, forward_frames).  Changing the type invalidates the ingested weights (call set_weights again). */
+int prego_vit_set_compute_dtype(prego_vit* h, int compute_dtype);
+
 /* ViTEnc.forward (ViT.py:117-143): rgb/flow device fp32 [batch, window, d_rgb/d_flow] (flow NULL = zeros);
  * out_logits device fp32 [batch, n_classes] (the reference returns it as [batch, 1, n_classes], raw logits in both
  * modes).  flags bit 0: causal self-attention (extension; the reference module has no mask, Attention.py:21-41).
@@ -267,6 +272,8 @@ int prego_attention_layer_forward(int batch, int len, int d_model, int heads, in
 typedef struct prego_attn_layer prego_attn_layer;
 int prego_attention_layer_create(prego_attn_layer** out, int d_model, int heads);
 void prego_attention_layer_destroy(prego_attn_layer* h);
+/* PREGO_BF16 (default) or PREGO_F16 operands for the handle's forward; changing the type invalidates the ingested weights. */
+int prego_attention_layer_set_compute_dtype(prego_attn_layer* h, int compute_dtype);
 int prego_attention_layer_set_weights(prego_attn_layer* h, const float* wq, const float* bq, const float* wk, const float* bk,
                                       const float* wv, const float* bv, const float* wo, const float* bo, prego_stream_t stream);
 size_t prego_attention_layer_handle_workspace_bytes(const prego_attn_layer* h, int batch, int len);

@@ -31,6 +31,7 @@ SYMBOLS = [
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events",
+    "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
 ]
 
 
@@ -100,6 +101,8 @@ def load() -> C.CDLL:
     lib.prego_vit_frames_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_vit_frames_workspace_bytes.restype = sz
     lib.prego_vit_forward_frames.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32, vp, sz, vp]
+    lib.prego_vit_set_compute_dtype.argtypes = [vp, i32]
+    lib.prego_attention_layer_set_compute_dtype.argtypes = [vp, i32]
     lib.prego_vit_set_dropout.argtypes = [vp, C.c_float, C.c_float, C.c_uint64]
     lib.prego_vit_train_workspace_bytes.argtypes = [vp, i32]
     lib.prego_vit_train_workspace_bytes.restype = sz

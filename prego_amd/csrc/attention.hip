@@ -50,7 +50,8 @@ __device__ __forceinline__ float rows_sum(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <int DH, int QG, int NW>
+// OT: 16-bit operand type tag (bf16_t / f16_t, common.h): Q, K, V, the probabilities P and the output share it
+template <int DH, int QG, int NW, typename OT = bf16_t>
 __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void flash_attention_v2_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, bf16_t* __restrict__ out,
     int Nq, int N, int heads, int causal, float* __restrict__ lse, unsigned drop_thresh, float drop_scale,
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
       for (int j = 0; j < GK; ++j) {
         const int ks = (gi * GK + j) >> 2, t = (gi * GK + j) & 3;
 #pragma unroll
-        for (int u = 0; u < QG; ++u) st[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[gi & 1][j], qf[u][ks], st[u][t], 0, 0, 0);
+        for (int u = 0; u < QG; ++u) st[u][t] = op16<OT>::mfma(kf[gi & 1][j], qf[u][ks], st[u][t]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (gi + 2 < NGK) {
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
 #pragma unroll
           for (int e = 0; e < 4; ++e) p[e] = dropout_keep_(drop_seed, rowi + e, drop_thresh) ? p[e] : 0.f;
         }
-        pw[t >> 1][2 * (t & 1)] = pack_bf16x2(p[0], p[1]);
-        pw[t >> 1][2 * (t & 1) + 1] = pack_bf16x2(p[2], p[3]);
+        pw[t >> 1][2 * (t & 1)] = op16<OT>::pack2(p[0], p[1]);
+        pw[t >> 1][2 * (t & 1) + 1] = op16<OT>::pack2(p[2], p[3]);
       }
       rs = rows_sum(rs);
       l_run[u] = l_run[u] * alpha + rs;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
       for (int j = 0; j < GV; ++j) {
         const int s2 = (gi * GV + j) / DT, dt = (gi * GV + j) % DT;
 #pragma unroll
-        for (int u = 0; u < QG; ++u) o[u][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[gi & 1][j], pf[u][s2], o[u][dt], 0, 0, 0);
+        for (int u = 0; u < QG; ++u) o[u][dt] = op16<OT>::mfma(vf[gi & 1][j], pf[u][s2], o[u][dt]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if (gi + 2 < NGV) {
@@ -279,8 +280,8 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
     bf16_t* orow = out + ((size_t)b * Nq + (live ? own[u] : 0)) * heads * DH + (size_t)hd * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; dt += 2) {
-      const unsigned a0 = pack_bf16x2(o[u][dt][0] * inv, o[u][dt][1] * inv), a1 = pack_bf16x2(o[u][dt][2] * inv, o[u][dt][3] * inv);
-      const unsigned b0 = pack_bf16x2(o[u][dt + 1][0] * inv, o[u][dt + 1][1] * inv), b1 = pack_bf16x2(o[u][dt + 1][2] * inv, o[u][dt + 1][3] * inv);
+      const unsigned a0 = op16<OT>::pack2_sat(o[u][dt][0] * inv, o[u][dt][1] * inv), a1 = op16<OT>::pack2_sat(o[u][dt][2] * inv, o[u][dt][3] * inv);
+      const unsigned b0 = op16<OT>::pack2_sat(o[u][dt + 1][0] * inv, o[u][dt + 1][1] * inv), b1 = op16<OT>::pack2_sat(o[u][dt + 1][2] * inv, o[u][dt + 1][3] * inv);
       // odd 16-lane rows of (a0, a1) <-> even rows of (b0, b1): g even keeps a (its own d's of dt) and receives g + 1's;
       // g odd ends with both halves of dt + 1
       const auto x = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, 1) __attribute__((amdgpu_waves_per_eu(NW /
 // the last encoder layer of ViTEnc whose output is read at token 0 only, ViT.py:136)
 int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
                               int causal, hipStream_t s, float* lse, unsigned drop_thresh, float drop_scale,
-                              unsigned long long drop_seed) {
+                              unsigned long long drop_seed, bool f16) {
   if (!drop_thresh) drop_scale = 1.f;
   // long sequences: 8 waves x 16 queries (two waves per SIMD: one wave's softmax and LDS waits hide under the other's MFMAs);
   // 129-token windows: 4 waves x 16 queries = 3 x 64 query slots instead of 2 x 128
@@ -308,8 +309,11 @@ int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void*
   do {                                                                                                           \
     const size_t lds = (size_t)4 * AK * D * 2;                                                                   \
     static DeviceOnce once;                                                                                      \
-    once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_v2_kernel<D, G, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-    flash_attention_v2_kernel<D, G, W><<<grid, 64 * W, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, Nq, N, \
+    once.run([&] { (void)hipFuncSetAttribute((const void*)flash_attention_v2_kernel<D, G, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);   \
+                   (void)hipFuncSetAttribute((const void*)flash_attention_v2_kernel<D, G, W, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+    if (f16) flash_attention_v2_kernel<D, G, W, f16_t><<<grid, 64 * W, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, Nq, N, \
+                                                                 heads, causal, lse, drop_thresh, drop_scale, drop_seed);  \
+    else flash_attention_v2_kernel<D, G, W><<<grid, 64 * W, lds, s>>>((const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (bf16_t*)out, Nq, N, \
                                                                  heads, causal, lse, drop_thresh, drop_scale, drop_seed);  \
   } while (0)
 #define FA2D(D) do { if (nw == 8) FA2(D, 1, 8); else if (qg == 2) FA2(D, 2, 4); else FA2(D, 1, 4); } while (0)

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             if (epi.pre_f32) epi.pre_f32[(size_t)m * ldc + n] = v;   // training: keep the pre-activation for gelu'
             float gv = gelu_erf_(v);
             if (epi.drop_thresh) gv = dropout_keep_(epi.drop_seed, (size_t)m * ldc + n, epi.drop_thresh) ? gv * epi.drop_scale : 0.f;
-            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = f2bf(gv);
+            ((bf16_t*)epi.out_b)[(size_t)m * ldc + n] = op16<OT>::cvt_sat(gv);
           } else if constexpr (EPI == EPI_TOKENS) {                   // x[b, t] = v + pe[t], row m = b n_tok + t -> m + b
             const int b = m / epi.n_tok, t = m - b * epi.n_tok;
             ((float*)C)[(size_t)(m + b) * ldc + n] = v + epi.pe[(size_t)t * ldc + n];
@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(
             const int blk = n / epi.emb, r = n - blk * epi.emb, which = blk + epi.which0;
             const int hd = r / epi.dh, d = r - hd * epi.dh;
             const size_t bh = (size_t)b * epi.heads + hd;
-            if (which == 0) ((bf16_t*)epi.q)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v * epi.q_scale);
-            else if (which == 1) ((bf16_t*)epi.k)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
+            if (which == 0) ((bf16_t*)epi.q)[(bh * epi.n_tok + t) * epi.dh + d] = op16<OT>::cvt_sat(v * epi.q_scale);
+            else if (which == 1) ((bf16_t*)epi.k)[(bh * epi.n_tok + t) * epi.dh + d] = op16<OT>::cvt_sat(v);
             else {
-              ((bf16_t*)epi.vn)[(bh * epi.n_tok + t) * epi.dh + d] = f2bf(v);
+              ((bf16_t*)epi.vn)[(bh * epi.n_tok + t) * epi.dh + d] = op16<OT>::cvt_sat(v);
             }
           }
         }
@@ -355,16 +355,22 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
     if (launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, cdst, ldc, M, N, K, epi, s) == 0) return;
   }
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
-  if (epi.f16) {                 // fp16 operands (MiniROAD inference projections): plain and 16-bit stores only
-    static DeviceOnce once16;
-    once16.run([] {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, EPI_STORE, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, EPI_STORE_BF16, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    });
-    if (epi.mode == EPI_STORE_BF16)
-      gemm_bf16_nt_kernel<float, EPI_STORE_BF16, f16_t><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi);
-    else
-      gemm_bf16_nt_kernel<float, EPI_STORE, f16_t><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi);
+  if (epi.f16) {                 // IEEE fp16 operands / 16-bit outputs
+#define GL16(E)                                                                                                  \
+  do {                                                                                                           \
+    static DeviceOnce once;                                                                                      \
+    once.run([] { (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<float, E, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); }); \
+    gemm_bf16_nt_kernel<float, E, f16_t><<<ntm * ntn, 256, 65536, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc, epi); \
+  } while (0)
+    switch (epi.mode) {
+      case EPI_STORE: GL16(EPI_STORE); break;
+      case EPI_RESIDUAL: GL16(EPI_RESIDUAL); break;
+      case EPI_GELU_BF16: GL16(EPI_GELU_BF16); break;
+      case EPI_STORE_BF16: GL16(EPI_STORE_BF16); break;
+      case EPI_TOKENS: GL16(EPI_TOKENS); break;
+      default: GL16(EPI_QKV); break;
+    }
+#undef GL16
     return;
   }
 #define GL(E)                                                                                                   \
@@ -384,7 +390,13 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 #undef GL
 }
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
-                         int N, int K, hipStream_t s) {
+                         int N, int K, hipStream_t s, bool f16) {
+  if (f16) {                             // fp16 operands: ping-pong kernel for whole-chip shapes, the 128 x 128 kernel below
+    GemmEpi e16{};
+    e16.mode = EPI_STORE; e16.f16 = 1;
+    launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, e16, s);
+    return;
+  }
   static const bool no_big = getenv("PREGO_GEMM_NO_BIG") != nullptr;
   if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles: ping-pong 8-phase schedule with 16-byte stores (gemm_pp.hip)
     static const bool no_pp = getenv("PREGO_GEMM_NO_PINGPONG") != nullptr;      // A/B knob: the previous production kernel

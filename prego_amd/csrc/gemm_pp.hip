@@ -284,13 +284,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
             if (which < 2) {
               const float sc = which == 0 ? epi.q_scale : 1.f;
               uint4 pk;
-              pk.x = pack_bf16x2(o[0] * sc, o[1] * sc); pk.y = pack_bf16x2(o[2] * sc, o[3] * sc);
-              pk.z = pack_bf16x2(o[4] * sc, o[5] * sc); pk.w = pack_bf16x2(o[6] * sc, o[7] * sc);
+              pk.x = op16<OT>::pack2_sat(o[0] * sc, o[1] * sc); pk.y = op16<OT>::pack2_sat(o[2] * sc, o[3] * sc);
+              pk.z = op16<OT>::pack2_sat(o[4] * sc, o[5] * sc); pk.w = op16<OT>::pack2_sat(o[6] * sc, o[7] * sc);
               bf16_t* dst = which == 0 ? (bf16_t*)epi.q : (bf16_t*)epi.k;
               *(uint4*)(dst + (bh * epi.n_tok + t) * epi.dh + d) = pk;
             } else {
               uint4 pk;                                                  // V by rows [B,h,n_tok,dh]: one 16-byte store
-              pk.x = pack_bf16x2(o[0], o[1]); pk.y = pack_bf16x2(o[2], o[3]); pk.z = pack_bf16x2(o[4], o[5]); pk.w = pack_bf16x2(o[6], o[7]);
+              pk.x = op16<OT>::pack2_sat(o[0], o[1]); pk.y = op16<OT>::pack2_sat(o[2], o[3]); pk.z = op16<OT>::pack2_sat(o[4], o[5]); pk.w = op16<OT>::pack2_sat(o[6], o[7]);
               *(uint4*)((bf16_t*)epi.vn + (bh * epi.n_tok + t) * epi.dh + d) = pk;
             }
           } else {
@@ -337,6 +337,10 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_TOKENS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_RESIDUAL, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_GELU_BF16, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_QKV, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_TOKENS, f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
     int d = 0;
     (void)hipGetDevice(&d);
     if (d >= 0 && d < 64) (void)hipGetSymbolAddress((void**)&zero_bias[d], HIP_SYMBOL(g_pp_zero_bias));
@@ -345,10 +349,17 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
   if (!bias) return -1;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
 #define PPL(E) gemm_bf16_nt_pingpong_kernel<E><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi)
-  if (epi.f16) {                 // fp16 operands: the MiniROAD projections only (fp32 or fp16 C)
-    if (epi.mode == EPI_STORE) gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
-    else if (epi.mode == EPI_STORE_BF16) gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
-    else return -1;
+  if (epi.f16) {                 // IEEE fp16 operands / 16-bit outputs: same kernel, other MFMA opcode and conversions
+#define PPL16(E) gemm_bf16_nt_pingpong_kernel<E, f16_t><<<ntiles, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi)
+    switch (epi.mode) {
+      case EPI_STORE: PPL16(EPI_STORE); break;
+      case EPI_STORE_BF16: PPL16(EPI_STORE_BF16); break;
+      case EPI_RESIDUAL: PPL16(EPI_RESIDUAL); break;
+      case EPI_GELU_BF16: PPL16(EPI_GELU_BF16); break;
+      case EPI_TOKENS: PPL16(EPI_TOKENS); break;
+      default: PPL16(EPI_QKV); break;
+    }
+#undef PPL16
     return 0;
   }
   switch (epi.mode) {

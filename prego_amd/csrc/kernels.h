@@ -90,7 +90,7 @@ struct GemmEpi {
   // EPI_TOKENS (ViT.py:125-129 in the encoding GEMM's epilogue): GEMM row m = b n_tok + t goes to row m + b of C (one cls row per
   // window is left for the caller) with the learned positional row pe[t] added: x[b, t] = W_enc f + b_enc + pe[t]
   const float* pe;
-  int f16;                     // operands (and a 16-bit output) are IEEE fp16 instead of bf16 (EPI_STORE / EPI_STORE_BF16 only)
+  int f16;                     // operands (and every 16-bit output) are IEEE fp16 instead of bf16
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
@@ -114,7 +114,7 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
-                         int N, int K, hipStream_t s);
+                         int N, int K, hipStream_t s, bool f16 = false);
 void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
                         int N, int K, hipStream_t s);
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);
@@ -165,7 +165,7 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
 // attention forward (attention.hip): query on the lane, V row-major [B,h,N,dh], Nq queries against N keys
 int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void* out, int B, int Nq, int N, int heads, int dh,
                               int causal, hipStream_t s, float* lse = nullptr, unsigned drop_thresh = 0, float drop_scale = 1.f,
-                              unsigned long long drop_seed = 0);
+                              unsigned long long drop_seed = 0, bool f16 = false /* Q, K, V, P and the output are IEEE fp16 */);
 // attention backward (attention_bwd.hip): dqkv [B*N, 3*heads*dh] bf16; delta: scratch fp32 [B*heads*N]
 int launch_attention_bwd(const void* Qs, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                          float* delta, void* dqkv, int B, int N, int heads, int dh, int causal, float q_scale, hipStream_t s,
@@ -183,7 +183,7 @@ void launch_vit_head_bwd(const float* x, const float* dlogits, int B, int N, int
                          float* g_hb, hipStream_t s);
 void launch_vit_tokens_bwd(const float* dx, int B, int T, int E, float* denc, float* g_pe, float* g_cls, hipStream_t s,
                            unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
-void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s);
+void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s, bool f16 = false);
 void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
                        unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0);
 void launch_vit_cls_rows(const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s);
@@ -191,7 +191,7 @@ void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, cons
                      const float* hb, int C, float* out, hipStream_t s, int* argmax = nullptr);
 // sliding windows over one video: token rows of windows ending at frames t0 .. t0 + B - 1 from the per-frame encoding (vit.hip)
 void launch_vit_sliding_tokens(const float* enc, const float* enc_b, const float* cls, const float* pe, int t0, int B, int T, int E,
-                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s);
+                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s, bool f16 = false);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);
 
 // streaming step (stream_step.hip): skinny products for n <= 16 rows, one frame per stream

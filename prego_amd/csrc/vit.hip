@@ -5,6 +5,7 @@
 #include "common.h"
 #include "kernels.h"
 
+template <typename OT>
 __global__ void cat_convert_kernel(const float* __restrict__ rgb, const float* __restrict__ flow, int rows, int d_rgb,
                                    int d_flow, bf16_t* __restrict__ out) {
   const int din = d_rgb + d_flow;
@@ -12,7 +13,7 @@ __global__ void cat_convert_kernel(const float* __restrict__ rgb, const float* _
     for (int c = threadIdx.x * 4; c < din; c += blockDim.x * 4) {
       const float4 v = c < d_rgb ? *(const float4*)(rgb + (size_t)r * d_rgb + c)
                                  : (flow ? *(const float4*)(flow + (size_t)r * d_flow + (c - d_rgb)) : make_float4(0, 0, 0, 0));
-      uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+      uint2 o; o.x = op16<OT>::pack2_sat(v.x, v.y); o.y = op16<OT>::pack2_sat(v.z, v.w);
       *(uint2*)(out + (size_t)r * din + c) = o;
     }
 }
@@ -44,7 +45,7 @@ __global__ void vit_cls_rows_kernel(const float* __restrict__ cls, const float* 
 // feature row encodes to the bias alone), token T = cls + pe[T] (ViT.py:124-129).  One wave per token row.  Outputs, all
 // optional: x (fp32 residual stream [B][T+1][E]), xn (bf16 LayerNorm(ln_w, ln_b) of the row: the first block's pre-norm fused in,
 // so a one-layer model never materialises x), x0 (fp32 [B][E]: token 0 of every window, the only residual row its last block reads).
-template <int MAXV>
+template <int MAXV, typename OT>
 __global__ __launch_bounds__(256) void vit_sliding_tokens_kernel(const float* __restrict__ enc, const float* __restrict__ enc_b,
                                                                  const float* __restrict__ cls, const float* __restrict__ pe, int t0,
                                                                  int B, int T, int E, float* __restrict__ x,
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(256) void vit_sliding_tokens_kernel(const float* __
         const int c = (i * 64 + lane) * 4;
         const float4 g = *(const float4*)(ln_w + c), bb = *(const float4*)(ln_b + c);
         uint2 o;
-        o.x = pack_bf16x2((v[i][0] - mu) * rstd * g.x + bb.x, (v[i][1] - mu) * rstd * g.y + bb.y);
-        o.y = pack_bf16x2((v[i][2] - mu) * rstd * g.z + bb.z, (v[i][3] - mu) * rstd * g.w + bb.w);
+        o.x = op16<OT>::pack2_sat((v[i][0] - mu) * rstd * g.x + bb.x, (v[i][1] - mu) * rstd * g.y + bb.y);
+        o.y = op16<OT>::pack2_sat((v[i][2] - mu) * rstd * g.z + bb.z, (v[i][3] - mu) * rstd * g.w + bb.w);
         *(uint2*)(xn + (size_t)row * E + c) = o;
       }
   }
@@ -149,9 +150,10 @@ __global__ __launch_bounds__(256) void vit_head_kernel(const float* __restrict__
   }
 }
 
-void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s) {
+void launch_cat_convert(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, void* out_bf16, hipStream_t s, bool f16) {
   if (rows <= 0) return;
-  cat_convert_kernel<<<rows < 16384 ? rows : 16384, 256, 0, s>>>(rgb, flow, rows, d_rgb, d_flow, (bf16_t*)out_bf16);
+  if (f16) cat_convert_kernel<f16_t><<<rows < 16384 ? rows : 16384, 256, 0, s>>>(rgb, flow, rows, d_rgb, d_flow, (bf16_t*)out_bf16);
+  else cat_convert_kernel<bf16_t><<<rows < 16384 ? rows : 16384, 256, 0, s>>>(rgb, flow, rows, d_rgb, d_flow, (bf16_t*)out_bf16);
 }
 void launch_vit_tokens(const float* enc, const float* cls, const float* pe, int B, int T, int E, float* x, hipStream_t s,
                        unsigned drop_thresh, float drop_scale, unsigned long long drop_seed) {
@@ -165,9 +167,11 @@ void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, cons
   vit_head_kernel<<<B, 256, (E + 8 + C) * sizeof(float), s>>>(x, N, E, lnw, lnb, hw, hb, C, out, argmax);
 }
 void launch_vit_sliding_tokens(const float* enc, const float* enc_b, const float* cls, const float* pe, int t0, int B, int T, int E,
-                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s) {
+                               float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s, bool f16) {
   long long rows = (long long)B * (T + 1);
   int grid = (int)((rows + 3) / 4 < 32768 ? (rows + 3) / 4 : 32768);
-  if (E <= 2048) vit_sliding_tokens_kernel<8><<<grid, 256, 0, s>>>(enc, enc_b, cls, pe, t0, B, T, E, x, ln_w, ln_b, (bf16_t*)xn, x0);
-  else vit_sliding_tokens_kernel<16><<<grid, 256, 0, s>>>(enc, enc_b, cls, pe, t0, B, T, E, x, ln_w, ln_b, (bf16_t*)xn, x0);
+#define VST(MV, OT) vit_sliding_tokens_kernel<MV, OT><<<grid, 256, 0, s>>>(enc, enc_b, cls, pe, t0, B, T, E, x, ln_w, ln_b, (bf16_t*)xn, x0)
+  if (E <= 2048) { if (f16) VST(8, f16_t); else VST(8, bf16_t); }
+  else { if (f16) VST(16, f16_t); else VST(16, bf16_t); }
+#undef VST
 }

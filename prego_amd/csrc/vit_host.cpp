@@ -1,5 +1,5 @@
 // C ABI of the "Transformer" (ViTEnc) path and of the causal AttentionLayer op (include/prego_amd.h).
-// bf16 MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax.
+// bf16 (or, inference only, IEEE fp16) MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax.
 #include "../../include/prego_amd.h"
 #include "kernels.h"
 
@@ -31,6 +31,7 @@ struct prego_vit {
   float *lnf_w = nullptr, *lnf_b = nullptr, *head_w = nullptr, *head_b = nullptr;
   std::vector<void*> allocs;
   bool have_weights = false;
+  bool f16 = false;                // IEEE fp16 operands / 16-bit activations instead of bf16 (prego_vit_set_compute_dtype; inference only)
   // training-mode dropout (cfg['dropout']; ViT.py:130 pe_dropout, Transformer.py:31 PreNormDrop, Transformer.py:41,46 FeedForward)
   float drop_p = 0.f;
   float attn_drop_p = 0.f;         // cfg['attn_dropout_rate']: attention probabilities (Attention.py:17,36) and proj_drop (Attention.py:19,40)
@@ -101,6 +102,15 @@ extern "C" void prego_vit_destroy(prego_vit* h) {
   delete h;
 }
 
+extern "C" int prego_vit_set_compute_dtype(prego_vit* h, int compute_dtype) {
+  if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
+  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16)
+    return prego_fail_(PREGO_EINVAL, "ViTEnc compute_dtype %d: PREGO_BF16 or PREGO_F16", compute_dtype);
+  if ((compute_dtype == PREGO_F16) != h->f16) h->have_weights = false;      // the 16-bit weight copies are of the other type: re-ingest
+  h->f16 = compute_dtype == PREGO_F16;
+  return PREGO_OK;
+}
+
 extern "C" int prego_vit_num_tensors(const prego_vit* h) { return h ? 4 + 11 * h->layers + 4 : 0; }
 
 extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_tensors, prego_stream_t stream) {
@@ -111,16 +121,16 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
   const int E = h->emb, din = h->d_rgb + h->d_flow, mlp = h->mlp;
   int k = 0;
   auto f32 = [&](float* dst, size_t n) { return hipMemcpyAsync(dst, t[k++], n * 4, hipMemcpyDeviceToDevice, s); };
-  launch_pad_convert(true, t[k++], E, din, din, h->enc_w, E, din, s);
+  launch_pad_convert(true, t[k++], E, din, din, h->enc_w, E, din, s, h->f16);
   HIPCHK(f32(h->enc_b, E)); HIPCHK(f32(h->cls, E)); HIPCHK(f32(h->pe, (size_t)(h->window + 1) * E));
   for (auto& l : h->L) {
     HIPCHK(f32(l.ln1_w, E)); HIPCHK(f32(l.ln1_b, E));
-    launch_pad_convert(true, t[k++], 3 * E, E, E, l.qkv_w, 3 * E, E, s);
-    launch_pad_convert(true, t[k++], E, E, E, l.proj_w, E, E, s);
+    launch_pad_convert(true, t[k++], 3 * E, E, E, l.qkv_w, 3 * E, E, s, h->f16);
+    launch_pad_convert(true, t[k++], E, E, E, l.proj_w, E, E, s, h->f16);
     HIPCHK(f32(l.proj_b, E)); HIPCHK(f32(l.ln2_w, E)); HIPCHK(f32(l.ln2_b, E));
-    launch_pad_convert(true, t[k++], mlp, E, E, l.ff1_w, mlp, E, s);
+    launch_pad_convert(true, t[k++], mlp, E, E, l.ff1_w, mlp, E, s, h->f16);
     HIPCHK(f32(l.ff1_b, mlp));
-    launch_pad_convert(true, t[k++], E, mlp, mlp, l.ff2_w, E, mlp, s);
+    launch_pad_convert(true, t[k++], E, mlp, mlp, l.ff2_w, E, mlp, s, h->f16);
     HIPCHK(f32(l.ff2_b, E));
   }
   HIPCHK(f32(h->lnf_w, E)); HIPCHK(f32(h->lnf_b, E)); HIPCHK(f32(h->head_w, (size_t)h->ncls * E)); HIPCHK(f32(h->head_b, h->ncls));
@@ -133,6 +143,7 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
 extern "C" int prego_vit_adamw_step(prego_vit* h, float* const* params, const float* const* grads, float* const* exp_avg,
                                     float* const* exp_avg_sq, int n_tensors, int64_t step, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, prego_stream_t stream) {
+  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_adamw_step on an fp16-operand handle: training runs on bf16 handles");
   if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return prego_fail_(PREGO_EINVAL, "vit adamw: NULL argument");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "vit adamw step before set_weights");
   if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d tensors, got %d", prego_vit_num_tensors(h), n_tensors);
@@ -179,16 +190,16 @@ extern "C" size_t prego_vit_workspace_bytes(const prego_vit* h, int batch) { ret
 static int encoder_block(const prego_vit* h, const VitLayer& l, float* x, char* ws, const VitWs& w, int B, int N, int causal,
                          hipStream_t s) {
   const int E = h->emb, M = B * N, dh = E / h->heads;
-  launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
-  GemmEpi e{};
+  launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0, false, h->f16);
+  GemmEpi e{}; e.f16 = h->f16 ? 1 : 0;
   e.mode = EPI_QKV; e.q = ws + w.q; e.k = ws + w.k; e.vn = ws + w.vn; e.n_tok = N; e.heads = h->heads;
   e.dh = dh; e.emb = E; e.q_scale = 1.0f / sqrtf((float)dh);                      // Attention.py:14 (dh^-0.5)
   launch_gemm_bf16_nt_epi(ws + w.xn, E, l.qkv_w, E, nullptr, nullptr, 0, M, 3 * E, E, e, s);
-  if (launch_flash_attention_v2(ws + w.q, ws + w.k, ws + w.vn, ws + w.ao, B, N, N, h->heads, dh, causal, s)) return -1;
-  GemmEpi r{}; r.mode = EPI_RESIDUAL;
+  if (launch_flash_attention_v2(ws + w.q, ws + w.k, ws + w.vn, ws + w.ao, B, N, N, h->heads, dh, causal, s, nullptr, 0, 1.f, 0, h->f16)) return -1;
+  GemmEpi r{}; r.f16 = h->f16 ? 1 : 0; r.mode = EPI_RESIDUAL;
   launch_gemm_bf16_nt_epi(ws + w.ao, E, l.proj_w, E, l.proj_b, x, E, M, E, E, r, s);          // x += proj(attn)
-  launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
-  GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f;
+  launch_ln_relu(true, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0, false, h->f16);
+  GemmEpi g{}; g.f16 = h->f16 ? 1 : 0; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f;
   launch_gemm_bf16_nt_epi(ws + w.xn, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, M, h->mlp, E, g, s);   // gelu(W1 x + b1)
   launch_gemm_bf16_nt_epi(ws + w.f, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x, E, M, E, h->mlp, r, s);     // x += W2 . + b2
   return 0;
@@ -203,21 +214,21 @@ static int encoder_block(const prego_vit* h, const VitLayer& l, float* x, char* 
 static int encoder_block_token0(const prego_vit* h, const VitLayer& l, const float* x, char* ws, const VitWs& w, int B, int N,
                                 int causal, hipStream_t s, bool have_xn = false) {
   const int E = h->emb, M = B * N, dh = E / h->heads;
-  if (!have_xn) launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0);
-  GemmEpi e{};
+  if (!have_xn) launch_ln_relu(true, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, ws + w.xn, nullptr, 0.f, 0, 0, s, 0, false, h->f16);
+  GemmEpi e{}; e.f16 = h->f16 ? 1 : 0;
   e.mode = EPI_QKV; e.q = ws + w.q0; e.k = ws + w.k; e.vn = ws + w.vn; e.n_tok = N; e.heads = h->heads; e.dh = dh; e.emb = E;
   e.q_scale = 1.0f / sqrtf((float)dh);
   e.which0 = 1;                                                                                // k | v for every token
   launch_gemm_bf16_nt_epi(ws + w.xn, E, (const char*)l.qkv_w + (size_t)E * E * 2, E, nullptr, nullptr, 0, M, 2 * E, E, e, s);
   e.which0 = 0; e.n_tok = 1;                                                                   // q for token 0: rows b * N of xn
   launch_gemm_bf16_nt_epi(ws + w.xn, N * E, l.qkv_w, E, nullptr, nullptr, 0, B, E, E, e, s);
-  if (launch_flash_attention_v2(ws + w.q0, ws + w.k, ws + w.vn, ws + w.ao0, B, 1, N, h->heads, dh, causal, s)) return -1;
+  if (launch_flash_attention_v2(ws + w.q0, ws + w.k, ws + w.vn, ws + w.ao0, B, 1, N, h->heads, dh, causal, s, nullptr, 0, 1.f, 0, h->f16)) return -1;
   float* x0 = (float*)(ws + w.x0);
   if (!have_xn && hipMemcpy2DAsync(x0, (size_t)E * 4, x, (size_t)N * E * 4, (size_t)E * 4, B, hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
-  GemmEpi r{}; r.mode = EPI_RESIDUAL;
+  GemmEpi r{}; r.f16 = h->f16 ? 1 : 0; r.mode = EPI_RESIDUAL;
   launch_gemm_bf16_nt_epi(ws + w.ao0, E, l.proj_w, E, l.proj_b, x0, E, B, E, E, r, s);
-  launch_ln_relu(true, x0, l.ln2_w, l.ln2_b, B, E, 1e-5f, ws + w.xn0, nullptr, 0.f, 0, 0, s, 0);
-  GemmEpi g{}; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f0;
+  launch_ln_relu(true, x0, l.ln2_w, l.ln2_b, B, E, 1e-5f, ws + w.xn0, nullptr, 0.f, 0, 0, s, 0, false, h->f16);
+  GemmEpi g{}; g.f16 = h->f16 ? 1 : 0; g.mode = EPI_GELU_BF16; g.out_b = ws + w.f0;
   launch_gemm_bf16_nt_epi(ws + w.xn0, E, l.ff1_w, E, l.ff1_b, nullptr, h->mlp, B, h->mlp, E, g, s);
   launch_gemm_bf16_nt_epi(ws + w.f0, h->mlp, l.ff2_w, h->mlp, l.ff2_b, x0, E, B, E, h->mlp, r, s);
   return 0;
@@ -236,15 +247,15 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   const int B = batch, T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow;
   const int causal = (flags & 1) ? 1 : 0;
   const bool all_rows = (flags & 2) != 0;             // bit 1 (debug / A-B): run the last block on every token as well
-  launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
+  launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s, h->f16);
   // ViT.py:125-129: the encoding GEMM writes the residual stream itself (frame rows + positional rows in its epilogue: no fp32
   // encoding tensor, no token kernel pass); the cls row of every window is B short rows
   static const bool no_epi_tokens = getenv("PREGO_VIT_TOKENS_KERNEL") != nullptr;       // A/B: the separate token kernel
   if (no_epi_tokens || B * T < 4096) {       // small batches: the 128 x 128 kernel's per-element epilogue costs more than the token kernel
-    launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);
+    launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s, h->f16);
     launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);
   } else {
-    GemmEpi te{};
+    GemmEpi te{}; te.f16 = h->f16 ? 1 : 0;
     te.mode = EPI_TOKENS; te.pe = h->pe; te.n_tok = T;
     launch_gemm_bf16_nt_epi(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.x), E, B * T, E, din, te, s);
     launch_vit_cls_rows(h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);
@@ -301,14 +312,14 @@ extern "C" int prego_vit_forward_frames(prego_vit* h, int n_frames, const float*
   const int T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow;
   const int causal = (flags & 1) ? 1 : 0;
   float* enc = (float*)(base + f.enc);
-  launch_cat_convert(rgb, flow, n_frames, h->d_rgb, h->d_flow, base + f.xb, s);
-  launch_gemm_bf16_nt(base + f.xb, din, h->enc_w, din, h->enc_b, enc, E, n_frames, E, din, s);       // ViT.py:124, once per frame
+  launch_cat_convert(rgb, flow, n_frames, h->d_rgb, h->d_flow, base + f.xb, s, h->f16);
+  launch_gemm_bf16_nt(base + f.xb, din, h->enc_w, din, h->enc_b, enc, E, n_frames, E, din, s, h->f16);       // ViT.py:124, once per frame
   const bool fused = h->layers == 1;            // one layer: the token kernel writes LayerNorm1(x) and x0; x is never materialised
   for (int t0 = 0; t0 < n_frames; t0 += wb) {
     const int B = std::min(wb, n_frames - t0);
     const VitLayer& l0 = h->L[0];
     launch_vit_sliding_tokens(enc, h->enc_b, h->cls, h->pe, t0, B, T, E, fused ? nullptr : (float*)(ws + w.x), l0.ln1_w, l0.ln1_b,
-                              fused ? ws + w.xn : nullptr, fused ? (float*)(ws + w.x0) : nullptr, s);
+                              fused ? ws + w.xn : nullptr, fused ? (float*)(ws + w.x0) : nullptr, s, h->f16);
     for (int li = 0; li < h->layers; ++li) {
       const bool last = li + 1 == h->layers;
       const int rc = last ? encoder_block_token0(h, h->L[li], (const float*)(ws + w.x), ws, w, B, N, causal, s, fused)
@@ -368,6 +379,7 @@ extern "C" size_t prego_vit_train_workspace_bytes(const prego_vit* h, int batch)
 
 extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
                                        void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_forward_train on an fp16-operand handle: training runs on bf16 handles");
   if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0) return prego_fail_(PREGO_EINVAL, "batch %d", batch);
@@ -423,6 +435,7 @@ static void wgrad(const void* a_rows, bool a_bf16, int Mo, const void* b_rows, b
 
 extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
                                   void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_backward on an fp16-operand handle: training runs on bf16 handles");
   if (!h || !dlogits || !grads || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
   if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d gradient tensors, got %d", prego_vit_num_tensors(h), n_tensors);
   for (int i = 0; i < n_tensors; ++i) if (!grads[i]) return prego_fail_(PREGO_EINVAL, "gradient tensor %d is NULL", i);
@@ -538,17 +551,17 @@ extern "C" int prego_debug_attention_fwd(int batch, int n_query, int len, int he
 // the attention arithmetic shared by the stateless op and the handle: wqkv bf16 [3D][D] (rows q | k | v), bqkv fp32 [3D],
 // wob bf16 [D][D]; act = 5 activation buffers of M*D bf16 (x, q, k, v, attention output)
 static int attention_layer_run(int batch, int len, int d_model, int heads, int causal, const float* x, const void* wqkv,
-                               const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s) {
+                               const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s, bool f16 = false) {
   const size_t M = (size_t)batch * len, D = d_model, step = align_up(M * D * 2, 256);
   const int dh = d_model / heads;
   char* xb = act; char* q = act + step; char* k = act + 2 * step; char* vn = act + 3 * step; char* ao = act + 4 * step;
-  launch_cat_convert(x, nullptr, (int)M, d_model, 0, xb, s);
-  GemmEpi e{};
+  launch_cat_convert(x, nullptr, (int)M, d_model, 0, xb, s, f16);
+  GemmEpi e{}; e.f16 = f16 ? 1 : 0;
   e.mode = EPI_QKV; e.q = q; e.k = k; e.vn = vn; e.n_tok = len; e.heads = heads; e.dh = dh; e.emb = d_model;
   e.q_scale = 1.0f / sqrtf((float)dh);                                   // attn.py:44 scale = 1/sqrt(E)
   launch_gemm_bf16_nt_epi(xb, d_model, wqkv, d_model, bqkv, nullptr, 0, (int)M, 3 * d_model, d_model, e, s);
-  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s)) return -1;
-  launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s);
+  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s, nullptr, 0, 1.f, 0, f16)) return -1;
+  launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s, f16);
   return 0;
 }
 static int attention_layer_check(int d_model, int heads) {
@@ -563,7 +576,16 @@ struct prego_attn_layer {
   int d_model, heads;
   void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr;
   bool have_weights = false;
+  bool f16 = false;                // IEEE fp16 operands instead of bf16 (prego_attention_layer_set_compute_dtype)
 };
+extern "C" int prego_attention_layer_set_compute_dtype(prego_attn_layer* h, int compute_dtype) {
+  if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
+  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16)
+    return prego_fail_(PREGO_EINVAL, "AttentionLayer compute_dtype %d: PREGO_BF16 or PREGO_F16", compute_dtype);
+  if ((compute_dtype == PREGO_F16) != h->f16) h->have_weights = false;
+  h->f16 = compute_dtype == PREGO_F16;
+  return PREGO_OK;
+}
 extern "C" int prego_attention_layer_create(prego_attn_layer** out, int d_model, int heads) {
   if (!out) return prego_fail_(PREGO_EINVAL, "out is NULL");
   *out = nullptr;
@@ -591,10 +613,10 @@ extern "C" int prego_attention_layer_set_weights(prego_attn_layer* h, const floa
   hipStream_t s = (hipStream_t)stream;
   const int d = h->d_model;
   const size_t D = d;
-  launch_pad_convert(true, wq, d, d, d, h->wqkv, d, d, s);
-  launch_pad_convert(true, wk, d, d, d, (char*)h->wqkv + D * D * 2, d, d, s);
-  launch_pad_convert(true, wv, d, d, d, (char*)h->wqkv + 2 * D * D * 2, d, d, s);
-  launch_pad_convert(true, wo, d, d, d, h->wo, d, d, s);
+  launch_pad_convert(true, wq, d, d, d, h->wqkv, d, d, s, h->f16);
+  launch_pad_convert(true, wk, d, d, d, (char*)h->wqkv + D * D * 2, d, d, s, h->f16);
+  launch_pad_convert(true, wv, d, d, d, (char*)h->wqkv + 2 * D * D * 2, d, d, s, h->f16);
+  launch_pad_convert(true, wo, d, d, d, h->wo, d, d, s, h->f16);
   HIPCHK(hipMemcpyAsync(h->bqkv, bq, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice, s));
@@ -613,7 +635,7 @@ extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int bat
   if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
   if (workspace_bytes < prego_attention_layer_handle_workspace_bytes(h, batch, len)) return prego_fail_(PREGO_EWORKSPACE, "workspace too small");
   if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, (char*)workspace,
-                          (hipStream_t)stream))
+                          (hipStream_t)stream, h->f16))
     return prego_fail_(PREGO_EINVAL, "attention launch failed");
   HIPCHK(hipGetLastError());
   return PREGO_OK;

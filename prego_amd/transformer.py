@@ -97,8 +97,15 @@ class ViTEnc(nn.Module):
         self.dropout_rate = float(cfg.get("dropout", 0.0))           # ViT.py:38
         self.attn_dropout_rate = float(cfg.get("attn_dropout_rate", 0.0))   # ViT.py:47
         self.causal = bool(cfg.get("causal_attention", False))     # extension, see DESIGN.md
-        self._h = None
+        # MFMA operand type of the INFERENCE entry points (forward in eval mode, forward_frames): 'fp16' (default: same rate as bf16,
+        # 8x less operand rounding) or 'bf16'.  Training always runs on the bf16 handle.
+        self.compute_dtype = cfg.get("compute_dtype", "fp16")
+        if self.compute_dtype not in ("fp16", "bf16"):
+            raise PregoError(f"ViTEnc compute_dtype {self.compute_dtype!r}: 'fp16' or 'bf16' (16-bit MFMA operands; there is no fp32-operand transformer path)")
+        self._h = None               # bf16 handle: training, and inference when compute_dtype == 'bf16'
         self._ver = None
+        self._h16 = None             # fp16 handle (inference only), own weight copies
+        self._ver16 = None
         self._ws = None
 
     def _handle(self):
@@ -122,6 +129,31 @@ class ViTEnc(nn.Module):
             self._keep, self._ver = ts, ver
         return lib, dev
 
+    def _eval_handle(self):
+        """(lib, device, handle) of the inference entry points: the fp16-operand handle when compute_dtype == 'fp16'"""
+        if self.compute_dtype != "fp16":
+            lib, dev = self._handle()
+            return lib, dev, self._h
+        dev = self.mlp_head.weight.device
+        if dev.type != "cuda":
+            raise PregoError("prego_amd runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        lib = _lib.load()
+        if self._h16 is None:
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                check(lib.prego_vit_create(C.byref(h), self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim,
+                                           self.num_heads, self.num_layers, self.img_dim, self.out_dim))
+                check(lib.prego_vit_set_compute_dtype(h, _lib.PREGO_F16))
+            self._h16 = h
+        sd = dict(self.named_parameters())
+        ver = tuple((p.data_ptr(), p._version) for p in sd.values())
+        if ver != self._ver16:
+            ts = [sd[k].detach().float().contiguous() for k in _tensor_order(self.num_layers)]
+            with torch.cuda.device(dev):
+                check(lib.prego_vit_set_weights(self._h16, ptr_array([t.data_ptr() for t in ts]), len(ts), C.c_void_p(_stream_ptr(dev))))
+            self._keep16, self._ver16 = ts, ver
+        return lib, dev, self._h16
+
     def _inputs(self, sequence_input_rgb, sequence_input_flow):
         rgb = sequence_input_rgb.float().contiguous() if self.use_rgb else None
         flow = sequence_input_flow.float().contiguous() if self.use_flow else None
@@ -135,14 +167,14 @@ class ViTEnc(nn.Module):
             names = _tensor_order(self.num_layers)
             sd = dict(self.named_parameters())
             return {"logits": _ViTTrainFn.apply(self, sequence_input_rgb, sequence_input_flow, *[sd[k] for k in names]).unsqueeze(1)}
-        lib, dev = self._handle()
+        lib, dev, hnd = self._eval_handle()
         rgb, flow, B = self._inputs(sequence_input_rgb, sequence_input_flow)
-        need = lib.prego_vit_workspace_bytes(self._h, B)
+        need = lib.prego_vit_workspace_bytes(hnd, B)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((B, self.out_dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            check(lib.prego_vit_forward(self._h, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
+            check(lib.prego_vit_forward(hnd, B, None if rgb is None else C.c_void_p(rgb.data_ptr()), None if flow is None else C.c_void_p(flow.data_ptr()),
                                         C.c_void_p(out.data_ptr()), (1 if self.causal else 0) | (2 if getattr(self, "debug_all_rows", False) else 0),
                                         C.c_void_p(self._ws.data_ptr()),
                                         self._ws.numel(), C.c_void_p(_stream_ptr(dev))))
@@ -158,7 +190,7 @@ class ViTEnc(nn.Module):
         logits[t] = the reference forward on the `window_size` frames ending at t, zero feature rows in front of the video - the
         windows the training loader cuts (dataset.py:53-55,96-103) at stride 1; linear_encoding runs once per frame
         (prego_vit_forward_frames).  ViTEnc's output is raw logits in both modes (ViT.py:138-141)."""
-        lib, dev = self._handle()
+        lib, dev, hnd = self._eval_handle()
         rgb = rgb.float().contiguous() if self.use_rgb else None
         flow = flow.float().contiguous() if (self.use_flow and flow is not None) else None
         src = rgb if rgb is not None else flow
@@ -166,14 +198,14 @@ class ViTEnc(nn.Module):
             raise PregoError("forward_frames: a --no_rgb model needs the flow tensor")
         T = int(src.shape[0])
         wb = min(self.windows_per_batch, T)
-        need = lib.prego_vit_frames_workspace_bytes(self._h, T, wb)
+        need = lib.prego_vit_frames_workspace_bytes(hnd, T, wb)
         if getattr(self, "_ws_frames", None) is None or self._ws_frames.numel() < need:
             self._ws_frames = None
             self._ws_frames = torch.empty(need, dtype=torch.uint8, device=dev)
         out = torch.empty((T, self.out_dim), dtype=torch.float32, device=dev)
         arg = torch.empty((T,), dtype=torch.int32, device=dev) if want_argmax else None
         with torch.cuda.device(dev):
-            check(lib.prego_vit_forward_frames(self._h, T, None if rgb is None else C.c_void_p(rgb.data_ptr()),
+            check(lib.prego_vit_forward_frames(hnd, T, None if rgb is None else C.c_void_p(rgb.data_ptr()),
                                                None if flow is None else C.c_void_p(flow.data_ptr()), C.c_void_p(out.data_ptr()),
                                                None if arg is None else C.c_void_p(arg.data_ptr()), wb, 1 if self.causal else 0,
                                                C.c_void_p(self._ws_frames.data_ptr()), self._ws_frames.numel(), C.c_void_p(_stream_ptr(dev))))
@@ -197,8 +229,9 @@ class ViTEnc(nn.Module):
 
     def __del__(self):
         try:
-            if self._h is not None:
-                _lib.load().prego_vit_destroy(self._h)
+            for h in (self._h, getattr(self, "_h16", None)):
+                if h is not None:
+                    _lib.load().prego_vit_destroy(h)
         except Exception:
             pass
 
@@ -249,8 +282,11 @@ class AttentionLayer:
     """AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170 as an object that owns converted weights: the four projection
     matrices are ingested (fp32 -> bf16) once, every call only moves activations."""
 
-    def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True):
+    def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16"):
         self.lib = _lib.load()
+        if compute_dtype not in ("fp16", "bf16"):
+            raise PregoError(f"AttentionLayer compute_dtype {compute_dtype!r}: 'fp16' or 'bf16'")
+        self.compute_dtype = compute_dtype
         self.device = wq.device
         if self.device.type != "cuda":
             raise PregoError("prego_amd runs on an MI355X only (device must be cuda:N); there is no CPU path")
@@ -258,6 +294,7 @@ class AttentionLayer:
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.prego_attention_layer_create(C.byref(h), self.d_model, self.n_heads))
+            check(self.lib.prego_attention_layer_set_compute_dtype(h, _lib.PREGO_F16 if compute_dtype == "fp16" else _lib.PREGO_BF16))
             ts = [t.detach().float().contiguous() for t in (wq, bq, wk, bk, wv, bv, wo, bo)]
             self.h = h
             check(self.lib.prego_attention_layer_set_weights(self.h, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_void_p(_stream_ptr(self.device))))
@@ -289,14 +326,14 @@ class AttentionLayer:
 _LAYER_CACHE = {}
 
 
-def attention_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True):
+def attention_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16"):
     """AttentionLayer(FullAttention(mask_flag)) forward (attn.py:139-170): x [B,L,D] fp32 cuda -> [B,L,D].  Functional form: the
     converted weights are cached on (tensor identity, version), so repeated calls with the same parameters ingest them once."""
     ws = (wq, bq, wk, bk, wv, bv, wo, bo)
-    key = tuple((t.data_ptr(), t._version) for t in ws) + (int(n_heads), bool(mask_flag))
+    key = tuple((t.data_ptr(), t._version) for t in ws) + (int(n_heads), bool(mask_flag), compute_dtype)
     layer = _LAYER_CACHE.get("layer") if _LAYER_CACHE.get("key") == key else None
     if layer is None:
-        layer = AttentionLayer(*ws, n_heads=n_heads, mask_flag=mask_flag)
+        layer = AttentionLayer(*ws, n_heads=n_heads, mask_flag=mask_flag, compute_dtype=compute_dtype)
         _LAYER_CACHE.clear()
         _LAYER_CACHE.update(key=key, layer=layer)
     return layer(x)

@@ -20,11 +20,15 @@ def _vit_cfg(**kw):
     return assembly101_cfg(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, **kw)
 
 
-def test_g5_vit_forward_matches_reference():
+VTOL = {"fp16": 1e-3, "bf16": 1e-2}     # north star: 1e-3 (fp32) / 1e-2 (bf16); fp16 operands meet the fp32 figure on this path
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_g5_vit_forward_matches_reference(dtype):
     from prego_amd.registry import build_model
     import prego_amd.transformer  # noqa: F401
     g = np.load(os.path.join(G, "g5_vit_forward.npz"))
-    cfg = _vit_cfg()
+    cfg = _vit_cfg(compute_dtype=dtype)
     sd = W.vit_state_dict(cfg, 20)
     m = build_model(cfg, "cuda:0")
     missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})   # strict: same keys as the reference
@@ -37,8 +41,8 @@ def test_g5_vit_forward_matches_reference():
     assert out.shape == (2, 1, 86)
     got = out.cpu().numpy()
     err = np.abs(got - g["logits"]).max()
-    print("vit logits max abs err", err, "scale", np.abs(g["logits"]).max())
-    assert err < 1e-2 * max(1.0, np.abs(g["logits"]).max())
+    print(f"vit logits {dtype} max abs err", err, "scale", np.abs(g["logits"]).max())
+    assert err < VTOL[dtype] * max(1.0, np.abs(g["logits"]).max())
     assert np.array_equal(got.argmax(-1), g["logits"].argmax(-1))
 
 
@@ -55,23 +59,24 @@ def test_vit_state_dict_keys_match_reference():
     assert sum(p.numel() for p in m.parameters()) == 29822038
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 @pytest.mark.parametrize("L", [128, 1024])
-def test_g6_causal_attention_layer(L):
+def test_g6_causal_attention_layer(L, dtype):
     from prego_amd.transformer import attention_layer
     g = np.load(os.path.join(G, f"g6_causal_attention_L{L}.npz"))
     sd = W.attention_layer_state_dict(2048, 20)
     x = W.normal((1, L, 2048), 20, f"g6.x.{L}")
     names = ("query_projection", "key_projection", "value_projection", "out_projection")
     args = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
-    out = attention_layer(torch.from_numpy(x).cuda(), *args, n_heads=8, mask_flag=True)[0].cpu().numpy()
+    out = attention_layer(torch.from_numpy(x).cuda(), *args, n_heads=8, mask_flag=True, compute_dtype=dtype)[0].cpu().numpy()
     ref = g["out"]
     err = np.abs(out[g["rows"]] - ref).max()
-    print(f"causal attention L={L}: max abs err {err:.3e}, output scale {np.abs(ref).max():.3f}")
-    assert err < 1e-2 * max(1.0, np.abs(ref).max())
+    print(f"causal attention L={L} {dtype}: max abs err {err:.3e}, output scale {np.abs(ref).max():.3f}")
+    assert err < VTOL[dtype] * max(1.0, np.abs(ref).max())
     # causality property at full size: perturbing the last frame leaves rows 0..L-2 bit-identical
     x2 = x.copy()
     x2[0, -1] += 1.0
-    out2 = attention_layer(torch.from_numpy(x2).cuda(), *args, n_heads=8, mask_flag=True)[0].cpu().numpy()
+    out2 = attention_layer(torch.from_numpy(x2).cuda(), *args, n_heads=8, mask_flag=True, compute_dtype=dtype)[0].cpu().numpy()
     assert np.array_equal(out[:-1], out2[:-1])
     assert not np.array_equal(out[-1], out2[-1])
 
