@@ -200,14 +200,21 @@ def test_fused_adamw_refreshes_vit_handle(layers):
     from prego_amd.optim import FusedAdamW
     from prego_amd.registry import build_criterion, build_model
     import prego_amd.loss, prego_amd.transformer  # noqa: F401
-    cfg = _vit_cfg(num_layers=layers)
+    cfg = _vit_cfg(num_layers=layers, compute_dtype="bf16")      # eval on the SAME (bf16) handle whose copies the fused step refreshes
     sd = W.vit_state_dict(cfg, 20)
     rgb = torch.from_numpy(W.tsn_features((3, 128, 2048), 22, "va.rgb")).cuda()
     flow = torch.from_numpy(W.tsn_features((3, 128, 2048), 22, "va.flow")).cuda()
     tgt = torch.from_numpy(_targets(3, 128, 86, 22, "va.tgt")).cuda()
     lib = _lib.load()
     res = {}
+    real_set_weights = lib.prego_vit_set_weights
     for kind in ("handle", "generic"):
+        ingests = []
+
+        def counting(*a, _n=ingests):
+            _n.append(1)
+            return real_set_weights(*a)
+        lib.prego_vit_set_weights = counting
         model = build_model(cfg, "cuda:0")
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         crit = build_criterion(cfg, "cuda:0")
@@ -226,9 +233,12 @@ def test_fused_adamw_refreshes_vit_handle(layers):
         with torch.no_grad():
             logits = model(rgb, flow)["logits"]
         torch.cuda.synchronize()
-        res[kind] = (losses, logits.clone(), {k: p.detach().clone() for k, p in model.named_parameters()}, vers, model._ver)
-    # the handle path never re-ingested (the version key of the ingested weights did not move), the generic path did every step
-    assert res["handle"][3][0] == res["handle"][4] and res["generic"][3][0] != res["generic"][4]
+        lib.prego_vit_set_weights = real_set_weights
+        res[kind] = (losses, logits.clone(), {k: p.detach().clone() for k, p in model.named_parameters()}, vers, len(ingests))
+    # the handle path ingested the weights ONCE (the fused step rewrites the handle's copies and records the bumped parameter
+    # versions as ingested); the generic path re-ingested after every step: before forwards 2 and 3 and before the eval forward
+    assert res["handle"][4] == 1 and res["generic"][4] == 4, (res["handle"][4], res["generic"][4])
+    assert len(set(res["handle"][3])) == 3          # the parameter versions DO move now (raw-pointer update made visible)
     assert res["handle"][0] == res["generic"][0] and res["handle"][0][2] < res["handle"][0][0]
     for k in res["handle"][2]:
         assert torch.equal(res["handle"][2][k], res["generic"][2][k]), k
