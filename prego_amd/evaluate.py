@@ -56,15 +56,18 @@ class Evaluate(nn.Module):
         """the reference's output file ({vid: {"pred": [...], "gt": [...]}}, eval.py:59-65) written from the int arrays directly:
         class ids through a table of pre-formatted byte strings (json.dump walks 2 x frames Python ints one at a time: 0.25 s for
         0.8 M frames, five times the forward pass).  Same JSON value; numbers are padded with blanks, which JSON allows."""
-        lut = np.array([("%4d," % i).encode() for i in range(1000)], dtype="S5")
+        lut4 = np.frombuffer(b"".join(("%3d," % i).encode() for i in range(100)), dtype=np.uint32)         # one 4-byte gather per id < 100
+        lut5 = np.frombuffer(b"".join(("%4d," % i).encode() for i in range(1000)), dtype=np.uint8).reshape(1000, 5)
 
         def arr(a):
-            a = np.asarray(a, dtype=np.int64)
+            a = np.asarray(a)
             if a.size == 0:
                 return b"[]"
-            if a.min() < 0 or a.max() >= 1000:
+            lo, hi = int(a.min()), int(a.max())
+            if lo < 0 or hi >= 1000:
                 return json.dumps(a.tolist()).encode()
-            return b"[" + lut[a].tobytes()[:-1] + b"]"
+            body = lut4[a].tobytes() if hi < 100 else np.take(lut5, a, axis=0).tobytes()
+            return b"[" + body[:-1] + b"]"
         parts = [json.dumps(str(vid)).encode() + b': {"pred": ' + arr(v["pred"]) + b', "gt": ' + arr(v["gt"]) + b"}" for vid, v in output.items()]
         return b"{" + b", ".join(parts) + b"}"
 
@@ -91,13 +94,18 @@ class Evaluate(nn.Module):
             rgb = [b[0].to(device) for b in batch]
             flow = None if zero_flow else [b[1].to(device) for b in batch]
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        want_json = self.cfg["eval"] is not None
+        arg_host = torch.cat(args).cpu().numpy() if want_json else None     # ONE device -> host copy for the whole batch's argmax
+        o = 0
         for (r, f, target, vid), p, a in zip(batch, probs, args):
             # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
             # once at the end); the reference extends Python lists by one row object per frame (eval.py:46-49)
             pred_scores.append(p)
             gt_targets.append(target.to(p.device, non_blocking=True))
-            if self.cfg["eval"] is not None:
-                output[vid] = {"pred": a.cpu().numpy(), "gt": torch.argmax(target, dim=1).numpy()}      # int arrays; lists only at the end
+            if want_json:
+                n = int(a.shape[0])
+                output[vid] = {"pred": arg_host[o:o + n], "gt": torch.argmax(target, dim=1).numpy()}      # int arrays; text only at the end
+                o += n
                 self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
         batch.clear()
 

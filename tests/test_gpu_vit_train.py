@@ -20,7 +20,8 @@ G = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def _vit_cfg(**over):
-    cfg = dict(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0)
+    # compute_dtype bf16: the training tests compare eval-mode and training-mode forwards of the SAME (bf16) handle bit for bit
+    cfg = dict(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, compute_dtype="bf16")
     cfg.update(over)
     return assembly101_cfg(**cfg)
 
