@@ -38,6 +38,8 @@ def parse():
                     help="eval = the headline metric (per-frame inference); train = BASELINE configs[2]: data-parallel training steps "
                          "(fwd + OadLoss + BPTT + bucketed gradient all-reduce over RCCL + fused AdamW), global batch fixed (strong scaling)")
     ap.add_argument("--global-batch", type=int, default=16, help="--mode train: windows per step over all ranks (configs/miniroad_assembly101-O.yaml: 16)")
+    ap.add_argument("--local-batch", type=int, default=0, help="--mode train: windows per step PER RANK (weak scaling: the global batch grows with N); "
+                                                               "0 = split --global-batch over the ranks")
     ap.add_argument("--grad-compress", default=None, choices=["bf16"], help="--mode train: all-reduce the gradient bucket in bf16")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (train step, ViTEnc, causal attention, fp32 mode)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU work): checks the N-rank launch path on a CPU box")
@@ -113,9 +115,12 @@ def train_mode(args, rank, world, dev, dist):
     from prego_amd.optim import FusedAdamW
     from prego_amd.registry import TRAINER, build_criterion, build_model
     import prego_amd.loss, prego_amd.model, prego_amd.trainer  # noqa: F401,E401
-    if args.global_batch % world:
+    weak = args.local_batch > 0
+    if not weak and args.global_batch % world:
         raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of {world} ranks")
-    Bl, T = args.global_batch // world, 128
+    Bl, T = (args.local_batch if weak else args.global_batch // world), 128
+    if weak:
+        args.global_batch = Bl * world
     cfg = assembly101_cfg(compute_dtype="bf16", grad_compress=args.grad_compress)
     model = build_model(cfg, dev)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.miniroad_state_dict(cfg, 20).items()})
@@ -155,7 +160,7 @@ def train_mode(args, rank, world, dev, dist):
         print(json.dumps({
             "metric": "training frames/sec (MiniROAD, windows of 128 frames, OadLoss + AdamW), data parallel", "value": frames / (dt / args.steps),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_ms,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "mode": "train",
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "mode": "train",
             "config": {"workload": "BASELINE configs[2]: Assembly101-O training step, global batch %d windows x 128 frames x (2048 rgb + 2048 "
                                    "flow), dropout 0.2, AdamW lr 1e-4 wd 0.05" % args.global_batch,
                        "local_batch": Bl, "parallelism": f"window-sharded dp{world}, one gradient all-reduce per step in 3 sub-buckets (RCCL)",

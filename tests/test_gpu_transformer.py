@@ -172,7 +172,7 @@ def test_attention_layer_stateless_op_equals_handle():
     names = ("query_projection", "key_projection", "value_projection", "out_projection")
     ws = [torch.from_numpy(sd[n + s]).cuda() for n in names for s in (".weight", ".bias")]
     x = torch.from_numpy(W.normal((B, L, d), 20, "attn.handle.x")).cuda()
-    a = AttentionLayer(*ws, n_heads=H, mask_flag=True)(x)
+    a = AttentionLayer(*ws, n_heads=H, mask_flag=True, compute_dtype="bf16")(x)      # the stateless op is the bf16 form
     need = lib.prego_attention_layer_workspace_bytes(B, L, d)
     wsb = torch.empty(need, dtype=torch.uint8, device="cuda")
     out = torch.empty_like(x)
