@@ -38,6 +38,7 @@
 //  * every spin is bounded; a timeout raises an abort word that ends the launch (no hung GPU).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 #define SPIN_LIMIT (1u << 22)
 #ifndef GRU_NSEG
@@ -518,6 +519,402 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Multi-tile steps, software-pipelined (round 3).  With two or more live clip tiles per group the kernel above runs the
+// tiles of a step strictly one after the other (measured 2.0 / 4.0 / 8.6 us per step for 1 / 2 / 4 tiles): every tile pays its
+// own gather - ~1 000 cycles of L2 latency and transfer for 32 KB per CU, although its data was published a whole tile-slot
+// earlier and is simply sitting in the XCD's L2.  Here the gather of the NEXT tile-slot (tile ct + 1 of this step, or tile 0
+// of the next step after the last live tile) is issued right behind this tile's MFMAs as LDS-DMA (global_load_lds_dwordx4: L2 ->
+// LDS, lane-linear 1 KiB per fragment, wave-private region, no destination registers the compiler could copy before the data has
+// landed - a first version with asm loads into VGPRs was miscompiled exactly that way: hipcc parked the "loaded" registers in
+// AGPRs right behind the issue), and consumed one slot later: a hand-counted `s_waitcnt vmcnt(5)`, then eight ds_read_b128 of the
+// wave's own image.  Exactly five vector-memory instructions
+// are issued between the two points on every path - the three gi prefetch loads, the publish store and the relu(h) store, all
+// made unconditional (lanes / tiles that must not act use an offset past the buffer's num_records: no memory access, but the
+// instruction is issued and counted; a wait count that is too SMALL only waits longer, one that is too large would read
+// registers before their data has landed).  The compiler's own waits stay correct: it counts fewer outstanding operations
+// than there are, i.e. it can only over-wait.  Same arithmetic, same summation order as the kernel above: bit-identical
+// results (the chunking / continuous-batching / clip-alone tests run both).  bf16 / fp16 operands, inference only.
+// A step with ONE live tile cannot prefetch (its h is not produced yet) and runs the classic sequence; launches whose live
+// slots fit one tile per group use the kernel above (launch_gru_recurrence picks per launch).
+// ------------------------------------------------------------------------------------------------------------------------
+#define GRU_MT_DMA(SRC, LDSADDR, POLICY) \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off " POLICY : : "v"(SRC), "s"(LDSADDR) : "memory", "m0")
+
+template <typename WT, int HID, int NCT, bool SPEC>
+__global__ __launch_bounds__(256, 1) void gru_recurrence_mt_kernel(GruArgs a) {
+  static_assert(sizeof(WT) == 2 && NCT >= 2, "multi-tile kernel: 16-bit operands, two or more clip tiles");
+  typedef typename gru_ot<WT>::type OT;
+  constexpr int UT = 2, UNITS = 16 * UT, KQ = HID / 4, NKS = KQ / 32, KF = 32, EPL = 8;
+  constexpr unsigned TAGM = 0x40004000u;
+  constexpr int GROUP_BYTES = (HID / KF) * GRU_MAX_TILES * 1024;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f32x4* red = (f32x4*)smem;                  // [2 parities][4 waves][3 gates][UT][64 lanes]
+  constexpr int RED_STRIDE = 4 * 3 * UT * 64;
+  constexpr int RED_BYTES = 2 * RED_STRIDE * 16;
+  char* gsm = smem + RED_BYTES;               // gather images [2 buffers][4 waves][NKS fragments][64 lanes][16 B]
+  const unsigned gsm_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)gsm;
+  constexpr int GATHER_BYTES = 2 * 4 * NKS * 1024;
+  // gi rows (16-bit pairs of my two units) also arrive by LDS-DMA: [2 step parities][NCT][3 gates][256 threads] dwords.  With
+  // no compiler-visible vector load left in the loop, hipcc inserts no vmcnt wait of its own (its conservative vmcnt(0) in
+  // front of the loop-carried gi registers would wait for the gather prefetch too: measured in the first build of this kernel)
+  unsigned* gism = (unsigned*)(gsm + GATHER_BYTES);
+  const unsigned gism_lds = gsm_lds + (unsigned)GATHER_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- placement rendezvous (as in gru_recurrence_kernel)
+  constexpr int P = HID / UNITS;
+  __shared__ int s_place[4];
+  if (tid == 0) {
+    int gg = blockIdx.x % a.G, ww = blockIdx.x / a.G, loc = 0;
+    if (a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P) {
+      const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+      const unsigned ticket = __hip_atomic_fetch_add(a.sync + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      bool ok = true;
+      while (__hip_atomic_load(a.sync + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+        if (++spins > SPIN_LIMIT) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (!ok) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); loc = -1; }
+      else {
+        loc = 1;
+        for (int i = 0; i < 8; ++i)
+          if (__hip_atomic_load(a.sync + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)P) loc = 0;
+        if (loc) { gg = xcc; ww = (int)ticket; }
+      }
+    }
+    s_place[0] = gg; s_place[1] = ww; s_place[2] = loc;
+  }
+  __syncthreads();
+  const int g = __builtin_amdgcn_readfirstlane(s_place[0]);
+  const int w = __builtin_amdgcn_readfirstlane(s_place[1]);
+  const int place = __builtin_amdgcn_readfirstlane(s_place[2]);
+  if (place < 0) return;
+  const bool local = place == 1;
+  if (g >= a.n_clips) return;
+  {
+    typedef const __attribute__((address_space(4))) int* cint_p0;
+    if (g >= ((cint_p0)a.nact)[a.t0]) return;
+  }
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // ---- resident weights
+  bf16x8 wb[3][UT][NKS];
+#pragma unroll
+  for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const size_t row = (size_t)gate * HID + w * UNITS + ut * 16 + l15;
+        wb[gate][ut][ks] = *(const bf16x8*)((const bf16_t*)a.whh + row * HID + q * KQ + ks * 32 + 8 * l4);
+      }
+  const int own_ut = q & 1, own_r0 = (q >> 1) * 2;
+  const int ucol = w * UNITS + own_ut * 16 + l4 * 4 + own_r0;
+  float hreg[NCT][2], bhn[2];
+  int sidx[NCT], tfirst[NCT];
+  bhn[0] = a.b_hn[ucol]; bhn[1] = a.b_hn[ucol + 1];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    sidx[ct] = ct * 16 * a.G + l15 * a.G + g;
+    tfirst[ct] = ct * 16 * a.G + g;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) hreg[ct][e] = (sidx[ct] < a.n_clips) ? a.h_state[(size_t)sidx[ct] * HID + ucol + e] : 0.f;
+  }
+  int nstart[NCT], segp[NCT], sege[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    nstart[ct] = 0x7fffffff; segp[ct] = 0; sege[ct] = 0;
+    if (a.seg_start != nullptr && sidx[ct] < a.n_clips) {
+      int k = a.seg_off[sidx[ct]];
+      sege[ct] = a.seg_off[sidx[ct] + 1];
+      while (k < sege[ct] && a.seg_start[k] < a.t0) ++k;
+      if (k < sege[ct] && a.seg_start[k] == a.t0 && a.t0 > 0) { hreg[ct][0] = 0.f; hreg[ct][1] = 0.f; }
+      while (k < sege[ct] && a.seg_start[k] <= a.t0) ++k;
+      segp[ct] = k;
+      nstart[ct] = k < sege[ct] ? a.seg_start[k] : 0x7fffffff;
+    }
+  }
+
+  // ---- exchange buffers; relu(h) output through a buffer resource (dead lanes: offset past num_records, instruction still issued)
+  const int buf_stride = a.G * GROUP_BYTES;
+  char* hx_base = (char*)a.hx + (size_t)g * GROUP_BYTES;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hx_base, 0, buf_stride + GROUP_BYTES, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs_hr = __builtin_amdgcn_make_buffer_rsrc(a.h_relu_out, 0, 0x7FFFFFF0, 0x00020000);
+  constexpr int OOR = 0x7FFFFFF8;                 // >= num_records of both resources
+  auto publish = [&](int ct, int buf, unsigned tag, bool zero, bool cond) {
+    const int off = buf * buf_stride + ((ucol / KF) * GRU_MAX_TILES + ct) * 1024 + ((((ucol % KF) / EPL) << 4) + l15) * 16 + (ucol % EPL) * 2;
+    f32x2 hv = {zero ? 0.f : hreg[ct][0], zero ? 0.f : hreg[ct][1]};
+    hv[0] = __builtin_amdgcn_fmed3f(hv[0], -1.9921875f, 1.9921875f);
+    hv[1] = __builtin_amdgcn_fmed3f(hv[1], -1.9921875f, 1.9921875f);
+    const unsigned v = (op16<OT>::pack2(hv[0], hv[1]) & 0xBFFFBFFFu) | (tag ? 0x40004000u : 0u);
+    if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, cond ? off : OOR, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(v, rs, cond ? off : OOR, 0, AUX_SC1);
+  };
+  // gi of one step for tile ct -> LDS (three 4-byte DMA per wave: counted instructions 1-3 of a slot); lanes whose slot has ended read
+  // row 0 of the step, which always exists, and ignore it
+  auto gi_dma = [&](int par, int ct, int na, int rbase) {
+    const int r = rbase + (sidx[ct] < na ? sidx[ct] : 0);
+    const bf16_t* src = (const bf16_t*)a.gi + (size_t)r * (3 * HID) + ucol;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(gism_lds + (unsigned)(((par * NCT + ct) * 3) * 1024 + q * 256)));
+#pragma unroll
+    for (int gate = 0; gate < 3; ++gate)
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(src + gate * HID), "s"(dst + (unsigned)gate * 1024u) : "memory", "m0");
+  };
+  // gather issue: the 8 fragments of tile ct from exchange buffer rbuf into LDS image `img` (0 / 1) of this wave; dead columns are
+  // not fetched (their lanes are masked off: the image keeps whatever it held, the columns are never used)
+  auto issue = [&](int img, int rbuf, int ct, bool col_live, bool sc1) {
+    const char* src = hx_base + (size_t)rbuf * buf_stride + (size_t)((q * NKS) * GRU_MAX_TILES + ct) * 1024 + lane * 16;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(gsm_lds + (unsigned)((img * 4 + q) * NKS) * 1024u));
+    if (col_live) {
+      if (!sc1) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) GRU_MT_DMA(src + (size_t)ks * GRU_MAX_TILES * 1024, dst + (unsigned)ks * 1024u, "nt");
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) GRU_MT_DMA(src + (size_t)ks * GRU_MAX_TILES * 1024, dst + (unsigned)ks * 1024u, "sc1");
+      }
+    }
+  };
+  auto fetch = [&](u32x4 (&hbr)[NKS], int img) {           // the wave's own image -> fragment registers
+    const u32x4* p = (const u32x4*)(gsm + (size_t)((img * 4 + q) * NKS) * 1024) + lane;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) hbr[ks] = p[ks * 64];
+  };
+
+  typedef const __attribute__((address_space(4))) int* cint_p;
+  cint_p nact_c = (cint_p)a.nact;
+  cint_p rowoff_c = (cint_p)a.rowoff;
+  const int nsteps = a.t1 - a.t0;
+  int na_c = nact_c[a.t0], rb_c = rowoff_c[a.t0];
+  int na_n = nsteps > 1 ? nact_c[a.t0 + 1] : 0, rb_n = nsteps > 1 ? rowoff_c[a.t0 + 1] : 0;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+    if (tfirst[ct] < na_c) {
+      publish(ct, 1, 1u, false, true);
+      gi_dma(0, ct, na_c, rb_c - a.row_base);      // step tl = 0 reads parity 0
+    }
+  int parity = 0;
+  bool pre0 = false;                              // tile 0 of the step about to run was prefetched into image 0
+  // debug stamps (PREGO_GRU_STAMPS=1), workgroup 0 / wave 0, cycle sums per tile-slot phase: 0 gather wait, 1 LDS fetch + MFMA with the tag
+  // check and the next slot's DMA inside, 2 = COUNT of tiles redone on stale data, 3 gi DMA issue, 4 LDS reduction write + barrier, 5 gates, 6 stores; [7] = tile-slots; retries in [5]'s slot of the classic layout is not kept
+  const bool stamp = a.stamps != nullptr && blockIdx.x == 0 && q == 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_t = 0;
+#ifdef GRU_MT_STAMPS      // diagnostic build only (scripts/probes/mt_stamps.py): the stamp branches cut every phase into its own basic block
+#define MSTAMP(i) do { if (stamp) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define MSTAMP(i) do { } while (0)
+#endif
+
+  auto step = [&](const int tl) -> bool {
+    const int t = a.t0 + tl;
+    const int na = na_c;
+    const int rbase = rb_c - a.row_base;
+    const bool more = tl + 1 < nsteps;
+    const int t2 = (tl + 2 < nsteps) ? t + 2 : t;
+    const int na_2 = nact_c[t2], rb_2 = rowoff_c[t2];
+    const int rbuf = (tl + 1) & 1;
+    const unsigned etag = (unsigned)(((tl - 1) >> 1) & 1);
+    const unsigned eword = etag ? TAGM : 0u;
+    const unsigned untag = etag ? ~TAGM : 0xFFFFFFFFu;
+    // what the NEXT step's tile-0 gather expects (issued at the end of this step when two or more tiles are alive)
+    const int rbuf_n = tl & 1;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      if (tfirst[ct] < na) {
+        u32x4 HB[NKS];
+        const bool col_live = sidx[ct] < na;
+        // ---- (1) this tile's h_{t-1}: prefetched one slot ago (hand-counted wait), or fetched now (first step of the launch, or
+        // the previous step had a single live tile)
+        const bool prefetched = ct > 0 || pre0;
+#ifdef GRU_MT_STAMPS
+        if (stamp) { st_t = __builtin_amdgcn_s_memtime(); st_acc[7] += 1; }
+#endif
+        if (prefetched) {
+          asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+          issue(ct & 1, rbuf, ct, col_live, !local);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        MSTAMP(0);
+        fetch(HB, ct & 1);
+        // ---- where the next tile-slot's gather comes from (decided before the multiply: its eight DMA go out BETWEEN the MFMAs)
+        const bool next_is_tile = ct + 1 < NCT && tfirst[ct + 1 < NCT ? ct + 1 : ct] < na;
+        int nx_img = 0, nx_rbuf = rbuf, nx_ct = 0;
+        bool nx_any = false, nx_live = false;
+        if (ct + 1 < NCT && next_is_tile) {
+          nx_any = true; nx_img = (ct + 1) & 1; nx_ct = ct + 1; nx_live = sidx[ct + 1 < NCT ? ct + 1 : ct] < na;
+        } else if (ct > 0) {                         // last live tile of this step, and not the only one: tile 0 of step t + 1
+          pre0 = more && tfirst[0] < na_n;
+          nx_any = pre0; nx_img = 0; nx_rbuf = rbuf_n; nx_ct = 0; nx_live = sidx[0] < na_n;
+        } else {
+          pre0 = false;                              // a single live tile: its next h does not exist yet
+        }
+        const char* nx_src = hx_base + (size_t)nx_rbuf * buf_stride + (size_t)((q * NKS) * GRU_MAX_TILES + nx_ct) * 1024 + lane * 16;
+        const unsigned nx_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(gsm_lds + (unsigned)((nx_img * 4 + q) * NKS) * 1024u));
+        const bool nx_issue = nx_any && nx_live;
+        // ---- tag check + multiply in a fixed order.  With four tiles per group a prefetched image is two or more slots old and
+        // practically never stale (10 of 2 048 slots in the stamped run): the check (64 VALU operations) then rides in the MFMAs'
+        // issue shadow and a stale tile is fetched again and REDONE; with two tiles the image is one slot old and stale half of the
+        // time (measured), so the check comes first there
+        f32x4 acc[3][UT];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        auto refetch = [&]() -> bool {                   // until every fragment shows the expected tag; false = timed out
+          unsigned spins = 0;
+          for (;;) {
+            if (++spins > SPIN_LIMIT) {
+              if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              return false;
+            }
+            if ((spins & 255u) == 0u) {
+              if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            }
+            issue(ct & 1, rbuf, ct, col_live, !(local && spins < 6u));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fetch(HB, ct & 1);
+            unsigned b2 = 0u;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+              b2 |= ((HB[ks][0] ^ eword) | (HB[ks][1] ^ eword)) | ((HB[ks][2] ^ eword) | (HB[ks][3] ^ eword));
+            if (__all(!col_live || (b2 & TAGM) == 0u)) return true;
+          }
+        };
+        unsigned badv = 0u;
+        if constexpr (!SPEC) {
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+            badv |= ((HB[ks][0] ^ eword) | (HB[ks][1] ^ eword)) | ((HB[ks][2] ^ eword) | (HB[ks][3] ^ eword));
+          if (!__all(!col_live || (badv & TAGM) == 0u)) {
+            if (!refetch()) return false;
+          }
+          badv = 0u;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          u32x4 v = HB[ks];
+          if constexpr (SPEC) badv |= ((v[0] ^ eword) | (v[1] ^ eword)) | ((v[2] ^ eword) | (v[3] ^ eword));
+          v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;
+          const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+          for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int ut = 0; ut < UT; ++ut) acc[gate][ut] = op16<OT>::mfma(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut]);
+        }
+        if constexpr (SPEC) {
+          if (!__all(!col_live || (badv & TAGM) == 0u)) {
+            if (!refetch()) return false;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {           // the same products, same order, on the valid fragments
+              u32x4 v = HB[ks];
+              v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;
+              const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+              for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+                for (int ut = 0; ut < UT; ++ut) acc[gate][ut] = op16<OT>::mfma(wb[gate][ut][ks], bfrag, ks == 0 ? zero4 : acc[gate][ut]);
+            }
+          }
+        }
+        MSTAMP(1);
+        // ---- (2) the next tile-slot's gather goes out now, under this tile's reduction and gate phase (behind the MFMAs: a
+        // vector-memory instruction that waits for queue space blocks the wave's whole instruction stream, MFMAs included -
+        // issuing the eight DMA BETWEEN the MFMAs measured slower, 8.66 against 7.62 us per four-tile step)
+        if (nx_issue) {
+          if (local) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) GRU_MT_DMA(nx_src + (size_t)ks * GRU_MAX_TILES * 1024, nx_dst + (unsigned)ks * 1024u, "nt");
+          } else {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) GRU_MT_DMA(nx_src + (size_t)ks * GRU_MAX_TILES * 1024, nx_dst + (unsigned)ks * 1024u, "sc1");
+          }
+        }
+        // ---- (3) gi of step t + 1 for this tile (always issued: counted instructions 1-3; rows clamp to a live one)
+        gi_dma((tl + 1) & 1, ct, more ? na_n : na, (more ? rb_n : rb_c) - a.row_base);
+        MSTAMP(3);
+        // ---- (4) K-quarter reduction through LDS
+        f32x4* redw = red + parity * RED_STRIDE;
+        parity ^= 1;
+#pragma unroll
+        for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+          for (int ut = 0; ut < UT; ++ut) redw[((q * 3 + gate) * UT + ut) * 64 + lane] = acc[gate][ut];
+        __syncthreads();
+        MSTAMP(4);
+        // ---- (5) gates + state update
+        {
+          const f32x2* rp = (const f32x2*)((const float*)&redw[own_ut * 64 + lane] + own_r0);
+          f32x2 part[3][4];
+#pragma unroll
+          for (int gate = 0; gate < 3; ++gate)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) part[gate][qq] = rp[((qq * 3 + gate) * UT) * 64 * 2];
+          asm volatile("" : "+v"(part[0][0]), "+v"(part[0][1]), "+v"(part[0][2]), "+v"(part[0][3]), "+v"(part[1][0]), "+v"(part[1][1]),
+                            "+v"(part[1][2]), "+v"(part[1][3]), "+v"(part[2][0]), "+v"(part[2][1]), "+v"(part[2][2]), "+v"(part[2][3]));
+          f32x2 gh[3];
+#pragma unroll
+          for (int gate = 0; gate < 3; ++gate) gh[gate] = (part[gate][0] + part[gate][1]) + (part[gate][2] + part[gate][3]);
+          if (col_live) {
+            const f32x2 one = {1.f, 1.f};
+            f32x2 gr, gz, gn;
+            const unsigned* gl = gism + ((tl & 1) * NCT + ct) * 3 * 256 + tid;      // landed before this slot's gather wait
+            const unsigned ur = gl[0], uz = gl[256], un = gl[512];
+            gr = (f32x2){op16<OT>::lo(ur), op16<OT>::hi(ur)};
+            gz = (f32x2){op16<OT>::lo(uz), op16<OT>::hi(uz)};
+            gn = (f32x2){op16<OT>::lo(un), op16<OT>::hi(un)};
+            const f32x2 hp = {hreg[ct][0], hreg[ct][1]}, bh = {bhn[0], bhn[1]};
+            const f32x2 xr = gr + gh[0], xz = gz + gh[1];
+            f32x2 r, z, n;
+            r[0] = sigmoidf_(xr[0]); r[1] = sigmoidf_(xr[1]);
+            z[0] = sigmoidf_(xz[0]); z[1] = sigmoidf_(xz[1]);
+            const f32x2 ghn = gh[2] + bh;
+            const f32x2 xn = gn + r * ghn;
+            n[0] = tanhf_(xn[0]); n[1] = tanhf_(xn[1]);
+            const f32x2 hn = (one - z) * n + z * hp;
+            hreg[ct][0] = hn[0]; hreg[ct][1] = hn[1];
+          }
+        }
+        MSTAMP(5);
+        // ---- (6) publish h_t (counted instruction 4) and relu(h_t) (counted instruction 5): always issued
+        const bool restart = (t + 1 == nstart[ct]);
+        publish(ct, tl & 1, (unsigned)((tl >> 1) & 1), restart, more && sidx[ct] < na_n);
+        {
+          const unsigned hv = op16<OT>::pack2(fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f));
+          const long long o = ((long long)(rbase + sidx[ct]) * HID + ucol) * 2;
+          __builtin_amdgcn_raw_buffer_store_b32(hv, rs_hr, (col_live && a.h_relu_out != nullptr) ? (int)o : OOR, 0, 0);
+        }
+        if (restart) {
+          hreg[ct][0] = 0.f; hreg[ct][1] = 0.f;
+          ++segp[ct];
+          nstart[ct] = segp[ct] < sege[ct] ? a.seg_start[segp[ct]] : 0x7fffffff;
+          asm volatile("" : "+v"(nstart[ct]));
+        }
+        MSTAMP(6);
+      }
+    }
+    na_c = na_n; rb_c = rb_n; na_n = na_2; rb_n = rb_2;
+    return true;
+  };
+  for (int tl = 0; tl < nsteps; ++tl) {
+    if (tfirst[0] >= na_c) break;
+    if (!step(tl)) return;
+  }
+  if (stamp && lane == 0) {
+    for (int i = 0; i < 8; ++i) a.stamps[i] += st_acc[i];
+  }
+#undef MSTAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a prefetch issued by the last step may still be in flight
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+    if (sidx[ct] < a.n_clips) {
+      a.h_state[(size_t)sidx[ct] * HID + ucol] = hreg[ct][0];
+      a.h_state[(size_t)sidx[ct] * HID + ucol + 1] = hreg[ct][1];
+    }
+}
+
 // Returns 0 on success, -1 for unsupported (hid, nct).
 // a.hx must hold [2][G][GROUP_BYTES] bytes (gru_hx_bytes); both buffers are re-armed here (stream ordered):
 // buffer 0 := tag 1 everywhere (first expected tag there is 0), buffer 1 := tag 0 (first expected tag is 1).
@@ -545,6 +942,33 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
   gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, buf_bytes / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);
   const int grid = a.G * P;
   const bool train = a.keep_r != nullptr || a.h_raw_out != nullptr;
+  // two or more clip tiles per group, inference: the software-pipelined multi-tile kernel (PREGO_GRU_NO_MT=1: the classic kernel, A/B)
+  static const bool no_mt = getenv("PREGO_GRU_NO_MT") != nullptr;
+#ifdef GRU_MT_STAMPS
+  const bool stamps_ok = true;
+#else
+  const bool stamps_ok = a.stamps == nullptr;       // PREGO_GRU_STAMPS=1 on a production build: the classic kernel carries the stamps
+#endif
+  if (bf16 && a.gi_bf16 && nct >= 2 && nct <= 4 && !train && !no_mt && stamps_ok) {
+    static const int spec_env = getenv("PREGO_GRU_MT_SPEC") ? atoi(getenv("PREGO_GRU_MT_SPEC")) : -1;     // A/B: tag check inside (1) / before (0) the multiply
+    const bool spec = spec_env >= 0 ? spec_env != 0 : nct >= 3;
+    // reduction buffers + two gather images per wave + the gi rows of two steps
+    const size_t lds = (size_t)2 * 4 * 3 * 2 * 64 * 16 + (size_t)2 * 4 * 8 * 1024 + (size_t)2 * (nct == 2 ? 2 : 4) * 3 * 1024;
+#define LAUNCH_MT(WT, NCT)                                                                                   \
+    do {                                                                                                       \
+      static DeviceOnce once;                                                                                  \
+      once.run([&] {                                                                                           \
+        (void)hipFuncSetAttribute((const void*)gru_recurrence_mt_kernel<WT, 1024, NCT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        (void)hipFuncSetAttribute((const void*)gru_recurrence_mt_kernel<WT, 1024, NCT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      });                                                                                                      \
+      if (spec) gru_recurrence_mt_kernel<WT, 1024, NCT, true><<<grid, 256, lds, s>>>(a);                       \
+      else gru_recurrence_mt_kernel<WT, 1024, NCT, false><<<grid, 256, lds, s>>>(a);                           \
+    } while (0)
+    if (a.f16) { if (nct == 2) LAUNCH_MT(f16_t, 2); else LAUNCH_MT(f16_t, 4); }
+    else { if (nct == 2) LAUNCH_MT(bf16_t, 2); else LAUNCH_MT(bf16_t, 4); }
+#undef LAUNCH_MT
+    return 0;
+  }
 #define LAUNCH(WT, UT, NCT)                                                                            \
   do {                                                                                                 \
     const size_t lds = (size_t)2 * 4 * 3 * UT * 64 * 16;                                               \

@@ -244,7 +244,9 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
 // recurrence cost per time step (us) by live 16-clip tiles per group, measured (scripts/probes/slot_sweep.sh, round 2: 512 clips x
 // 512 frames forced into 128 / 256 / 512 slots = 2.01 / 4.03 / 8.55 us per step): the tiles of a step run one after the other,
 // so the cost is linear in the tile count and the fewest slots that cover the clips win unless a longer slot chain dominates
-static const double kStepCost[5] = {0.0, 2.0, 4.03, 6.3, 8.55};
+// Round 3: two or more tiles run on the software-pipelined kernel (gru_recurrence_mt_kernel): 2.0 / 3.84 / 7.41 us per step for
+// 1 / 2 / 4 tiles (scripts/probes/mt_ab2.sh; the classic kernel: 2.0 / 3.99 / 8.47 on the same device).
+static const double kStepCost[5] = {0.0, 2.0, 3.84, 5.7, 7.41};
 
 // Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
 // backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
@@ -614,7 +616,11 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     const bool prefetch_next = prefetch && t1 < h->t_max;
     ev = ev_begin(h, 1, s);
     if (prefetch_next) HIPCHK(hipEventRecord(h->ev_fork, s));      // fork point: everything before the recurrence launch
-    if (launch_gru_recurrence(h->bf16, H, nct, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct);
+    // clip tiles per group that are still alive at this launch's first step (nact never grows): later launches of a pass whose
+    // slots have thinned out run the kernels for fewer tiles (fewer registers; one tile = the classic kernel)
+    const int live_slots = h->h_nact[t0];
+    const int nct_l = std::max(1, std::min(nct, (((live_slots + h->G - 1) / h->G) + 15) / 16));
+    if (launch_gru_recurrence(h->bf16, H, nct_l, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct_l);
     ev_end(ev, s);
     if (prefetch_next) {
       // X is dead once the layer1 GEMM of this chunk has run: stream the next chunk's features into it while the recurrence
