@@ -39,8 +39,15 @@ if rows:
     p = [r for r in rows if "pack_rows" in r["kernel"]]
     u = [r for r in rows if "gru_recurrence_kernel" in r["kernel"]]
     tot = lambda rs: sum((r["read_bytes_per_launch_corrected_x2"] + r["write_bytes_per_launch"]) * r["launches"] for r in rs) / max(1, sum(r["launches"] for r in rs))
-    json.dump({"source": f"profiles/{tag}_pmc_traffic.csv", "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p),
-               "gru_bytes_per_launch": tot(u)},
+    import subprocess
+    try:
+        git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        git = None
+    json.dump({"source": f"profiles/{tag}_pmc_traffic.csv", "git": git, "dtype": os.environ.get("PREGO_PROFILE_DTYPE", "fp16"),
+               "workload": "bench.py --clips 64 --len-scale 0.25 (64 clips at a quarter of the bench lengths: the same 49 152-row chunks per launch), "
+                           "two separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE)",
+               "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p), "gru_bytes_per_launch": tot(u)},
               open(os.path.join(dst, "traffic_latest.json"), "w"))
     for r in rows[:12]:
         print(r)
