@@ -340,6 +340,12 @@ def main():
             "model_flop_per_frame": FLOP_PER_FRAME, "model_tflops": value * FLOP_PER_FRAME / 1e12,
             "output_sane": ok,
         }
+        try:
+            from prego_amd.build import build_info
+            bi = build_info()
+            line["build"] = {k: bi.get(k) for k in ("build_mode", "built_at", "host", "hipcc", "git_head_at_build", "sources_match_tree")}
+        except Exception as e:       # provenance only: never fails the measurement
+            line["build"] = {"build_mode": f"unknown ({e})"}
         line.update(extra)
         if not args.no_secondary and world == 1 and not synth and args.dtype in ("bf16", "fp16"):
             del rgb, flow, out

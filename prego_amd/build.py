@@ -52,7 +52,50 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+        _write_build_info(len(jobs))
     return LIB
+
+
+def _write_build_info(n_compiled: int):
+    """provenance of the shared library next to it (prego_amd/lib/build_info.json, travels with the .so): where and when it was
+    built, by which compiler, from which tree - `build_info()` / bench.py report it, so a run can tell a library built on its own box
+    from one shipped prebuilt"""
+    import hashlib
+    import json
+    import platform
+    import time
+    h = hashlib.sha256()
+    for f in sources() + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    try:
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        ver = "unknown"
+    try:
+        git = subprocess.run(["git", "-C", os.path.dirname(HERE), "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        git = None
+    info = {"built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": platform.node(), "hipcc": ver, "arch": ARCH,
+            "flags": FLAGS, "sources_sha256": h.hexdigest(), "git_head_at_build": git, "objects_compiled_in_this_call": n_compiled,
+            "sources": len(sources())}
+    json.dump(info, open(os.path.join(LIBDIR, "build_info.json"), "w"), indent=1)
+
+
+def build_info() -> dict:
+    """build_info.json of the library in use + whether it matches the sources in this tree and was built on this host"""
+    import hashlib
+    import json
+    import platform
+    p = os.path.join(LIBDIR, "build_info.json")
+    if not os.path.exists(p):
+        return {"build_mode": "unknown (no build_info.json beside the library)"}
+    info = json.load(open(p))
+    h = hashlib.sha256()
+    for f in sources() + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    info["sources_match_tree"] = h.hexdigest() == info.get("sources_sha256")
+    info["build_mode"] = "built on this host" if info.get("host") == platform.node() else "prebuilt elsewhere, shipped with the tree"
+    return info
 
 
 if __name__ == "__main__":

@@ -263,3 +263,13 @@ def test_feeder_feature_dtype_holds_16_bit_test_features(tmp_path):
         assert tr[0][0].dtype == torch.float32
     with pytest.raises(ValueError):
         StepRecognitionDataset(epic_tent_cfg(root_path=str(tmp_path), video_list_path=vl, feature_dtype="int8"), "test")
+
+
+def test_build_provenance_record_matches_the_tree():
+    """prego_amd/lib/build_info.json (written by the in-tree build, shipped with the .so): bench.py quotes it, so a run can tell a
+    library built on its own box from a prebuilt one, and whether it was built from the sources in this tree"""
+    from prego_amd import build as B
+    B.build(force=False)
+    info = B.build_info()
+    assert info["sources_match_tree"] is True and info["arch"] == "gfx950" and info["build_mode"] in (
+        "built on this host", "prebuilt elsewhere, shipped with the tree")
