@@ -71,37 +71,64 @@ class Evaluate(nn.Module):
         parts = [json.dumps(str(vid)).encode() + b': {"pred": ' + arr(v["pred"]) + b', "gt": ' + arr(v["gt"]) + b"}" for vid, v in output.items()]
         return b"{" + b", ".join(parts) + b"}"
 
-    def _flush(self, model, batch, pred_scores, gt_targets, output, device):
-        if not batch:
-            return
+    def _enqueue(self, model, sub, device):
+        """H2D of one sub-batch on the copy stream + its forward on the compute stream; nothing here waits for the GPU"""
         zero_flow = self._zero_flow(model)
         dev = torch.device(device)
         if dev.type == "cuda":
-            # H2D on a side stream: the copies of this batch run while the previous batch is still computing (the loader's
-            # pin_memory=True makes them true async DMA); the compute stream waits on one event per batch
+            # H2D on a side stream: these copies run while whatever was enqueued before is still computing (the loader's
+            # pin_memory=True makes them true async DMA); the compute stream waits on one event per sub-batch
             if self._copy_stream is None:
                 self._copy_stream = torch.cuda.Stream(dev)
             cur = torch.cuda.current_stream(dev)
             with torch.cuda.stream(self._copy_stream):
-                rgb = [b[0].to(dev, non_blocking=True) for b in batch]
-                flow = None if zero_flow else [b[1].to(dev, non_blocking=True) for b in batch]
+                rgb = [b[0].to(dev, non_blocking=True) for b in sub]
+                flow = None if zero_flow else [b[1].to(dev, non_blocking=True) for b in sub]
+                tgt = [b[2].to(dev, non_blocking=True) for b in sub]
                 ready = torch.cuda.Event()
                 ready.record(self._copy_stream)
             cur.wait_event(ready)
-            for t in rgb + (flow or []):
+            for t in rgb + (flow or []) + tgt:
                 t.record_stream(cur)         # allocated on the copy stream, consumed on the compute stream
         else:
-            rgb = [b[0].to(device) for b in batch]
-            flow = None if zero_flow else [b[1].to(device) for b in batch]
+            rgb = [b[0].to(device) for b in sub]
+            flow = None if zero_flow else [b[1].to(device) for b in sub]
+            tgt = [b[2].to(device) for b in sub]
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        return probs, args, tgt
+
+    def _flush(self, model, batch, pred_scores, gt_targets, output, device):
+        if not batch:
+            return
+        # A batch runs as long as its longest video's recurrence; its H2D copy would sit in front of that.  Large batches go in two
+        # sub-batches ordered by length: the few longest videos first (little to copy, the long critical path), then the bulk of
+        # the bytes, whose copy runs under the first sub-batch's recurrence.  Results return to the loader's order below.
+        order = list(range(len(batch)))
+        parts = [order]
+        frames = [int(b[0].shape[0]) for b in batch]
+        if len(batch) >= 16 and torch.device(device).type == "cuda" and self.cfg.get("eval_split_by_length", True):
+            order.sort(key=lambda i: -frames[i])
+            budget, k, acc = 0.2 * sum(frames), 0, 0
+            while k < len(order) - 1 and acc + frames[order[k]] <= budget:
+                acc += frames[order[k]]
+                k += 1
+            if k >= 1:
+                parts = [order[:k], order[k:]]
+        res = {}
+        for part in parts:
+            probs, args, tgt = self._enqueue(model, [batch[i] for i in part], device)
+            for i, p, a, t in zip(part, probs, args, tgt):
+                res[i] = (p, a, t)
         want_json = self.cfg["eval"] is not None
-        arg_host = torch.cat(args).cpu().numpy() if want_json else None     # ONE device -> host copy for the whole batch's argmax
+        # ONE device -> host copy of the whole batch's argmax, after everything has been enqueued (the first wait for the GPU)
+        arg_host = torch.cat([res[i][1] for i in range(len(batch))]).cpu().numpy() if want_json else None
         o = 0
-        for (r, f, target, vid), p, a in zip(batch, probs, args):
+        for i, (r, f, target, vid) in enumerate(batch):
+            p, a, t = res[i]
             # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
             # once at the end); the reference extends Python lists by one row object per frame (eval.py:46-49)
             pred_scores.append(p)
-            gt_targets.append(target.to(p.device, non_blocking=True))
+            gt_targets.append(t)
             if want_json:
                 n = int(a.shape[0])
                 output[vid] = {"pred": arg_host[o:o + n], "gt": torch.argmax(target, dim=1).numpy()}      # int arrays; text only at the end
