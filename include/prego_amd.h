@@ -285,6 +285,14 @@ int prego_attention_layer_handle_forward(prego_attn_layer* h, int batch, int len
  * [6] = time steps.  Synchronises the device. */
 int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
 
+/* Probes of DESIGN.md section 5c (scripts/probes/xcd_overlap_probe.py), not product entry points: ONLY the recurrence kernel over
+ * n_steps steps of n_slots equal slots dealt to gd groups (0 = all; gi: device 16-bit [n_steps * n_slots][3 H], h_relu: device 16-bit
+ * [rows][H]); and the projection GEMM as a persistent worker that leaves XCDs below xcd_lo at once and claims 256 x 256 tiles from
+ * *counter (device word, zero at launch). */
+int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n_steps, int gd, const void* gi, void* h_relu, prego_stream_t stream);
+int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int xcd_lo,
+                            unsigned* counter, int grid, prego_stream_t stream);
+
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
 int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,

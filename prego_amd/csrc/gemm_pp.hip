@@ -51,7 +51,9 @@ __device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >>
 // x += .), EPI_GELU_BF16 (bf16(gelu(.))), EPI_QKV (head split into Q, K [B,h,N,dh] and V^T [B,h,dh,Npad]).  A lane holds 8
 // consecutive columns of a row, so every epilogue but V^T's is 16-byte vector accesses.
 // OT = operand type tag (common.h: bf16_t or f16_t): selects the MFMA opcode and the 16-bit output conversion only.
-template <int EPI, typename OT = bf16_t>
+// WORKER (probe of DESIGN 5c, prego_debug_gemm_worker): a persistent workgroup that leaves at once on XCDs below epi.xcd_lo and
+// otherwise claims tiles from the atomic counter epi.counter until none is left (m-major order: consecutive tiles share A rows).
+template <int EPI, typename OT = bf16_t, bool WORKER = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
@@ -66,8 +68,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   const int ntiles = ntm * ntn;
   const int nk = K / PBK;
   int idx = blockIdx.x;
-  int tile = pp_xcd_remap(idx, ntiles);
+  int tile = WORKER ? 0 : pp_xcd_remap(idx, ntiles);
   int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
+  __shared__ int s_tile;
+  if constexpr (WORKER) {
+    const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;           // HW_REG_XCC_ID
+    if (xcc < epi.xcd_lo) return;
+  }
 
   // ---- LDS-DMA sources: this lane's two pieces (8 rows x 128 B) of every half-tile.  One buffer resource per operand and
   // tile (base = the tile's first row, num_records = its valid rows: rows past M read as zeros, no clamp), a 32-bit lane
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)tm0 * lda), 0, rows * lda * 2, 0x00020000);
     rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)tn0 * ldb), 0, PBN * ldb * 2, 0x00020000);
   };
-  set_sources(m0, n0);
+  if constexpr (!WORKER) set_sources(m0, n0);
   // slot X of buffer b: A0 = 0, A1 = 1, B0 = 2, B1 = 3
   auto stage_a = [&](int hf, int kt) {
     char* dst = smem + (kt & 1) * PBUF + hf * PHALF + wave * 2048;
@@ -165,6 +172,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);     // A0 B0 B1 A1 of K tile 0
     stage_a(0, 1); stage_b(0, 1); stage_b(1, 1);                            // A0 B0 B1 of K tile 1 (nk >= 2)
   };
+  for (;;) {                                                     // one pass unless WORKER
+  if constexpr (WORKER) {
+    if (tid == 0) s_tile = (int)atomicAdd(epi.counter, 1u);
+    __syncthreads();
+    tile = s_tile;
+    __syncthreads();
+    if (tile >= ntiles) break;
+    m0 = (tile / ntn) * PBM; n0 = (tile % ntn) * PBN;
+    set_sources(m0, n0);
+  }
   prologue();
   PP_WAIT(10);
   bar();
@@ -302,6 +319,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
         acc[x][y][i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
+  if constexpr (!WORKER) break;
+  }
 #ifdef PP_DIAG
   if (wave == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -371,6 +390,26 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     default: PPL(EPI_QKV); break;
   }
 #undef PPL
+  return 0;
+}
+
+// The ping-pong kernel as a persistent worker: `grid` workgroups claim tiles from *counter (zero at launch) in m-major order; those that
+// land on XCDs below xcd_lo leave at once.  out16: 16-bit C of the operand type (the inference projections), else fp32 C.
+int launch_gemm_bf16_pingpong_worker(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
+                                     int K, int xcd_lo, unsigned* counter, int grid, hipStream_t s, bool out16, bool f16) {
+  if (N % PBN || K % PBK || K < 2 * PBK || !bias || !counter) return -1;
+  static DeviceOnce once;
+  once.run([&] {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, bf16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+  });
+  GemmEpi epi{};
+  epi.mode = out16 ? EPI_STORE_BF16 : EPI_STORE; epi.xcd_lo = xcd_lo; epi.counter = counter; epi.f16 = f16 ? 1 : 0;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+  if (!out16) gemm_bf16_nt_pingpong_kernel<EPI_STORE, bf16_t, true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
+  else if (f16) gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, f16_t, true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
+  else gemm_bf16_nt_pingpong_kernel<EPI_STORE_BF16, bf16_t, true><<<grid, 512, 2 * PBUF, s>>>(a, b, bias, C, M, N, K, lda, ldb, ldc, epi);
   return 0;
 }
 

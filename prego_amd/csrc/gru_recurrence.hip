@@ -89,7 +89,24 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   __shared__ int s_place[4];
   if (tid == 0) {
     int gg = blockIdx.x % a.G, ww = blockIdx.x / a.G, loc = 0;
-    if (a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P) {
+    if (a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P && a.Gd > 0 && a.Gd < a.G) {
+      // compacted launch (a.Gd groups; probe of DESIGN 5c): the rendezvous is per XCD - a workgroup on an XCD without a group leaves
+      // at once and is not waited for (another kernel may hold those CUs for the whole launch); the others wait for the 32 of
+      // their own XCD only.  An XCD below Gd that does not collect exactly P workgroups ends the launch with the abort word.
+      const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+      if (xcc >= a.Gd) loc = -2;
+      else {
+        const unsigned ticket = __hip_atomic_fetch_add(a.sync + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(a.sync + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
+          if (++spins > SPIN_LIMIT) { ok = false; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok || ticket >= (unsigned)P) { __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); loc = -1; }
+        else { loc = 1; gg = xcc; ww = (int)ticket; }
+      }
+    } else if (a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P) {
       const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;          // HW_REG_XCC_ID[2:0]
       const unsigned ticket = __hip_atomic_fetch_add(a.sync + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(a.sync + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -119,6 +136,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   // The slots are sorted by load, so every group gets a cross-section of the loads and its live columns thin out over the
   // whole run (instead of group 0 holding the 16 longest slots to the end): the per-step gather below skips dead columns, so
   // the 1 MB-per-step L2 burst of an XCD - what bounds the hand-off - shrinks with the number of live clips.
+  // a.Gd (0 = a.G): groups the slots are dealt to in this launch.  Fewer than a.G packs the live slots into the first Gd groups
+  // (XCDs 0 .. Gd - 1 under the verified placement): the other XCDs' workgroups leave at once (overlap probe)
+  const int gd = (a.Gd > 0 && a.Gd < a.G) ? a.Gd : a.G;
+  if (g >= gd) return;
   if (g >= a.n_clips) return;                 // group without slots (its most loaded slot is slot g)
   {                                           // group whose slots have all ended before this launch (nact never grows)
     typedef const __attribute__((address_space(4))) int* cint_p0;
@@ -158,8 +179,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   for (int e = 0; e < OWN_R; ++e) bhn[e] = a.b_hn[ucol + e];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
-    sidx[ct] = ct * 16 * a.G + l15 * a.G + g;
-    tfirst[ct] = ct * 16 * a.G + g;
+    sidx[ct] = ct * 16 * gd + l15 * gd + g;
+    tfirst[ct] = ct * 16 * gd + g;
 #pragma unroll
     for (int e = 0; e < OWN_R; ++e) hreg[ct][e] = (sidx[ct] < a.n_clips) ? a.h_state[(size_t)sidx[ct] * HID + ucol + e] : 0.f;
   }

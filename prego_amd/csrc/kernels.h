@@ -52,6 +52,7 @@ struct GruArgs {
   unsigned long long* stamps;  // debug: per-phase cycle sums of block 0 / wave 0 (nullable)
   int gi_bf16;                 // gi rows are bf16 (inference path with bf16 intermediates)
   int f16;                     // 16-bit operands / intermediates are IEEE fp16 instead of bf16 (launch_gru_recurrence picks the instantiation)
+  int Gd;                      // groups the slots are dealt to (0 = G); one-tile kernel only
 };
 
 // persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward
@@ -91,6 +92,7 @@ struct GemmEpi {
   // window is left for the caller) with the learned positional row pe[t] added: x[b, t] = W_enc f + b_enc + pe[t]
   const float* pe;
   int f16;                     // operands (and every 16-bit output) are IEEE fp16 instead of bf16
+  int xcd_lo; unsigned* counter;   // WORKER instantiation (probe): XCDs below xcd_lo leave at once; tiles are claimed from *counter
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
@@ -111,6 +113,8 @@ int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void*
                                    int M, int N, int K, bool out_bf16, hipStream_t s, bool f16 = false);
 int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
                                   int K, GemmEpi epi, hipStream_t s);
+int launch_gemm_bf16_pingpong_worker(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
+                                     int K, int xcd_lo, unsigned* counter, int grid, hipStream_t s, bool out16 = false, bool f16 = false);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,

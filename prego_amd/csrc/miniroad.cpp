@@ -109,12 +109,15 @@ struct prego_miniroad {
   // recurrence workgroup on every CU, so it runs on a handle-owned side stream, forked from and joined to the caller's stream
   // by events (the caller still sees one in-order stream)
   hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; bool pack_prefetch = true;
+  // layer1 GEMM of chunk c + 1 on the XCDs the (compacted) recurrence of chunk c does not hold (off: PREGO_NO_XCD_OVERLAP=1):
+  // one tile counter per chunk, zeroed once per forward
+  unsigned* tile_ctr = nullptr; bool xcd_overlap = false;
   int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
   // timing
   bool timing = false;
   std::vector<EventPair> ev_pool;
-  std::vector<int> ev_kind;     // 0 gemm, 1 gru, 2 pack
+  std::vector<int> ev_kind;     // 0 gemm (static launches), 1 gru, 2 pack, 3 overlapped layer1 worker
   size_t ev_used = 0;
   double gemm_flop = 0, pack_bytes = 0;
 };
@@ -187,6 +190,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
+  A((void**)&h->tile_ctr, 4096 * sizeof(unsigned));
+  h->xcd_overlap = getenv("PREGO_NO_XCD_OVERLAP") == nullptr;       // A/B knob: PREGO_NO_XCD_OVERLAP=1 = the serial pass of round 2
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
@@ -201,7 +206,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
 extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
-                  h->flags, h->h_state, h->stamps, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
+                  h->flags, h->h_state, h->stamps, h->tile_ctr, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
                   h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -581,6 +586,9 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   };
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
+  bool l1_done = false;           // Y already holds layer1 of this chunk (XCD overlap: the worker GEMM ran under the previous recurrence)
+  const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8;
+  if (overlap_ok) HIPCHK(hipMemsetAsync(h->tile_ctr, 0, 4096 * sizeof(unsigned), s));
   // every exit path after a fork joins the side stream: an error return while the next chunk's pack is still writing X / RM
   // would leave the caller's stream unordered against it (the next forward on this handle could race with that pack)
   struct SideJoin {
@@ -596,14 +604,18 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     if (!packed) pack_chunk(t0, t1, s, ci);
     packed = false;
 
-    ev = ev_begin(h, 0, s);
-    proj(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx);
-    ev_end(ev, s);
+    if (!l1_done) {
+      ev = ev_begin(h, 0, s);
+      proj(X, kx, h->w1, din, h->b1, Y, E, rows, E, kx);
+      ev_end(ev, s);
+      if (h->timing) h->gemm_flop += 2.0 * rows * (double)E * kx;
+    }
+    l1_done = false;
     launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16);
     ev = ev_begin(h, 0, s);
     proj(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E);
     ev_end(ev, s);
-    if (h->timing) h->gemm_flop += 2.0 * rows * ((double)E * kx + 3.0 * H * E);
+    if (h->timing) h->gemm_flop += 2.0 * rows * 3.0 * H * E;
 
     GruArgs ga;
     ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = i16 ? 1 : 0; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
@@ -613,7 +625,23 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
+    {
+      // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
+      // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)
+      static const bool compact = getenv("PREGO_GRU_COMPACT") != nullptr;
+      const int live0 = h->h_nact[t0];
+      ga.Gd = (compact && live0 <= 16 * h->G) ? std::max(1, std::min(h->G, (live0 + 15) / 16)) : 0;
+    }
     const bool prefetch_next = prefetch && t1 < h->t_max;
+    // XCD overlap: when the live slots fit fewer than eight groups, this launch is compacted onto XCDs 0 .. Gd - 1
+    // and the NEXT chunk's layer1 GEMM runs as a persistent worker on the side stream behind its pack: its workgroups can only be
+    // dispatched where no recurrence workgroup is resident, i.e. on the free XCDs, until this launch ends; the tile queue balances
+    bool ov = false;
+    if (overlap_ok && prefetch_next && ci + 1 < 4096) {
+      const int live0 = h->h_nact[t0];
+      const int gd0 = (live0 + 15) / 16;
+      if (live0 <= 16 * h->G && gd0 < h->G && h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1] >= 4096) { ov = true; ga.Gd = std::max(1, gd0); }
+    }
     ev = ev_begin(h, 1, s);
     if (prefetch_next) HIPCHK(hipEventRecord(h->ev_fork, s));      // fork point: everything before the recurrence launch
     // clip tiles per group that are still alive at this launch's first step (nact never grows): later launches of a pass whose
@@ -629,6 +657,13 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
       pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
       side_join.pending = true;
+      if (ov) {
+        const int rows_n = h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1];
+        EventPair* evw = ev_begin(h, 3, h->side);       // kind 3: overlapped worker (its span includes waiting for the recurrence's XCDs)
+        if (launch_gemm_bf16_pingpong_worker(X, kx, h->w1, din, h->b1, Y, E, rows_n, E, kx, 0, h->tile_ctr + (ci + 1), 256, h->side, true, h->f16) == 0)
+          l1_done = true;
+        ev_end(evw, h->side);
+      }
       HIPCHK(hipEventRecord(h->ev_join, h->side));
       packed = true;
     }
@@ -709,8 +744,8 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
                                           int64_t* pack_launches, double* pack_bytes) {
   HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
-  double ms[3] = {0, 0, 0};
-  int64_t n[3] = {0, 0, 0};
+  double ms[4] = {0, 0, 0, 0};
+  int64_t n[4] = {0, 0, 0, 0};
   for (size_t i = 0; i < h->ev_used; ++i) {
     HIPCHK(hipEventSynchronize(h->ev_pool[i].b));
     float t = 0;
@@ -729,6 +764,34 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
   h->ev_used = 0;
   h->gemm_flop = 0;
   h->pack_bytes = 0;
+  return PREGO_OK;
+}
+
+// debug / probe: ONLY the recurrence kernel, one launch over n_steps steps of n_slots equally long slots dealt to `gd` groups
+// (0 = all), on caller-supplied gi rows [n_steps * n_slots][3H] (16-bit, the handle's operand type) -> relu(h) [rows][H].
+// scripts/probes/xcd_overlap_probe.py runs it beside an XCD-filtered GEMM worker.
+extern "C" int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n_steps, int gd, const void* gi, void* h_relu,
+                                           prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h || !gi || !h_relu) return fail(PREGO_EINVAL, "NULL argument");
+  if (!h->have_weights || !h->bf16) return fail(PREGO_EINVAL, "debug recurrence: a bf16 / fp16 handle with weights");
+  if (n_slots < 1 || n_slots > 16 * h->G || n_steps < 1) return fail(PREGO_EINVAL, "debug recurrence: %d slots, %d steps", n_slots, n_steps);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int32_t> lens((size_t)n_slots, n_steps);
+  int rc = build_plan(h, n_slots, lens.data(), true);
+  if (rc) return rc;
+  std::vector<const void*> tab((size_t)4 * max_clips_of(h), nullptr);
+  rc = stage_tables(h, tab.data(), tab.size(), s);
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)n_slots * h->hid * 4, s));
+  GruArgs ga{};
+  ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = gi; ga.gi_bf16 = 1; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = h_relu; ga.h_raw_out = nullptr;
+  ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
+  ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = 0; ga.t1 = n_steps; ga.row_base = 0;
+  ga.n_clips = n_slots; ga.G = h->G; ga.Gd = gd; ga.seg_off = nullptr; ga.seg_start = nullptr; ga.stamps = nullptr;
+  ga.sync = h->no_local ? nullptr : h->flags;
+  if (launch_gru_recurrence(true, h->hid, 1, ga, s)) return fail(PREGO_EINVAL, "debug recurrence: launch failed");
+  HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
 
@@ -1053,6 +1116,17 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
     return fail(PREGO_EINVAL, "adamw: bad step %lld", (long long)step);
   launch_add_vec(params[6], params[7], h->bias2, (int)(3 * H), (int)(2 * H), s);      // r,z rows: b_ih + b_hh ; n rows: b_ih
   HIPCHK(hipMemcpyAsync(h->b_hn, params[7] + 2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// probe: the ping-pong GEMM as a persistent worker that only runs on XCDs >= xcd_lo and claims tiles from `counter`
+// (device word, zeroed by the caller in stream order); grid = workgroups launched (256 = one per CU)
+extern "C" int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int xcd_lo,
+                                       unsigned* counter, int grid, prego_stream_t stream) {
+  if (!A || !B || !bias || !C || !counter || M <= 0 || grid <= 0) return fail(PREGO_EINVAL, "debug gemm worker: bad arguments");
+  if (launch_gemm_bf16_pingpong_worker(A, K, B, K, bias, C, N, M, N, K, xcd_lo, counter, grid, (hipStream_t)stream))
+    return fail(PREGO_EINVAL, "debug gemm worker: unsupported shape");
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
