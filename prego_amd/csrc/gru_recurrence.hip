@@ -89,7 +89,12 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   __shared__ int s_place[4];
   if (tid == 0) {
     int gg = blockIdx.x % a.G, ww = blockIdx.x / a.G, loc = 0;
-    if (a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P && a.Gd > 0 && a.Gd < a.G) {
+    // word 20 of the rendezvous array survives the per-launch re-arm: 1 = an earlier full-width launch of this handle verified that
+    // every XCD receives exactly P workgroups (group := XCD).  Only then may a launch be compacted; otherwise it runs full width
+    const bool compact_ok = a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P && a.Gd > 0 && a.Gd < a.G &&
+                            __hip_atomic_load(a.sync + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
+    s_place[3] = compact_ok ? 1 : 0;
+    if (compact_ok) {
       // compacted launch (a.Gd groups; probe of DESIGN 5c): the rendezvous is per XCD - a workgroup on an XCD without a group leaves
       // at once and is not waited for (another kernel may hold those CUs for the whole launch); the others wait for the 32 of
       // their own XCD only.  An XCD below Gd that does not collect exactly P workgroups ends the launch with the abort word.
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         for (int i = 0; i < 8; ++i)
           if (__hip_atomic_load(a.sync + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)P) loc = 0;
         if (loc) { gg = xcc; ww = (int)ticket; }
+        if (blockIdx.x == 0) __hip_atomic_store(a.sync + 20, loc ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     s_place[0] = gg; s_place[1] = ww; s_place[2] = loc;
@@ -130,6 +136,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   const int g = __builtin_amdgcn_readfirstlane(s_place[0]);   // group
   const int w = __builtin_amdgcn_readfirstlane(s_place[1]);   // member of the group
   const int place = __builtin_amdgcn_readfirstlane(s_place[2]);
+  const bool compacted = __builtin_amdgcn_readfirstlane(s_place[3]) != 0;
   if (place < 0) return;                      // rendezvous timed out (abort word set)
   const bool local = place == 1;              // whole group on one XCD, verified
   // Slots are dealt to the groups INTERLEAVED: slot s of a layer of 16 G slots goes to group s % G, column s / G of its tile.
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   // the 1 MB-per-step L2 burst of an XCD - what bounds the hand-off - shrinks with the number of live clips.
   // a.Gd (0 = a.G): groups the slots are dealt to in this launch.  Fewer than a.G packs the live slots into the first Gd groups
   // (XCDs 0 .. Gd - 1 under the verified placement): the other XCDs' workgroups leave at once (overlap probe)
-  const int gd = (a.Gd > 0 && a.Gd < a.G) ? a.Gd : a.G;
+  const int gd = compacted ? a.Gd : a.G;
   if (g >= gd) return;
   if (g >= a.n_clips) return;                 // group without slots (its most loaded slot is slot g)
   {                                           // group whose slots have all ended before this launch (nact never grows)
