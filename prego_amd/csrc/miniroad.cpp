@@ -640,7 +640,20 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     if (overlap_ok && prefetch_next && ci + 1 < 4096) {
       const int live0 = h->h_nact[t0];
       const int gd0 = (live0 + 15) / 16;
-      if (live0 <= 16 * h->G && gd0 < h->G && h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1] >= 4096) { ov = true; ga.Gd = std::max(1, gd0); }
+      const int rows_n = h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1];
+      if (live0 <= 16 * h->G && gd0 < h->G && rows_n >= 4096) {
+        // how many groups?  The fewest (gd0) frees the most XCDs; more groups mean fewer columns per group and a faster step
+        // (1.67 us + 0.0102 us per live column of the fullest group).  Take the widest spread that still leaves the worker enough
+        // XCD-time for the whole layer1 GEMM of the next chunk (13 ns per row on the whole chip, probe: >= proportional on a part)
+        const double l1_ms = rows_n * 13.0e-6;
+        int pick = std::max(1, gd0);
+        static const bool wide = getenv("PREGO_OVERLAP_NARROW") == nullptr;     // A/B knob: always the fewest groups (same device: 127.2 vs 125.5 ms)
+        for (int g2 = h->G - 1; wide && g2 > pick; --g2) {
+          const double rec_ms = (t1 - t0) * (1.67 + 0.0102 * ((live0 + g2 - 1) / g2)) * 1e-3;
+          if (l1_ms * h->G / (h->G - g2) <= 0.85 * rec_ms) { pick = g2; break; }
+        }
+        ov = true; ga.Gd = pick;
+      }
     }
     ev = ev_begin(h, 1, s);
     if (prefetch_next) HIPCHK(hipEventRecord(h->ev_fork, s));      // fork point: everything before the recurrence launch
