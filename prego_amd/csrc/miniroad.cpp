@@ -641,7 +641,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       const int live0 = h->h_nact[t0];
       const int gd0 = (live0 + 15) / 16;
       const int rows_n = h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1];
-      if (live0 <= 16 * h->G && gd0 < h->G && rows_n >= 4096) {
+      static const int max_gd = getenv("PREGO_OVERLAP_MAX_GD") ? atoi(getenv("PREGO_OVERLAP_MAX_GD")) : 7;     // A/B knob
+      if (live0 <= 16 * h->G && gd0 < h->G && gd0 <= max_gd && rows_n >= 4096) {
         // how many groups?  The fewest (gd0) frees the most XCDs; more groups mean fewer columns per group and a faster step
         // (1.67 us + 0.0102 us per live column of the fullest group).  Take the widest spread that still leaves the worker enough
         // XCD-time for the whole layer1 GEMM of the next chunk (13 ns per row on the whole chip, probe: >= proportional on a part)
