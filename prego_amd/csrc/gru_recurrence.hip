@@ -977,7 +977,10 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
 #else
   const bool stamps_ok = a.stamps == nullptr;       // PREGO_GRU_STAMPS=1 on a production build: the classic kernel carries the stamps
 #endif
-  if (bf16 && a.gi_bf16 && nct >= 2 && nct <= 4 && !train && !no_mt && stamps_ok) {
+  // the pipelined kernel stores relu(h) through a buffer resource (32-bit byte offsets): launches over more than 2^31 bytes of rows
+  // (a caller-chosen chunk of a million rows) stay on the classic kernel and its 64-bit addressing
+  const bool rows_ok = a.rows > 0 && (long long)a.rows * hid * 2 < (1ll << 31) - 65536;
+  if (bf16 && a.gi_bf16 && nct >= 2 && nct <= 4 && !train && !no_mt && stamps_ok && rows_ok) {
     static const int spec_env = getenv("PREGO_GRU_MT_SPEC") ? atoi(getenv("PREGO_GRU_MT_SPEC")) : -1;     // A/B: tag check inside (1) / before (0) the multiply
     const bool spec = spec_env >= 0 ? spec_env != 0 : nct >= 3;
     // reduction buffers + two gather images per wave + the gi rows of two steps

@@ -53,6 +53,7 @@ struct GruArgs {
   int gi_bf16;                 // gi rows are bf16 (inference path with bf16 intermediates)
   int f16;                     // 16-bit operands / intermediates are IEEE fp16 instead of bf16 (launch_gru_recurrence picks the instantiation)
   int Gd;                      // groups the slots are dealt to (0 = G); one-tile kernel only
+  int rows;                    // packed rows this launch covers (rowoff[t1] - row_base); 0 = unknown
 };
 
 // persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward

@@ -617,10 +617,10 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ev_end(ev, s);
     if (h->timing) h->gemm_flop += 2.0 * rows * 3.0 * H * E;
 
-    GruArgs ga;
+    GruArgs ga{};
     ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = i16 ? 1 : 0; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = HRAW;
     ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
-    ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base;
+    ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = t0; ga.t1 = t1; ga.row_base = base; ga.rows = rows;
     ga.keep_r = KR; ga.keep_z = KZ; ga.keep_n = KN; ga.keep_ghn = KG;
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
@@ -801,7 +801,7 @@ extern "C" int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n
   GruArgs ga{};
   ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = gi; ga.gi_bf16 = 1; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = h_relu; ga.h_raw_out = nullptr;
   ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
-  ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = 0; ga.t1 = n_steps; ga.row_base = 0;
+  ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = 0; ga.t1 = n_steps; ga.row_base = 0; ga.rows = n_slots * n_steps;
   ga.n_clips = n_slots; ga.G = h->G; ga.Gd = gd; ga.seg_off = nullptr; ga.seg_start = nullptr; ga.stamps = nullptr;
   ga.sync = h->no_local ? nullptr : h->flags;
   if (launch_gru_recurrence(true, h->hid, 1, ga, s)) return fail(PREGO_EINVAL, "debug recurrence: launch failed");

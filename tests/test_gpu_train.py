@@ -300,3 +300,49 @@ def test_amp_flag_runs_the_reference_gradscaler_protocol():
     assert abs(res[True][0] - res[False][0]) < 1e-6
     for k in res[True][1]:
         assert np.abs(res[True][1][k] - res[False][1][k]).max() < 2e-6, k
+
+
+@pytest.mark.parametrize("compress", [None, "bf16"])
+def test_data_parallel_bucket_path_on_one_gpu_with_a_stand_in_collective(monkeypatch, compress):
+    """The data-parallel gradient path on ONE GPU: torch.distributed is made to report a world of 2 whose all_reduce doubles the
+    tensor (two identical ranks), so after the mean the gradients must equal the single-process ones.  Exercises what the gloo tests
+    cannot: prego_miniroad_backward_events (events recorded inside the backward), the three sub-buckets reduced on a side stream
+    behind those events, and the bf16 wire format."""
+    import torch.distributed as dist
+    from prego_amd.trainer import _allreduce_grads
+    cfg = assembly101_cfg(dropout=0.0, compute_dtype="bf16", grad_compress=compress)
+    sd = W.miniroad_state_dict(cfg, 20)
+    rgb = torch.from_numpy(W.tsn_features((3, 16, 2048), 20, "dp.rgb")).cuda()
+    flow = torch.from_numpy(W.tsn_features((3, 16, 2048), 20, "dp.flow")).cuda()
+    tgt = torch.from_numpy(_targets(3, 16, 86, 20, "dp.tgt")).cuda()
+
+    def grads(model, crit):
+        model.train()
+        loss = crit(model(rgb, flow), tgt)
+        loss.backward()
+        _allreduce_grads(model)
+        torch.cuda.synchronize()
+        model.engine(train=True).check()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+    model, crit = _build(cfg, sd)
+    ref = grads(model, crit)                                   # world 1: no events, no reduce
+    calls = []
+    monkeypatch.setattr(dist, "is_available", lambda: True)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda *a, **k: 0)
+    monkeypatch.setattr(dist, "all_reduce", lambda t, op=None, **k: (calls.append((t.numel(), t.dtype)), t.mul_(2))[1])
+    model2, crit2 = _build(cfg, sd)
+    got = grads(model2, crit2)
+    eng = model2.engine(train=True)
+    assert eng._grad_events is not None and len(eng._grad_bounds) == 3           # events were armed and recorded by the backward
+    assert all(e is None or e.query() for e in eng._grad_events)
+    assert len(calls) == 3 and all(dt == (torch.bfloat16 if compress else torch.float32) for _, dt in calls)
+    assert sum(n for n, _ in calls) == eng._grad_flat.numel()
+    for k in ref:
+        if compress is None:
+            assert torch.equal(got[k], ref[k]), k              # x 2 / 2 is exact
+        else:
+            err = (got[k] - ref[k]).abs().max().item()
+            assert err <= 2.0 ** -7 * ref[k].abs().max().item() + 1e-12, (k, err)
