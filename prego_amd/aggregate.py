@@ -40,9 +40,12 @@ def aggregate(data: dict, output_path: str | None = None, window_size: int = 200
     return out
 
 
-def aggregate_device(preds: dict, gts: dict, output_path: str | None = None, window_size: int = 200, n_classes: int = 128) -> dict:
+def aggregate_device(preds: dict, gts: dict, output_path: str | None = None, window_size: int = 200, n_classes: int | None = None) -> dict:
     """preds: {vid: int32 CUDA tensor [T]} (per-frame argmax on the device); gts: {vid: sequence of per-frame ground-truth ids}.
-    Same result dict as `aggregate` / utils/aggregate.py:46-90."""
+    n_classes: the model's num_classes (ids outside [0, n_classes) are an error, as np.bincount's negative ids are in
+    utils/aggregate.py:60); None = 128, the kernel's limit.  Same result dict as `aggregate` / utils/aggregate.py:46-90."""
+    if n_classes is None:
+        n_classes = 128
     import ctypes as C
 
     import torch

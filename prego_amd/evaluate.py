@@ -203,5 +203,13 @@ class Evaluate(nn.Module):
             logger.info(f"Processed {num_frames} frames in {time_taken:.1f} seconds ({self.last_fps:.1f} FPS)")
         return result["mean_AP"]
 
+    def aggregate_last(self, output_path=None, window_size: int = 200):
+        """utils/aggregate.py:46-90 on the per-frame argmax the last eval left in HBM (`last_device_argmax`), with this config's
+        number of classes; ground truth from the output JSON's "gt" lists"""
+        from .aggregate import aggregate_device
+        js = json.load(open(os.path.join(self.output_dir, "output_miniROAD.json")))
+        return aggregate_device(self.last_device_argmax, {k: v["gt"] for k, v in js.items()}, output_path, window_size,
+                                n_classes=len(self.all_class_names))
+
     def forward(self, model, dataloader, logger, device):
         return self.eval(model, dataloader, logger, device)

@@ -68,6 +68,7 @@ def test_feeder_to_evaluate_to_json(tmp_path, dtype):
     # f2 on the same run: device vote over the int32 argmax still in HBM == host aggregate over the JSON
     dev = aggregate_device(ev.last_device_argmax, {k: v["gt"] for k, v in js.items()}, n_classes=12)
     assert dev == aggregate(js)
+    assert ev.aggregate_last() == dev                              # the evaluator's own helper passes the config's class count
 
 
 def test_window_vote_reproduces_reference_known_answer_g8():
