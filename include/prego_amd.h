@@ -279,6 +279,17 @@ int prego_attention_layer_set_weights(prego_attn_layer* h, const float* wq, cons
 size_t prego_attention_layer_handle_workspace_bytes(const prego_attn_layer* h, int batch, int len);
 int prego_attention_layer_handle_forward(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
                                          void* workspace, size_t workspace_bytes, prego_stream_t stream);
+/* The layer under autograd (attn.py:151-170 inside loss.backward(), trainer/train.py:20-24): forward_train is handle_forward that
+ * keeps x, q, k, v, the attention output (bf16) and the row log-sum-exp in `workspace`; backward reads them from the SAME
+ * workspace and overwrites grads[0..7] (fp32, set_weights order: wq, bq, wk, bk, wv, bv, wo, bo) and, if not NULL,
+ * dx [batch, len, d_model] (queries = keys = values = x: the three input gradients summed).  bf16 handles only; the
+ * attention_dropout of attn.py:39,49 is not modelled (p = 0, the state the reference's modules are in under .eval()). */
+size_t prego_attention_layer_train_workspace_bytes(const prego_attn_layer* h, int batch, int len);
+int prego_attention_layer_forward_train(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
+                                        void* workspace, size_t workspace_bytes, prego_stream_t stream);
+int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int causal, const float* dout, float* dx,
+                                   float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
+                                   prego_stream_t stream);
 
 /* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
  * recurrence kernel: out8[0..4] = rest of gather + mfma, step top -> first gather segment valid, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;

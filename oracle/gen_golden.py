@@ -249,6 +249,27 @@ def g6():
         print("g6", L, "done")
 
 
+def g6b():
+    """The same layer under autograd (attn.py:151-170 inside a backward pass): loss = sum(layer(x, x, x) * G) for a seeded G,
+    gradients of x and of the eight projection parameters: norms + sampled entries, causal and unmasked, two head dims."""
+    from model.transformer_models.attn import AttentionLayer, FullAttention
+    for d, H, B, L, mask in ((512, 8, 2, 192, True), (2048, 8, 1, 128, True), (1024, 8, 2, 100, False)):
+        sd = W.attention_layer_state_dict(d, seed=20)
+        layer = AttentionLayer(FullAttention(mask_flag=mask, attention_dropout=0.0), d, H).eval()
+        _load(layer, sd)
+        x = torch.from_numpy(W.normal((B, L, d), 20, f"g6b.x.{d}.{L}")).requires_grad_(True)
+        G = torch.from_numpy(W.normal((B, L, d), 20, f"g6b.g.{d}.{L}"))
+        out = layer(x, x, x, None)
+        (out * G).sum().backward()
+        save = {"out_norm": np.float64(np.linalg.norm(out.detach().numpy().astype(np.float64)))}
+        _grad_summary(layer, save)
+        g = x.grad.numpy().reshape(-1)
+        idx = np.linspace(0, g.size - 1, 512).astype(np.int64)
+        save.update({"norm.x": np.float64(np.linalg.norm(g.astype(np.float64))), "idx.x": idx, "val.x": g[idx].copy()})
+        np.savez_compressed(os.path.join(OUT, f"g6b_attention_grads_d{d}_L{L}_{'causal' if mask else 'full'}.npz"), **save)
+        print("g6b", d, L, mask, {k: float(v) for k, v in save.items() if k.startswith("norm.")})
+
+
 class _SynthEval(torch.utils.data.Dataset):
     def __init__(self, lens, C, seed):
         self.items = []
@@ -437,7 +458,7 @@ def g9():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-GROUPS = {"g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g6": g6, "g7": g7, "g8": g8, "g9": g9}
+GROUPS = {"g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

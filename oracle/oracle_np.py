@@ -251,6 +251,34 @@ def causal_attention_layer(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, mask_flag=T
     return linear(o, wo, bo)
 
 
+def causal_attention_layer_grads(x, wq, bq, wk, bk, wv, bv, wo, bo, heads, dout, mask_flag=True):
+    """d/d(x, parameters) of sum(causal_attention_layer(...) * dout): what autograd computes through attn.py:151-170
+    (nn.Linear projections, attn.py:41-52 scores / mask / softmax / A.V).  Returns (dx, [dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo])."""
+    B, L, D = x.shape
+    E = D // heads
+    x2 = x.reshape(B * L, D)
+    q = linear(x, wq, bq).reshape(B, L, heads, E)
+    k = linear(x, wk, bk).reshape(B, L, heads, E)
+    v = linear(x, wv, bv).reshape(B, L, heads, E)
+    s = np.einsum("blhe,bshe->bhls", q, k)
+    if mask_flag:
+        s = np.where(np.triu(np.ones((L, L), dtype=bool), 1), -np.inf, s)
+    sc = 1.0 / math.sqrt(E)
+    a = softmax(s * sc)
+    o = np.einsum("bhls,bshd->blhd", a, v).reshape(B * L, D)
+    dy = dout.reshape(B * L, D)
+    dwo, dbo = dy.T @ o, dy.sum(0)
+    do = (dy @ wo).reshape(B, L, heads, E)
+    dv = np.einsum("bhls,blhd->bshd", a, do)
+    da = np.einsum("blhd,bshd->bhls", do, v)
+    ds = a * (da - (da * a).sum(-1, keepdims=True)) * sc          # softmax backward; masked entries have a = 0
+    dq = np.einsum("bhls,bshe->blhe", ds, k).reshape(B * L, D)
+    dk = np.einsum("bhls,blhe->bshe", ds, q).reshape(B * L, D)
+    dv = dv.reshape(B * L, D)
+    dx = (dq @ wq + dk @ wk + dv @ wv).reshape(B, L, D)
+    return dx, [dq.T @ x2, dq.sum(0), dk.T @ x2, dk.sum(0), dv.T @ x2, dv.sum(0), dwo, dbo]
+
+
 def feedforward(x, w1, b1, w2, b2):
     """FeedForward (Transformer.py:35-47), dropout off."""
     return linear(gelu_erf(linear(x, w1, b1)), w2, b2)

@@ -29,7 +29,8 @@ SYMBOLS = [
     "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
-    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
+    "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward",
+    "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events",
     "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype", "prego_debug_recurrence_only", "prego_debug_gemm_worker",
 ]
@@ -118,6 +119,10 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_handle_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_handle_workspace_bytes.restype = sz
     lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.prego_attention_layer_train_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.prego_attention_layer_train_workspace_bytes.restype = sz
+    lib.prego_attention_layer_forward_train.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.prego_attention_layer_backward.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]
     lib.prego_debug_attention_bwd.argtypes = [i32] * 5 + [vp] * 7 + [vp]
     lib.prego_debug_attention_fwd.argtypes = [i32] * 6 + [vp] * 5 + [vp]
     lib.prego_debug_recurrence_only.argtypes = [vp, i32, i32, i32, vp, vp, vp]

@@ -140,6 +140,7 @@ void launch_gather_dlogits(bool bf16, const float* const* dl_ptrs, const int* ro
 void launch_transpose_convert(bool in_bf16, bool out_bf16, const void* src, int M, int N, int ld_src, void* dst, int Mpad,
                               hipStream_t s);
 void launch_colsum(const float* src, int M, int N, float* part, float* out, hipStream_t s);
+void launch_colsum_bf16(const void* src, int M, int N, float* part, float* out, hipStream_t s);
 void launch_colsum_stage2(const float* part, int nb, int N, float* out, hipStream_t s);
 void launch_gru_bwd_step(bool bf16, int t, int na, int na_next, int row_t, int row_tm1, int H, const float* dHout,
                          const float* carry_in, const float* dhpart, const float* R, const float* Z, const float* Nn,

@@ -119,12 +119,15 @@ __global__ void transpose_convert_kernel(const InT* __restrict__ src, int M, int
 
 // column sums, stage 1: block b sums rows [b*RB, (b+1)*RB) -> part[b][N]; stage 2 sums the partials in order.
 #define COLSUM_RB 64
-__global__ void colsum_stage1_kernel(const float* __restrict__ src, int M, int N, float* __restrict__ part) {
+template <typename InT>
+__global__ void colsum_stage1_kernel(const InT* __restrict__ src, int M, int N, float* __restrict__ part) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int m0 = blockIdx.y * COLSUM_RB;
   float s = 0.f;
-  for (int m = m0; m < m0 + COLSUM_RB && m < M; ++m) s += src[(size_t)m * N + n];
+  for (int m = m0; m < m0 + COLSUM_RB && m < M; ++m) {
+    if constexpr (sizeof(InT) == 2) s += bf2f(src[(size_t)m * N + n]); else s += src[(size_t)m * N + n];
+  }
   part[(size_t)blockIdx.y * N + n] = s;
 }
 // 64 columns x 16 row slices per workgroup: slice y sums its contiguous share of the partials in order, the 16 slice sums are
@@ -310,7 +313,14 @@ void launch_transpose_convert(bool in_bf16, bool out_bf16, const void* src, int 
 void launch_colsum(const float* src, int M, int N, float* part, float* out, hipStream_t s) {
   const int nb = (M + COLSUM_RB - 1) / COLSUM_RB;
   dim3 g1((N + 255) / 256, nb);
-  colsum_stage1_kernel<<<g1, 256, 0, s>>>(src, M, N, part);
+  colsum_stage1_kernel<float><<<g1, 256, 0, s>>>(src, M, N, part);
+  colsum_stage2_kernel<<<(N + 63) / 64, 1024, 0, s>>>(part, nb, N, out);
+}
+// the same over bf16 rows (fp32 accumulation)
+void launch_colsum_bf16(const void* src, int M, int N, float* part, float* out, hipStream_t s) {
+  const int nb = (M + COLSUM_RB - 1) / COLSUM_RB;
+  dim3 g1((N + 255) / 256, nb);
+  colsum_stage1_kernel<bf16_t><<<g1, 256, 0, s>>>((const bf16_t*)src, M, N, part);
   colsum_stage2_kernel<<<(N + 63) / 64, 1024, 0, s>>>(part, nb, N, out);
 }
 void launch_colsum_stage2(const float* part, int nb, int N, float* out, hipStream_t s) {

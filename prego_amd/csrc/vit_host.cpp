@@ -551,7 +551,8 @@ extern "C" int prego_debug_attention_fwd(int batch, int n_query, int len, int he
 // the attention arithmetic shared by the stateless op and the handle: wqkv bf16 [3D][D] (rows q | k | v), bqkv fp32 [3D],
 // wob bf16 [D][D]; act = 5 activation buffers of M*D bf16 (x, q, k, v, attention output)
 static int attention_layer_run(int batch, int len, int d_model, int heads, int causal, const float* x, const void* wqkv,
-                               const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s, bool f16 = false) {
+                               const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s, bool f16 = false,
+                               float* lse = nullptr) {
   const size_t M = (size_t)batch * len, D = d_model, step = align_up(M * D * 2, 256);
   const int dh = d_model / heads;
   char* xb = act; char* q = act + step; char* k = act + 2 * step; char* vn = act + 3 * step; char* ao = act + 4 * step;
@@ -560,7 +561,7 @@ static int attention_layer_run(int batch, int len, int d_model, int heads, int c
   e.mode = EPI_QKV; e.q = q; e.k = k; e.vn = vn; e.n_tok = len; e.heads = heads; e.dh = dh; e.emb = d_model;
   e.q_scale = 1.0f / sqrtf((float)dh);                                   // attn.py:44 scale = 1/sqrt(E)
   launch_gemm_bf16_nt_epi(xb, d_model, wqkv, d_model, bqkv, nullptr, 0, (int)M, 3 * d_model, d_model, e, s);
-  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s, nullptr, 0, 1.f, 0, f16)) return -1;
+  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s, lse, 0, 1.f, 0, f16)) return -1;
   launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s, f16);
   return 0;
 }
@@ -637,6 +638,87 @@ extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int bat
   if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, (char*)workspace,
                           (hipStream_t)stream, h->f16))
     return prego_fail_(PREGO_EINVAL, "attention launch failed");
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
+// ---- training: forward that keeps q, k, v, the attention output and the row log-sum-exp, and the backward over them --------
+// (attn.py:139-170 under autograd: the projections are nn.Linear, the attention FullAttention.forward attn.py:35-57 in eval
+// dropout state - attention_dropout acts on A only under module.train(), a state this op does not model: p = 0)
+struct AttnTrainWs { size_t act, lse, dyb, dO, dqkv, delta, T1, T2, WT, part, dW, vec, total; int Mp; };
+static AttnTrainWs attn_train_ws(int d_model, int heads, int batch, int len) {
+  const size_t M = (size_t)batch * len, D = d_model;
+  AttnTrainWs w{};
+  w.Mp = (int)align_up(M, 64);
+  size_t off = 0;
+  auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  w.act = put(5 * align_up(M * D * 2, 256)); w.lse = put((size_t)batch * heads * len * 4);
+  w.dyb = put(M * D * 2); w.dO = put(M * D * 2); w.dqkv = put(M * 3 * D * 2); w.delta = put((size_t)batch * heads * len * 4);
+  w.T1 = put(3 * D * (size_t)w.Mp * 2); w.T2 = put(3 * D * (size_t)w.Mp * 2); w.WT = put(3 * D * D * 2);
+  w.part = put((M / 64 + 2) * 3 * D * 4); w.dW = put(3 * D * D * 4); w.vec = put(3 * D * 4);
+  w.total = off;
+  return w;
+}
+extern "C" size_t prego_attention_layer_train_workspace_bytes(const prego_attn_layer* h, int batch, int len) {
+  return (h && batch > 0 && len > 0) ? attn_train_ws(h->d_model, h->heads, batch, len).total : 0;
+}
+extern "C" int prego_attention_layer_forward_train(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
+                                                   void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!h || !x || !out || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (h->f16) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_forward_train on an fp16-operand handle: training runs on bf16 handles");
+  if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
+  if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
+  const AttnTrainWs w = attn_train_ws(h->d_model, h->heads, batch, len);
+  if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
+  char* ws = (char*)workspace;
+  if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, ws + w.act,
+                          (hipStream_t)stream, false, (float*)(ws + w.lse)))
+    return prego_fail_(PREGO_EINVAL, "attention launch failed");
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+// grads: 8 fp32 tensors in set_weights order (wq, bq, wk, bk, wv, bv, wo, bo), overwritten; dx [batch*len, d_model] or NULL
+extern "C" int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int causal, const float* dout, float* dx,
+                                              float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
+                                              prego_stream_t stream) {
+  if (!h || !dout || !grads || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (h->f16) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_backward on an fp16-operand handle: training runs on bf16 handles");
+  if (n_tensors != 8) return prego_fail_(PREGO_EINVAL, "expected 8 gradient tensors, got %d", n_tensors);
+  for (int i = 0; i < 8; ++i) if (!grads[i]) return prego_fail_(PREGO_EINVAL, "gradient tensor %d is NULL", i);
+  if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
+  const AttnTrainWs w = attn_train_ws(h->d_model, h->heads, batch, len);
+  if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int D = h->d_model, M = batch * len, dh = D / h->heads, Mp = w.Mp;
+  const size_t step = align_up((size_t)M * D * 2, 256), DD = (size_t)D * D;
+  char* xb = ws + w.act; char* q = xb + step; char* k = xb + 2 * step; char* vn = xb + 3 * step; char* ao = xb + 4 * step;
+  float* part = (float*)(ws + w.part); float* vec = (float*)(ws + w.vec); float* dW = (float*)(ws + w.dW);
+  char* T1 = ws + w.T1; char* T2 = ws + w.T2; char* WT = ws + w.WT;
+  // ---- out_projection (attn.py:170): d bo, d Wo, d (attention output)
+  launch_f32_to_bf16(dout, ws + w.dyb, (size_t)M * D, s);
+  launch_colsum(dout, M, D, part, grads[7], s);
+  wgrad(dout, false, D, ao, true, D, M, Mp, T1, T2, grads[6], s);
+  launch_transpose_convert(true, true, h->wo, D, D, D, WT, D, s);
+  {
+    GemmEpi eb{}; eb.mode = EPI_STORE_BF16; eb.out_b = ws + w.dO;
+    launch_gemm_bf16_nt_epi(ws + w.dyb, D, WT, D, nullptr, nullptr, D, M, D, D, eb, s);
+  }
+  // ---- softmax(scale * Q K^T + mask) V (attn.py:41-52)
+  if (launch_attention_bwd(q, k, vn, ao, ws + w.dO, (const float*)(ws + w.lse), (float*)(ws + w.delta), ws + w.dqkv, batch, len,
+                           h->heads, dh, causal ? 1 : 0, 1.0f / sqrtf((float)dh), s))
+    return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
+  // ---- query / key / value projections (attn.py:160-162): rows of dqkv are [dq | dk | dv]
+  launch_colsum_bf16(ws + w.dqkv, M, 3 * D, part, vec, s);
+  wgrad(ws + w.dqkv, true, 3 * D, xb, true, D, M, Mp, T1, T2, dW, s);
+  for (int j = 0; j < 3; ++j) {
+    HIPCHK(hipMemcpyAsync(grads[2 * j], dW + j * DD, DD * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(grads[2 * j + 1], vec + (size_t)j * D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (dx) {     // self-attention: queries = keys = values = x, the three input gradients add up = dqkv . Wqkv
+    launch_transpose_convert(true, true, h->wqkv, 3 * D, D, D, WT, 3 * D, s);
+    launch_gemm_bf16_nt(ws + w.dqkv, 3 * D, WT, 3 * D, nullptr, dx, D, M, D, 3 * D, s);
+  }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

@@ -278,9 +278,52 @@ class _ViTTrainFn(torch.autograd.Function):
         return (None, None, None) + tuple(grads)
 
 
+class _AttnLayerTrainFn(torch.autograd.Function):
+    """AttentionLayer.forward under autograd (attn.py:151-170): the two C-ABI calls around torch's graph"""
+
+    @staticmethod
+    def forward(ctx, layer, x_in, *params):
+        lib, dev = layer.lib, layer.device
+        h = layer._train_handle(params)
+        B, L, D = x_in.shape
+        x = x_in.detach().float().contiguous()
+        need = lib.prego_attention_layer_train_workspace_bytes(h, B, L)
+        if layer._ws_train is None or layer._ws_train.numel() < need:
+            layer._ws_train = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, L, D), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.prego_attention_layer_forward_train(h, B, L, 1 if layer.mask_flag else 0, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                          C.c_void_p(layer._ws_train.data_ptr()), layer._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))
+        layer._train_gen += 1      # q, k, v, the attention output and the row log-sum-exp stay in the layer's ONE training workspace
+        ctx.layer, ctx.dims, ctx.gen, ctx.need_dx = layer, (B, L, D), layer._train_gen, bool(x_in.requires_grad)
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        layer, (B, L, D) = ctx.layer, ctx.dims
+        if layer._train_gen != ctx.gen:
+            raise PregoError("AttentionLayer backward: another training forward ran on this layer since the forward of this graph; its "
+                             "kept activations were overwritten (run backward before the next forward)")
+        lib, dev = layer.lib, layer.device
+        dout = dout.float().contiguous()
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        dx = torch.empty((B, L, D), dtype=torch.float32, device=dev) if ctx.need_dx else None
+        with torch.cuda.device(dev):
+            check(lib.prego_attention_layer_backward(layer._ht, B, L, 1 if layer.mask_flag else 0, C.c_void_p(dout.data_ptr()),
+                                                     None if dx is None else C.c_void_p(dx.data_ptr()), ptr_array([g.data_ptr() for g in grads]),
+                                                     len(grads), C.c_void_p(layer._ws_train.data_ptr()), layer._ws_train.numel(),
+                                                     C.c_void_p(_stream_ptr(dev))))
+        return (None, dx) + tuple(grads)
+
+
 class AttentionLayer:
     """AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170 as an object that owns converted weights: the four projection
-    matrices are ingested (fp32 -> bf16) once, every call only moves activations."""
+    matrices are ingested (fp32 -> bf16) once, every call only moves activations.
+
+    Under autograd (grad mode on and x or a projection parameter requiring grad) the call keeps q, k, v, the attention output and
+    the row log-sum-exp and backward() returns the gradients of x and of the eight parameters; that path computes with bf16
+    operands on its own handle (as ViTEnc's training does), re-ingesting the parameters whenever an optimizer changed them."""
 
     def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16"):
         self.lib = _lib.load()
@@ -300,8 +343,26 @@ class AttentionLayer:
             check(self.lib.prego_attention_layer_set_weights(self.h, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_void_p(_stream_ptr(self.device))))
         self._keep = ts
         self._ws = None
+        self.params = (wq, bq, wk, bk, wv, bv, wo, bo)
+        self._ht, self._ht_key, self._ws_train, self._train_gen = None, None, None, 0
+
+    def _train_handle(self, params):
+        """the bf16 handle of the autograd path, holding the CURRENT values of the parameters"""
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        with torch.cuda.device(self.device):
+            if self._ht is None:
+                h = C.c_void_p()
+                check(self.lib.prego_attention_layer_create(C.byref(h), self.d_model, self.n_heads))
+                self._ht = h
+            if self._ht_key != key:
+                ts = [t.detach().float().contiguous() for t in params]
+                check(self.lib.prego_attention_layer_set_weights(self._ht, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_void_p(_stream_ptr(self.device))))
+                self._keep_train, self._ht_key = ts, key
+        return self._ht
 
     def __call__(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params)):
+            return _AttnLayerTrainFn.apply(self, x, *self.params)
         B, L, D = x.shape
         x = x.detach().float().contiguous()
         need = self.lib.prego_attention_layer_handle_workspace_bytes(self.h, B, L)
@@ -316,9 +377,10 @@ class AttentionLayer:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
-                self.lib.prego_attention_layer_destroy(self.h)
-                self.h = None
+            for name in ("h", "_ht"):
+                if getattr(self, name, None):
+                    self.lib.prego_attention_layer_destroy(getattr(self, name))
+                    setattr(self, name, None)
         except Exception:
             pass
 

@@ -81,6 +81,54 @@ def test_g6_causal_attention_layer(L, dtype):
     assert not np.array_equal(out[-1], out2[-1])
 
 
+@pytest.mark.parametrize("d,B,L,mask", [(512, 2, 192, True), (2048, 1, 128, True), (1024, 2, 100, False)])
+def test_g6b_attention_layer_backward(d, B, L, mask):
+    """AttentionLayer under autograd (attn.py:151-170 inside loss.backward()): gradients of x and of the eight projection parameters
+    against the reference's own autograd (fixture G6b) - cosine over the sampled entries and norm, the bar of the ViT training test -
+    and every tensor in full against the numpy backward of the oracle."""
+    from prego_amd.transformer import AttentionLayer
+    g = np.load(os.path.join(G, f"g6b_attention_grads_d{d}_L{L}_{'causal' if mask else 'full'}.npz"))
+    sd = W.attention_layer_state_dict(d, 20)
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    keys = [n + s for n in names for s in (".weight", ".bias")]
+    params = [torch.from_numpy(sd[k]).cuda().requires_grad_(True) for k in keys]
+    x_np, G_np = W.normal((B, L, d), 20, f"g6b.x.{d}.{L}"), W.normal((B, L, d), 20, f"g6b.g.{d}.{L}")
+    x = torch.from_numpy(x_np).cuda().requires_grad_(True)
+    layer = AttentionLayer(*params, n_heads=8, mask_flag=mask)
+    out = layer(x)
+    assert out.requires_grad
+    (out * torch.from_numpy(G_np).cuda()).sum().backward()
+    dx_o, grads_o = O.causal_attention_layer_grads(x_np.astype(np.float64), *[sd[k].astype(np.float64) for k in keys], heads=8,
+                                                   dout=G_np.astype(np.float64), mask_flag=mask)
+    assert abs(float(out.detach().double().norm()) - float(g["out_norm"])) < 1e-2 * float(g["out_norm"])
+    worst = (2.0, "")
+    qb = float(g["norm.query_projection.bias"])
+    for k, t, full in [("x", x, dx_o)] + list(zip(keys, params, grads_o)):
+        got = t.grad.detach().cpu().numpy().astype(np.float64)
+        if k == "key_projection.bias":          # zero in real arithmetic: what is left is rounding, small against its sibling
+            assert np.linalg.norm(got) < 0.05 * qb, (np.linalg.norm(got), qb)
+            continue
+        ref_n = float(g["norm." + k])
+        assert abs(np.linalg.norm(got) - ref_n) < 0.05 * ref_n, (k, np.linalg.norm(got), ref_n)
+        a, r = got.reshape(-1)[g["idx." + k]], g["val." + k].astype(np.float64)
+        cos_s = float(a @ r / (np.linalg.norm(a) * np.linalg.norm(r) + 1e-30))
+        cos_f = float(got.reshape(-1) @ full.reshape(-1) / (np.linalg.norm(got) * np.linalg.norm(full) + 1e-30))
+        worst = min(worst, (min(cos_s, cos_f), k))
+        assert cos_s > 0.995 and cos_f > 0.999, (k, cos_s, cos_f)
+    print(f"attention layer backward d={d} L={L} mask={mask}: worst cosine {worst[0]:.5f} ({worst[1]})")
+    # the parameters move (an optimizer step): the training handle re-ingests them, eval and train forwards agree again
+    with torch.no_grad():
+        params[6].mul_(0.5)
+    out2 = layer(x)
+    assert torch.allclose(out2.detach() - params[7].detach(), (out.detach() - params[7].detach()) * 0.5, atol=2e-2 * float(out.detach().abs().max()))
+    with torch.no_grad():
+        ev = AttentionLayer(*[p.detach() for p in params], n_heads=8, mask_flag=mask, compute_dtype="bf16")(x.detach())
+    assert torch.equal(ev, out2.detach())
+    # a stale graph (another training forward since) is refused
+    with pytest.raises(Exception, match="another training forward"):
+        out.sum().backward()
+
+
 def test_noncausal_attention_vs_oracle_ragged_length():
     """L = 129 (window + cls token; not a multiple of any tile) without mask, against the numpy oracle"""
     from prego_amd.transformer import attention_layer

@@ -159,6 +159,29 @@ def test_g6_causal_attention(L):
     assert np.array_equal(o[0, :-1], o2[0, :-1])
 
 
+G6B = [(512, 2, 192, True), (2048, 1, 128, True), (1024, 2, 100, False)]
+_ATTN = ("query_projection", "key_projection", "value_projection", "out_projection")
+
+
+@pytest.mark.parametrize("d,B,L,mask", G6B)
+def test_g6b_attention_layer_gradients(d, B, L, mask):
+    """the numpy backward of the AttentionLayer against autograd through the reference's module (attn.py:139-170)"""
+    g = _ld(f"g6b_attention_grads_d{d}_L{L}_{'causal' if mask else 'full'}.npz")
+    sd = W.attention_layer_state_dict(d, 20)
+    x = W.normal((B, L, d), 20, f"g6b.x.{d}.{L}").astype(np.float64)
+    G_ = W.normal((B, L, d), 20, f"g6b.g.{d}.{L}").astype(np.float64)
+    args = [sd[n + s].astype(np.float64) for n in _ATTN for s in (".weight", ".bias")]
+    dx, grads = O.causal_attention_layer_grads(x, *args, heads=8, dout=G_, mask_flag=mask)
+    names = [n + s for n in _ATTN for s in (".weight", ".bias")]
+    for k, got in [("x", dx)] + list(zip(names, grads)):
+        ref_n, got_n = float(g["norm." + k]), float(np.linalg.norm(got))
+        if k == "key_projection.bias":            # exactly zero in real arithmetic (a shift of every key moves a row's scores alike)
+            assert got_n < 1e-6 and ref_n < 1e-4
+            continue
+        assert abs(got_n - ref_n) < 2e-5 * ref_n, (k, got_n, ref_n)
+        assert np.abs(got.reshape(-1)[g["idx." + k]] - g["val." + k]).max() < 2e-5 * max(1.0, np.abs(g["val." + k]).max()), k
+
+
 def test_g7_evaluate_json_and_argmax():
     g = json.load(open(os.path.join(G, "g7_evaluate.json")))
     cfg = epic_tent_cfg()
