@@ -185,6 +185,9 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
   h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
   h->pack_prefetch = getenv("PREGO_NO_PACK_PREFETCH") == nullptr;
+  // the pack beside the recurrence slows its L2 hand-off; capped at 512 workgroups it still ends inside a 49 152-row launch and
+  // costs the pass 0.9 ms less than unthrottled (sweep: scripts/probes/env_sweep.sh, 128: +10 ms, 256: +1, 512: -0.9, 1024: 0)
+  h->prefetch_grid = 512;
   if (const char* pg = getenv("PREGO_PACK_PREFETCH_GRID")) h->prefetch_grid = atoi(pg);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -611,6 +614,16 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       if (h->timing) h->gemm_flop += 2.0 * rows * (double)E * kx;
     }
     l1_done = false;
+    // PREGO_PACK_EARLY=1 (A/B): X is dead from here on, so the next chunk's pack may run beside LayerNorm + the W_ih GEMM (MFMA-bound,
+    // HBM half idle) instead of beside the recurrence (whose L2 hand-off it slows)
+    static const bool pack_early = getenv("PREGO_PACK_EARLY") != nullptr;
+    const bool early = pack_early && prefetch && t1 < h->t_max;
+    if (early) {
+      HIPCHK(hipEventRecord(h->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
+      side_join.pending = true;
+    }
     launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16);
     ev = ev_begin(h, 0, s);
     proj(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E);
@@ -669,7 +682,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       // (latency-bound, one wave per SIMD) holds the CUs.  The recurrence is launched FIRST so that its 256 workgroups are
       // resident (placement rendezvous) before the copy's workgroups fill the wave slots
       HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-      pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
+      if (!early) pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
       side_join.pending = true;
       if (ov) {
         const int rows_n = h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1];
