@@ -963,11 +963,15 @@ __global__ void gru_arm_kernel(unsigned* __restrict__ hx, size_t words_per_buf, 
   if (sync != nullptr && i < 16) sync[i] = 0u;
 }
 
+GruArm gru_arm_desc(bool bf16, int hid, int G, void* hx, unsigned* sync) {
+  return GruArm{(unsigned*)hx, (unsigned long long)(gru_hx_bytes(bf16, hid, G) / 2 / 4), bf16 ? 0x40004000u : 0x40000000u, sync};
+}
+
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s) {
   if (hid != 1024) return -1;
   const int P = bf16 ? 32 : 64;
   const size_t buf_bytes = gru_hx_bytes(bf16, hid, a.G) / 2;
-  gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, buf_bytes / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);
+  if (!a.armed) gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, buf_bytes / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);
   const int grid = a.G * P;
   const bool train = a.keep_r != nullptr || a.h_raw_out != nullptr;
   // two or more clip tiles per group, inference: the software-pipelined multi-tile kernel (PREGO_GRU_NO_MT=1: the classic kernel, A/B)

@@ -54,7 +54,13 @@ struct GruArgs {
   int f16;                     // 16-bit operands / intermediates are IEEE fp16 instead of bf16 (launch_gru_recurrence picks the instantiation)
   int Gd;                      // groups the slots are dealt to (0 = G); one-tile kernel only
   int rows;                    // packed rows this launch covers (rowoff[t1] - row_base); 0 = unknown
+  int armed;                   // 1: hx / sync were re-armed by an earlier kernel of this stream (launch_ln_relu with a GruArm): no arm launch
 };
+// what a recurrence launch needs re-armed before it starts (gru_recurrence.hip: buffer 0 := tag 1 everywhere, buffer 1 := 0,
+// sync[0..15] := 0).  A LayerNorm launch that runs between two recurrence launches of a stream can do it on the side (one launch
+// and one launch gap fewer per chunk)
+struct GruArm { unsigned* hx; unsigned long long words_per_buf; unsigned pattern; unsigned* sync; };
+GruArm gru_arm_desc(bool bf16, int hid, int G, void* hx, unsigned* sync);
 
 // persistent reverse-time recurrence of BPTT (gru_bptt.hip); all row indices are absolute packed rows of the kept forward
 struct BpttArgs {
@@ -105,7 +111,7 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
                       bool in16 = false /* the feature arrays hold the 16-bit operand type already (PREGO_FWD_IN16) */);
 void launch_ln_relu(bool bf16, const void* Y, const float* gamma, const float* beta, int nrows, int E, float eps,
                     void* out, float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu = 1,
-                    bool in_bf16 = false, bool f16 = false);
+                    bool in_bf16 = false, bool f16 = false, const GruArm* arm = nullptr);
 void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
                         int cols_dst, hipStream_t s, bool f16 = false);

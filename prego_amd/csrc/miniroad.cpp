@@ -624,7 +624,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       pack_chunk(t1, chunk_end(t1), h->side, ci + 1);
       side_join.pending = true;
     }
-    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16);
+    // the LayerNorm launch also re-arms the recurrence's exchange buffers and rendezvous words (it runs after the previous recurrence
+    // launch of this stream and before the next): one launch and one launch gap fewer per chunk (PREGO_NO_ARM_FUSE=1: A/B)
+    static const bool arm_fuse = getenv("PREGO_NO_ARM_FUSE") == nullptr;
+    const GruArm arm = gru_arm_desc(h->bf16, h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags);
+    launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16,
+                   arm_fuse ? &arm : nullptr);
     ev = ev_begin(h, 0, s);
     proj(Eb, E, h->w_ih, E, h->bias2, GI, 3 * H, rows, 3 * H, E);
     ev_end(ev, s);
@@ -638,6 +643,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.n_clips = n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
+    ga.armed = (arm_fuse && rows > 0) ? 1 : 0;
     {
       // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
       // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)

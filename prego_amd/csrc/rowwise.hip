@@ -69,7 +69,15 @@ template <typename OutT, int MAXV, typename InT = float>
 __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
     const InT* __restrict__ Y, const float* __restrict__ gamma, const float* __restrict__ beta,
     int nrows, int E, float eps, OutT* __restrict__ out, float* __restrict__ stats /*nullable [nrows][2]*/,
-    float drop_p, unsigned long long seed, int row0_abs, int relu) {
+    float drop_p, unsigned long long seed, int row0_abs, int relu, GruArm arm) {
+  if (arm.hx != nullptr) {            // re-arm the recurrence's exchange buffers and rendezvous words on the side (kernels.h: GruArm)
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i0; k < arm.words_per_buf / 4; k += stride) {
+      ((uint4*)arm.hx)[k] = make_uint4(arm.pattern, arm.pattern, arm.pattern, arm.pattern);
+      ((uint4*)(arm.hx + arm.words_per_buf))[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (arm.sync != nullptr && i0 < 16) arm.sync[i0] = 0u;
+  }
   // training-mode Dropout(p) after the ReLU (rnn.py:43): stateless mask = hash(seed, absolute element index),
   // kept values scaled by 1/(1-p); the backward kernel regenerates the same mask
   const unsigned thresh = drop_p > 0.f ? (unsigned)(drop_p * 4294967296.0) : 0u;
@@ -173,33 +181,35 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
 }
 
 void launch_ln_relu(bool bf16, const void* Yv, const float* gamma, const float* beta, int nrows, int E, float eps, void* out,
-                    float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu, bool in_bf16, bool f16) {
+                    float* stats, float drop_p, unsigned long long seed, int row0_abs, hipStream_t s, int relu, bool in_bf16, bool f16,
+                    const GruArm* armp) {
   if (nrows <= 0) return;
+  const GruArm arm = armp ? *armp : GruArm{nullptr, 0ull, 0u, nullptr};
   int grid = (nrows + 3) / 4;
   if (grid > 16384) grid = 16384;
   const float* Y = (const float*)Yv;
   if (f16) {            // fp16 operand mode (inference): fp16 or fp32 rows in, fp16 out
     if (in_bf16) {
-      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
-      else ln_relu_rows_kernel<f16_t, 8, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
+      else ln_relu_rows_kernel<f16_t, 8, f16_t><<<grid, 256, 0, s>>>((const f16_t*)Yv, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
     } else {
-      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
-      else ln_relu_rows_kernel<f16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu);
+      if (E <= 2048) ln_relu_rows_kernel<f16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
+      else ln_relu_rows_kernel<f16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (f16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
     }
     return;
   }
   if (in_bf16) {        // bf16 in, bf16 out (inference path)
     const bf16_t* Yb = (const bf16_t*)Yv;
-    if (E <= 2048) ln_relu_rows_kernel<bf16_t, 4, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
-    else ln_relu_rows_kernel<bf16_t, 8, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
+    if (E <= 2048) ln_relu_rows_kernel<bf16_t, 4, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
+    else ln_relu_rows_kernel<bf16_t, 8, bf16_t><<<grid, 256, 0, s>>>(Yb, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
     return;
   }
   if (E <= 2048) {
-    if (bf16) ln_relu_rows_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
-    else ln_relu_rows_kernel<float, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
+    if (bf16) ln_relu_rows_kernel<bf16_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
+    else ln_relu_rows_kernel<float, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu, arm);
   } else {
-    if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu);
-    else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu);
+    if (bf16) ln_relu_rows_kernel<bf16_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (bf16_t*)out, stats, drop_p, seed, row0_abs, relu, arm);
+    else ln_relu_rows_kernel<float, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (float*)out, stats, drop_p, seed, row0_abs, relu, arm);
   }
 }
 
