@@ -210,7 +210,10 @@ int prego_vit_set_weights(prego_vit* h, const float* const* tensors, int n_tenso
 size_t prego_vit_workspace_bytes(const prego_vit* h, int batch);
 /* MFMA operand type of the handle: PREGO_BF16 (default) or PREGO_F16 (IEEE fp16 operands and 16-bit activations: the same rate
  * and bytes, 8x less operand rounding - logits within 1e-3 of the fp32 reference where bf16 gives 2.5e-3; inference entry points
- * only: forward, forward_frames).  Changing the type invalidates the ingested weights (call set_weights again). */
+ * only: forward, forward_frames), or PREGO_F32 (parity mode: the matrices stay fp32, the projections run on the exact-fp32 MFMA
+ * GEMM, attention / GELU / residuals in fp32, every block on every token; prego_vit_forward only - logits within 2e-5 of the
+ * reference; the north star's "1e-3 fp32" figure is checked on it).  Changing the type invalidates the ingested weights (call
+ * set_weights again); prego_vit_workspace_bytes follows the handle's type. */
 int prego_vit_set_compute_dtype(prego_vit* h, int compute_dtype);
 
 /* ViTEnc.forward (ViT.py:117-143): rgb/flow device fp32 [batch, window, d_rgb/d_flow] (flow NULL = zeros);
@@ -272,7 +275,8 @@ int prego_attention_layer_forward(int batch, int len, int d_model, int heads, in
 typedef struct prego_attn_layer prego_attn_layer;
 int prego_attention_layer_create(prego_attn_layer** out, int d_model, int heads);
 void prego_attention_layer_destroy(prego_attn_layer* h);
-/* PREGO_BF16 (default) or PREGO_F16 operands for the handle's forward; changing the type invalidates the ingested weights. */
+/* PREGO_BF16 (default), PREGO_F16 or PREGO_F32 (parity mode: fp32 projections and fp32 attention, handle_forward only) operands
+ * for the handle's forward; changing the type invalidates the ingested weights; handle_workspace_bytes follows the type. */
 int prego_attention_layer_set_compute_dtype(prego_attn_layer* h, int compute_dtype);
 int prego_attention_layer_set_weights(prego_attn_layer* h, const float* wq, const float* bq, const float* wk, const float* bk,
                                       const float* wv, const float* bv, const float* wo, const float* bo, prego_stream_t stream);

@@ -205,6 +205,13 @@ void launch_vit_head(const float* x, int B, int N, int E, const float* lnw, cons
 void launch_vit_sliding_tokens(const float* enc, const float* enc_b, const float* cls, const float* pe, int t0, int B, int T, int E,
                                float* x, const float* ln_w, const float* ln_b, void* xn, float* x0, hipStream_t s, bool f16 = false);
 void launch_add_bias_rows(float* x, const float* bias, int rows, int n, hipStream_t s);
+// fp32-operand mode of the Transformer path (vit_f32.hip): attention over fp32 rows (q / k / v at column offsets of one [B*N, ld]
+// array, Nq <= N queries per sequence), exact-erf GELU in place, x += y, [rgb | flow] rows
+int launch_attention_f32(const float* qkv, int ld, int q_off, int k_off, int v_off, float* out, int B, int N, int Nq, int heads,
+                         int dh, int causal, float scale, hipStream_t s);
+void launch_gelu_f32(float* u, size_t n, hipStream_t s);
+void launch_add_rows(float* x, const float* y, size_t n, hipStream_t s);
+void launch_cat_rows_f32(const float* rgb, const float* flow, int rows, int d_rgb, int d_flow, float* out, hipStream_t s);
 
 // streaming step (stream_step.hip): skinny products for n <= 16 rows, one frame per stream
 struct StreamGemv {

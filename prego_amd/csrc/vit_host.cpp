@@ -23,6 +23,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct VitLayer {
   float *ln1_w, *ln1_b, *proj_b, *ln2_w, *ln2_b, *ff1_b, *ff2_b;
   void *qkv_w, *proj_w, *ff1_w, *ff2_w;    // bf16
+  float *qkv_w32 = nullptr, *proj_w32 = nullptr, *ff1_w32 = nullptr, *ff2_w32 = nullptr;   // PREGO_F32 handles only
 };
 struct prego_vit {
   int d_rgb, d_flow, emb, mlp, heads, layers, window, ncls;
@@ -32,6 +33,8 @@ struct prego_vit {
   std::vector<void*> allocs;
   bool have_weights = false;
   bool f16 = false;                // IEEE fp16 operands / 16-bit activations instead of bf16 (prego_vit_set_compute_dtype; inference only)
+  bool f32 = false;                // fp32 operands everywhere (parity mode, prego_vit_forward only): the matrices are kept in fp32
+  float* enc_w32 = nullptr;
   // training-mode dropout (cfg['dropout']; ViT.py:130 pe_dropout, Transformer.py:31 PreNormDrop, Transformer.py:41,46 FeedForward)
   float drop_p = 0.f;
   float attn_drop_p = 0.f;         // cfg['attn_dropout_rate']: attention probabilities (Attention.py:17,36) and proj_drop (Attention.py:19,40)
@@ -104,10 +107,20 @@ extern "C" void prego_vit_destroy(prego_vit* h) {
 
 extern "C" int prego_vit_set_compute_dtype(prego_vit* h, int compute_dtype) {
   if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
-  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16)
-    return prego_fail_(PREGO_EINVAL, "ViTEnc compute_dtype %d: PREGO_BF16 or PREGO_F16", compute_dtype);
-  if ((compute_dtype == PREGO_F16) != h->f16) h->have_weights = false;      // the 16-bit weight copies are of the other type: re-ingest
+  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16 && compute_dtype != PREGO_F32)
+    return prego_fail_(PREGO_EINVAL, "ViTEnc compute_dtype %d: PREGO_BF16, PREGO_F16 or PREGO_F32", compute_dtype);
+  if ((compute_dtype == PREGO_F16) != h->f16 || (compute_dtype == PREGO_F32) != h->f32) h->have_weights = false;   // other copies: re-ingest
   h->f16 = compute_dtype == PREGO_F16;
+  h->f32 = compute_dtype == PREGO_F32;
+  if (h->f32 && !h->enc_w32) {          // fp32 copies of the matrices, allocated with the first switch to this mode
+    const size_t E = h->emb, din = h->d_rgb + h->d_flow, mlp = h->mlp;
+    int rc = dmalloc(h, (void**)&h->enc_w32, E * din * 4);
+    for (auto& l : h->L) {
+      rc |= dmalloc(h, (void**)&l.qkv_w32, 3 * E * E * 4); rc |= dmalloc(h, (void**)&l.proj_w32, E * E * 4);
+      rc |= dmalloc(h, (void**)&l.ff1_w32, mlp * E * 4); rc |= dmalloc(h, (void**)&l.ff2_w32, E * mlp * 4);
+    }
+    if (rc) { h->f32 = false; return PREGO_EHIP; }
+  }
   return PREGO_OK;
 }
 
@@ -121,6 +134,21 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
   const int E = h->emb, din = h->d_rgb + h->d_flow, mlp = h->mlp;
   int k = 0;
   auto f32 = [&](float* dst, size_t n) { return hipMemcpyAsync(dst, t[k++], n * 4, hipMemcpyDeviceToDevice, s); };
+  if (h->f32) {                                    // parity mode: every tensor is kept as it comes
+    HIPCHK(f32(h->enc_w32, (size_t)E * din));
+    HIPCHK(f32(h->enc_b, E)); HIPCHK(f32(h->cls, E)); HIPCHK(f32(h->pe, (size_t)(h->window + 1) * E));
+    for (auto& l : h->L) {
+      HIPCHK(f32(l.ln1_w, E)); HIPCHK(f32(l.ln1_b, E));
+      HIPCHK(f32(l.qkv_w32, (size_t)3 * E * E)); HIPCHK(f32(l.proj_w32, (size_t)E * E));
+      HIPCHK(f32(l.proj_b, E)); HIPCHK(f32(l.ln2_w, E)); HIPCHK(f32(l.ln2_b, E));
+      HIPCHK(f32(l.ff1_w32, (size_t)mlp * E)); HIPCHK(f32(l.ff1_b, mlp));
+      HIPCHK(f32(l.ff2_w32, (size_t)E * mlp)); HIPCHK(f32(l.ff2_b, E));
+    }
+    HIPCHK(f32(h->lnf_w, E)); HIPCHK(f32(h->lnf_b, E)); HIPCHK(f32(h->head_w, (size_t)h->ncls * E)); HIPCHK(f32(h->head_b, h->ncls));
+    HIPCHK(hipGetLastError());
+    h->have_weights = true;
+    return PREGO_OK;
+  }
   launch_pad_convert(true, t[k++], E, din, din, h->enc_w, E, din, s, h->f16);
   HIPCHK(f32(h->enc_b, E)); HIPCHK(f32(h->cls, E)); HIPCHK(f32(h->pe, (size_t)(h->window + 1) * E));
   for (auto& l : h->L) {
@@ -143,7 +171,7 @@ extern "C" int prego_vit_set_weights(prego_vit* h, const float* const* t, int n_
 extern "C" int prego_vit_adamw_step(prego_vit* h, float* const* params, const float* const* grads, float* const* exp_avg,
                                     float* const* exp_avg_sq, int n_tensors, int64_t step, float lr, float beta1, float beta2, float eps,
                                     float weight_decay, prego_stream_t stream) {
-  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_adamw_step on an fp16-operand handle: training runs on bf16 handles");
+  if (h && (h->f16 || h->f32)) return prego_fail_(PREGO_EINVAL, "prego_vit_adamw_step on an fp16- / fp32-operand handle: training runs on bf16 handles");
   if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return prego_fail_(PREGO_EINVAL, "vit adamw: NULL argument");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "vit adamw step before set_weights");
   if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d tensors, got %d", prego_vit_num_tensors(h), n_tensors);
@@ -184,7 +212,50 @@ static VitWs vit_ws(const prego_vit* h, int B) {
   w.total = off;
   return w;
 }
-extern "C" size_t prego_vit_workspace_bytes(const prego_vit* h, int batch) { return (h && batch > 0) ? vit_ws(h, batch).total : 0; }
+// fp32-operand mode: fp32 rows everywhere, every block on every token
+struct VitWs32 { size_t xc, enc, x, xn, qkv, ao, tmp, total; };
+static VitWs32 vit_ws32(const prego_vit* h, int B) {
+  const size_t E = h->emb, T = h->window, N = T + 1, din = h->d_rgb + h->d_flow, M = (size_t)B * N, mlp = h->mlp;
+  VitWs32 w{};
+  size_t off = 0;
+  auto put = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  w.xc = put((size_t)B * T * din * 4); w.enc = put((size_t)B * T * E * 4); w.x = put(M * E * 4); w.xn = put(M * E * 4);
+  w.qkv = put(M * 3 * E * 4); w.ao = put(M * E * 4); w.tmp = put(M * std::max(E, mlp) * 4);
+  w.total = off;
+  return w;
+}
+extern "C" size_t prego_vit_workspace_bytes(const prego_vit* h, int batch) {
+  if (!h || batch <= 0) return 0;
+  return h->f32 ? vit_ws32(h, batch).total : vit_ws(h, batch).total;
+}
+// ViTEnc.forward (ViT.py:117-143) with fp32 operands: the projections on the exact-fp32 MFMA GEMM, everything else in fp32 too
+static int vit_forward_f32(prego_vit* h, int B, const float* rgb, const float* flow, float* out_logits, int causal, char* ws,
+                           hipStream_t s) {
+  const VitWs32 w = vit_ws32(h, B);
+  const int T = h->window, N = T + 1, E = h->emb, din = h->d_rgb + h->d_flow, M = B * N, dh = E / h->heads, mlp = h->mlp;
+  float* xc = (float*)(ws + w.xc); float* enc = (float*)(ws + w.enc); float* x = (float*)(ws + w.x); float* xn = (float*)(ws + w.xn);
+  float* qkv = (float*)(ws + w.qkv); float* ao = (float*)(ws + w.ao); float* tmp = (float*)(ws + w.tmp);
+  launch_cat_rows_f32(rgb, flow, B * T, h->d_rgb, h->d_flow, xc, s);
+  launch_gemm_f32_nt(xc, din, h->enc_w32, din, h->enc_b, enc, E, B * T, E, din, s);                     // ViT.py:124
+  launch_vit_tokens(enc, h->cls, h->pe, B, T, E, x, s);                                                  // ViT.py:125-129
+  for (int li = 0; li < h->layers; ++li) {
+    const VitLayer& l = h->L[li];
+    launch_ln_relu(false, x, l.ln1_w, l.ln1_b, M, E, 1e-5f, xn, nullptr, 0.f, 0, 0, s, 0);
+    launch_gemm_f32_nt(xn, E, l.qkv_w32, E, nullptr, qkv, 3 * E, M, 3 * E, E, s);                       // Attention.py:23-27
+    if (launch_attention_f32(qkv, 3 * E, 0, E, 2 * E, ao, B, N, N, h->heads, dh, causal, 1.0f / sqrtf((float)dh), s))
+      return prego_fail_(PREGO_EINVAL, "attention launch failed");
+    launch_gemm_f32_nt(ao, E, l.proj_w32, E, l.proj_b, tmp, E, M, E, E, s);
+    launch_add_rows(x, tmp, (size_t)M * E, s);                                                           // Transformer.py:24-32
+    launch_ln_relu(false, x, l.ln2_w, l.ln2_b, M, E, 1e-5f, xn, nullptr, 0.f, 0, 0, s, 0);
+    launch_gemm_f32_nt(xn, E, l.ff1_w32, E, l.ff1_b, tmp, mlp, M, mlp, E, s);
+    launch_gelu_f32(tmp, (size_t)M * mlp, s);                                                            // Transformer.py:40
+    launch_gemm_f32_nt(tmp, mlp, l.ff2_w32, mlp, l.ff2_b, xn, E, M, E, mlp, s);
+    launch_add_rows(x, xn, (size_t)M * E, s);
+  }
+  launch_vit_head(x, B, N, E, h->lnf_w, h->lnf_b, h->head_w, h->head_b, h->ncls, out_logits, s);       // token 0, ViT.py:134-141
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
 
 // one pre-norm encoder block on the fp32 residual stream x [M = B*N, E] (Transformer.py:60-77)
 static int encoder_block(const prego_vit* h, const VitLayer& l, float* x, char* ws, const VitWs& w, int B, int N, int causal,
@@ -240,6 +311,10 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0) return prego_fail_(PREGO_EINVAL, "batch %d", batch);
   if ((h->d_rgb > 0 && !rgb) || (h->d_flow > 0 && !flow && h->d_rgb == 0)) return prego_fail_(PREGO_EINVAL, "missing input");
+  if (h->f32) {
+    if (workspace_bytes < vit_ws32(h, batch).total) return prego_fail_(PREGO_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, vit_ws32(h, batch).total);
+    return vit_forward_f32(h, batch, rgb, flow, out_logits, (flags & 1) ? 1 : 0, (char*)workspace, (hipStream_t)stream);
+  }
   const VitWs w = vit_ws(h, batch);
   if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "workspace %zu < %zu", workspace_bytes, w.total);
   hipStream_t s = (hipStream_t)stream;
@@ -299,6 +374,7 @@ extern "C" int prego_vit_forward_frames(prego_vit* h, int n_frames, const float*
                                         int32_t* out_argmax, int windows_per_batch, int flags, void* workspace, size_t workspace_bytes,
                                         prego_stream_t stream) {
   if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
+  if (h->f32) return prego_fail_(PREGO_EINVAL, "prego_vit_forward_frames on an fp32-operand handle: the parity mode covers prego_vit_forward");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (n_frames <= 0 || windows_per_batch <= 0) return prego_fail_(PREGO_EINVAL, "n_frames %d, windows_per_batch %d", n_frames, windows_per_batch);
   if ((h->d_rgb > 0 && !rgb) || (h->d_rgb == 0 && !flow)) return prego_fail_(PREGO_EINVAL, "missing input");
@@ -379,7 +455,7 @@ extern "C" size_t prego_vit_train_workspace_bytes(const prego_vit* h, int batch)
 
 extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb, const float* flow, float* out_logits, int flags,
                                        void* workspace, size_t workspace_bytes, prego_stream_t stream) {
-  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_forward_train on an fp16-operand handle: training runs on bf16 handles");
+  if (h && (h->f16 || h->f32)) return prego_fail_(PREGO_EINVAL, "prego_vit_forward_train on an fp16- / fp32-operand handle: training runs on bf16 handles");
   if (!h || !out_logits || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0) return prego_fail_(PREGO_EINVAL, "batch %d", batch);
@@ -435,7 +511,7 @@ static void wgrad(const void* a_rows, bool a_bf16, int Mo, const void* b_rows, b
 
 extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
                                   void* workspace, size_t workspace_bytes, prego_stream_t stream) {
-  if (h && h->f16) return prego_fail_(PREGO_EINVAL, "prego_vit_backward on an fp16-operand handle: training runs on bf16 handles");
+  if (h && (h->f16 || h->f32)) return prego_fail_(PREGO_EINVAL, "prego_vit_backward on an fp16- / fp32-operand handle: training runs on bf16 handles");
   if (!h || !dlogits || !grads || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
   if (n_tensors != prego_vit_num_tensors(h)) return prego_fail_(PREGO_EINVAL, "expected %d gradient tensors, got %d", prego_vit_num_tensors(h), n_tensors);
   for (int i = 0; i < n_tensors; ++i) if (!grads[i]) return prego_fail_(PREGO_EINVAL, "gradient tensor %d is NULL", i);
@@ -578,13 +654,22 @@ struct prego_attn_layer {
   void* wqkv = nullptr; float* bqkv = nullptr; void* wo = nullptr; float* bo = nullptr;
   bool have_weights = false;
   bool f16 = false;                // IEEE fp16 operands instead of bf16 (prego_attention_layer_set_compute_dtype)
+  bool f32 = false;                // fp32 operands (parity mode): wqkv32 [3D][D], wo32 [D][D]
+  float* wqkv32 = nullptr; float* wo32 = nullptr;
 };
 extern "C" int prego_attention_layer_set_compute_dtype(prego_attn_layer* h, int compute_dtype) {
   if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
-  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16)
-    return prego_fail_(PREGO_EINVAL, "AttentionLayer compute_dtype %d: PREGO_BF16 or PREGO_F16", compute_dtype);
-  if ((compute_dtype == PREGO_F16) != h->f16) h->have_weights = false;
+  if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16 && compute_dtype != PREGO_F32)
+    return prego_fail_(PREGO_EINVAL, "AttentionLayer compute_dtype %d: PREGO_BF16, PREGO_F16 or PREGO_F32", compute_dtype);
+  if ((compute_dtype == PREGO_F16) != h->f16 || (compute_dtype == PREGO_F32) != h->f32) h->have_weights = false;
   h->f16 = compute_dtype == PREGO_F16;
+  h->f32 = compute_dtype == PREGO_F32;
+  if (h->f32 && !h->wqkv32) {
+    const size_t D = h->d_model;
+    hipError_t e = hipMalloc((void**)&h->wqkv32, 3 * D * D * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->wo32, D * D * 4);
+    if (e != hipSuccess) { h->f32 = false; return prego_fail_(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+  }
   return PREGO_OK;
 }
 extern "C" int prego_attention_layer_create(prego_attn_layer** out, int d_model, int heads) {
@@ -604,7 +689,7 @@ extern "C" int prego_attention_layer_create(prego_attn_layer** out, int d_model,
 }
 extern "C" void prego_attention_layer_destroy(prego_attn_layer* h) {
   if (!h) return;
-  for (void* p : {h->wqkv, (void*)h->bqkv, h->wo, (void*)h->bo}) if (p) (void)hipFree(p);
+  for (void* p : {h->wqkv, (void*)h->bqkv, h->wo, (void*)h->bo, (void*)h->wqkv32, (void*)h->wo32}) if (p) (void)hipFree(p);
   delete h;
 }
 extern "C" int prego_attention_layer_set_weights(prego_attn_layer* h, const float* wq, const float* bq, const float* wk,
@@ -614,10 +699,17 @@ extern "C" int prego_attention_layer_set_weights(prego_attn_layer* h, const floa
   hipStream_t s = (hipStream_t)stream;
   const int d = h->d_model;
   const size_t D = d;
+  if (h->f32) {
+    HIPCHK(hipMemcpyAsync(h->wqkv32, wq, D * D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->wqkv32 + D * D, wk, D * D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->wqkv32 + 2 * D * D, wv, D * D * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->wo32, wo, D * D * 4, hipMemcpyDeviceToDevice, s));
+  } else {
   launch_pad_convert(true, wq, d, d, d, h->wqkv, d, d, s, h->f16);
   launch_pad_convert(true, wk, d, d, d, (char*)h->wqkv + D * D * 2, d, d, s, h->f16);
   launch_pad_convert(true, wv, d, d, d, (char*)h->wqkv + 2 * D * D * 2, d, d, s, h->f16);
   launch_pad_convert(true, wo, d, d, d, h->wo, d, d, s, h->f16);
+  }
   HIPCHK(hipMemcpyAsync(h->bqkv, bq, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->bqkv + D, bk, D * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->bqkv + 2 * D, bv, D * 4, hipMemcpyDeviceToDevice, s));
@@ -627,7 +719,9 @@ extern "C" int prego_attention_layer_set_weights(prego_attn_layer* h, const floa
   return PREGO_OK;
 }
 extern "C" size_t prego_attention_layer_handle_workspace_bytes(const prego_attn_layer* h, int batch, int len) {
-  return h ? 5 * align_up((size_t)batch * len * h->d_model * 2, 256) : 0;
+  if (!h) return 0;
+  if (h->f32) return 4 * align_up((size_t)batch * len * h->d_model * 4, 256);       // q | k | v rows [M, 3D] and the attention output
+  return 5 * align_up((size_t)batch * len * h->d_model * 2, 256);
 }
 extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
                                                     void* workspace, size_t workspace_bytes, prego_stream_t stream) {
@@ -635,6 +729,18 @@ extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int bat
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
   if (workspace_bytes < prego_attention_layer_handle_workspace_bytes(h, batch, len)) return prego_fail_(PREGO_EWORKSPACE, "workspace too small");
+  if (h->f32) {                 // attn.py:151-170 with fp32 operands: biased projections on the exact-fp32 GEMM, fp32 attention
+    hipStream_t s = (hipStream_t)stream;
+    const int D = h->d_model, M = batch * len, dh = D / h->heads;
+    float* qkv = (float*)workspace;
+    float* ao = qkv + (size_t)3 * align_up((size_t)M * D * 4, 256) / 4;
+    launch_gemm_f32_nt(x, D, h->wqkv32, D, h->bqkv, qkv, 3 * D, M, 3 * D, D, s);
+    if (launch_attention_f32(qkv, 3 * D, 0, D, 2 * D, ao, batch, len, len, h->heads, dh, causal ? 1 : 0, 1.0f / sqrtf((float)dh), s))
+      return prego_fail_(PREGO_EINVAL, "attention launch failed");
+    launch_gemm_f32_nt(ao, D, h->wo32, D, h->bo, out, D, M, D, D, s);
+    HIPCHK(hipGetLastError());
+    return PREGO_OK;
+  }
   if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, (char*)workspace,
                           (hipStream_t)stream, h->f16))
     return prego_fail_(PREGO_EINVAL, "attention launch failed");
@@ -665,7 +771,7 @@ extern "C" size_t prego_attention_layer_train_workspace_bytes(const prego_attn_l
 extern "C" int prego_attention_layer_forward_train(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
                                                    void* workspace, size_t workspace_bytes, prego_stream_t stream) {
   if (!h || !x || !out || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
-  if (h->f16) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_forward_train on an fp16-operand handle: training runs on bf16 handles");
+  if (h->f16 || h->f32) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_forward_train on an fp16- / fp32-operand handle: training runs on bf16 handles");
   if (!h->have_weights) return prego_fail_(PREGO_EINVAL, "forward before set_weights");
   if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);
   const AttnTrainWs w = attn_train_ws(h->d_model, h->heads, batch, len);
@@ -682,7 +788,7 @@ extern "C" int prego_attention_layer_backward(prego_attn_layer* h, int batch, in
                                               float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
                                               prego_stream_t stream) {
   if (!h || !dout || !grads || !workspace) return prego_fail_(PREGO_EINVAL, "NULL argument");
-  if (h->f16) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_backward on an fp16-operand handle: training runs on bf16 handles");
+  if (h->f16 || h->f32) return prego_fail_(PREGO_EINVAL, "prego_attention_layer_backward on an fp16- / fp32-operand handle: training runs on bf16 handles");
   if (n_tensors != 8) return prego_fail_(PREGO_EINVAL, "expected 8 gradient tensors, got %d", n_tensors);
   for (int i = 0; i < 8; ++i) if (!grads[i]) return prego_fail_(PREGO_EINVAL, "gradient tensor %d is NULL", i);
   if (batch <= 0 || len <= 0) return prego_fail_(PREGO_EINVAL, "batch %d, len %d", batch, len);

@@ -98,13 +98,14 @@ class ViTEnc(nn.Module):
         self.attn_dropout_rate = float(cfg.get("attn_dropout_rate", 0.0))   # ViT.py:47
         self.causal = bool(cfg.get("causal_attention", False))     # extension, see DESIGN.md
         # MFMA operand type of the INFERENCE entry points (forward in eval mode, forward_frames): 'fp16' (default: same rate as bf16,
-        # 8x less operand rounding) or 'bf16'.  Training always runs on the bf16 handle.
+        # 8x less operand rounding), 'bf16', or 'fp32' (parity mode: fp32 operands on the exact-fp32 MFMA GEMM and an fp32
+        # attention kernel; window forward only, no per-frame runner).  Training always runs on the bf16 handle.
         self.compute_dtype = cfg.get("compute_dtype", "fp16")
-        if self.compute_dtype not in ("fp16", "bf16"):
-            raise PregoError(f"ViTEnc compute_dtype {self.compute_dtype!r}: 'fp16' or 'bf16' (16-bit MFMA operands; there is no fp32-operand transformer path)")
+        if self.compute_dtype not in ("fp16", "bf16", "fp32"):
+            raise PregoError(f"ViTEnc compute_dtype {self.compute_dtype!r}: 'fp16', 'bf16' or 'fp32'")
         self._h = None               # bf16 handle: training, and inference when compute_dtype == 'bf16'
         self._ver = None
-        self._h16 = None             # fp16 handle (inference only), own weight copies
+        self._h16 = None             # fp16 / fp32 handle (inference only), own weight copies
         self._ver16 = None
         self._ws = None
 
@@ -130,8 +131,8 @@ class ViTEnc(nn.Module):
         return lib, dev
 
     def _eval_handle(self):
-        """(lib, device, handle) of the inference entry points: the fp16-operand handle when compute_dtype == 'fp16'"""
-        if self.compute_dtype != "fp16":
+        """(lib, device, handle) of the inference entry points: the fp16- / fp32-operand handle when compute_dtype says so"""
+        if self.compute_dtype == "bf16":
             lib, dev = self._handle()
             return lib, dev, self._h
         dev = self.mlp_head.weight.device
@@ -143,7 +144,7 @@ class ViTEnc(nn.Module):
             with torch.cuda.device(dev):
                 check(lib.prego_vit_create(C.byref(h), self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim,
                                            self.num_heads, self.num_layers, self.img_dim, self.out_dim))
-                check(lib.prego_vit_set_compute_dtype(h, _lib.PREGO_F16))
+                check(lib.prego_vit_set_compute_dtype(h, _lib.PREGO_F32 if self.compute_dtype == "fp32" else _lib.PREGO_F16))
             self._h16 = h
         sd = dict(self.named_parameters())
         ver = tuple((p.data_ptr(), p._version) for p in sd.values())
@@ -327,8 +328,8 @@ class AttentionLayer:
 
     def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16"):
         self.lib = _lib.load()
-        if compute_dtype not in ("fp16", "bf16"):
-            raise PregoError(f"AttentionLayer compute_dtype {compute_dtype!r}: 'fp16' or 'bf16'")
+        if compute_dtype not in ("fp16", "bf16", "fp32"):
+            raise PregoError(f"AttentionLayer compute_dtype {compute_dtype!r}: 'fp16', 'bf16' or 'fp32'")
         self.compute_dtype = compute_dtype
         self.device = wq.device
         if self.device.type != "cuda":
@@ -337,7 +338,7 @@ class AttentionLayer:
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.prego_attention_layer_create(C.byref(h), self.d_model, self.n_heads))
-            check(self.lib.prego_attention_layer_set_compute_dtype(h, _lib.PREGO_F16 if compute_dtype == "fp16" else _lib.PREGO_BF16))
+            check(self.lib.prego_attention_layer_set_compute_dtype(h, {"fp16": _lib.PREGO_F16, "bf16": _lib.PREGO_BF16, "fp32": _lib.PREGO_F32}[compute_dtype]))
             ts = [t.detach().float().contiguous() for t in (wq, bq, wk, bk, wv, bv, wo, bo)]
             self.h = h
             check(self.lib.prego_attention_layer_set_weights(self.h, *[C.c_void_p(t.data_ptr()) for t in ts], C.c_void_p(_stream_ptr(self.device))))
