@@ -96,7 +96,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   };
   if constexpr (!WORKER) set_sources(m0, n0);
   // slot X of buffer b: A0 = 0, A1 = 1, B0 = 2, B1 = 3
+  // timing-only diagnostic builds (scripts/probes/pp_skip.sh; never the product library): -DPP_SKIP_DMA issues no LDS-DMA,
+  // -DPP_SKIP_READS re-reads no fragment inside the K loop - wrong results, the K loop's instruction mix minus that part
   auto stage_a = [&](int hf, int kt) {
+#ifdef PP_SKIP_DMA
+    return;
+#endif
     char* dst = smem + (kt & 1) * PBUF + hf * PHALF + wave * 2048;
     const int so = hf * 128 * lda * 2 + kt * (PBK * 2);
 #pragma unroll
@@ -104,6 +109,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, a_off[i], so, 0, 0);
   };
   auto stage_b = [&](int hf, int kt) {
+#ifdef PP_SKIP_DMA
+    return;
+#endif
     char* dst = smem + (kt & 1) * PBUF + (2 + hf) * PHALF + wave * 2048;
     const int so = hf * 128 * ldb * 2 + kt * (PBK * 2);
 #pragma unroll
@@ -195,6 +203,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #define DS(i) do { } while (0)
 #endif
 
+#ifdef PP_SKIP_READS
+  read_b(b0, 2, 0); read_b(b1, 3, 0); read_a(a1, 1, 0);
+#define read_a(...) do { } while (0)
+#define read_b(...) do { } while (0)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const bool full = kt + 2 < nk;                               // every issue of this tile's phases is real
     // phase 1
@@ -228,6 +241,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     mma(acc[1][0], a1, b0);
     bar();
   }
+#ifdef PP_SKIP_READS
+#undef read_a
+#undef read_b
+#endif
   if (grp == 0) bar();                                           // pairs with group 1's last barrier: every LDS read of this tile has retired
 
   const int cm0 = m0, cn0 = n0;
