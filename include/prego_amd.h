@@ -295,6 +295,11 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
                                    float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
                                    prego_stream_t stream);
 
+/* Debug / probe: only the head kernel over n_slots equal slots x n_steps steps of caller-supplied relu(h) rows (16-bit, the handle's
+ * operand type, time-major packed [n_steps][n_slots][hidden]); out [n_slots][n_steps][n_classes], argmax [n_slots][n_steps]. */
+int prego_debug_head_only(prego_miniroad* h, int n_slots, int n_steps, const void* h_relu, float* out, int32_t* argmax,
+                          const void* rowmap /* nullable: int32 (clip, frame) per row, as the pack kernel writes it */, prego_stream_t stream);
+
 /* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
  * recurrence kernel: out8[0..4] = rest of gather + mfma, step top -> first gather segment valid, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
  * [6] = time steps.  Synchronises the device. */

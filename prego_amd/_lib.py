@@ -32,7 +32,7 @@ SYMBOLS = [
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward",
     "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events",
-    "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype", "prego_debug_recurrence_only", "prego_debug_gemm_worker",
+    "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype", "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
 ]
 
 
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_handle_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_handle_workspace_bytes.restype = sz
     lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.prego_debug_head_only.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.prego_attention_layer_train_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_train_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward_train.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]

@@ -205,22 +205,38 @@ __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
       }                                                                                                                 \
     }                                                                                                                   \
   } while (0)
+  // Vector-memory operations retire IN ORDER, so what an iteration requests and uses itself must be requested BEFORE the next
+  // block's rows, and nothing may touch the prefetched rows before the iteration is over.  (The first form of this loop requested the
+  // row map entry and the two pointer-table entries of a frame behind the prefetch and let hipcc spread the nxt -> cur copies among the
+  // MFMAs, each behind the wait for its load: every iteration waited for the rows it had just requested, 6.5 us per 32 frames.)
+  // Now: the row map entry of the NEXT block and the table entries of THIS block go out first (the entry of this block was requested an
+  // iteration ago), then the next block's rows, unconditionally (block index clamped: one path, static wait counts); the table entries
+  // are first used in the epilogue (16 younger requests stay in flight) and the copies sit behind a scheduling barrier at the very end.
+  const int rq = (q & 1) * 16 + l15;                          // my frame inside a block (waves 2, 3 mirror 0, 1: dummy requests)
+  auto map_row = [&](int b) { int r = b * 32 + rq; return r < nrows ? r : nrows - 1; };
   int blk = blockIdx.x;
-  if (blk < nblk) HEAD_LOAD(cur, blk);
+  int2 ct = make_int2(0, 0), ctn = make_int2(0, 0);
+  if (blk < nblk) {
+    if (rowmap != nullptr) ct = rowmap[map_row(blk)];
+    HEAD_LOAD(cur, blk);
+  }
   int parity = 0;
   for (; blk < nblk; blk += gridDim.x) {
     const int bn = blk + gridDim.x;
-    if (bn < nblk) HEAD_LOAD(nxt, bn);                                        // in flight under this block
+    const int bnc = bn < nblk ? bn : blk;                                     // a block that exists (the last iteration re-requests its own)
+    float* op_raw = nullptr; int* ap_raw = nullptr;
+    if (rowmap != nullptr) {                                                  // kernel-uniform
+      op_raw = out_ptrs ? out_ptrs[ct.x] : nullptr;
+      ap_raw = argmax_ptrs ? argmax_ptrs[ct.x] : nullptr;
+      ctn = rowmap[map_row(bnc)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    HEAD_LOAD(nxt, bnc);                                                      // in flight under this block
+    __builtin_amdgcn_sched_barrier(0);
     // destination of my frame (waves 0 / 1 own frame tile q; every lane looks its frame l15 up: 4x redundant, off the MFMA path)
     float* op = nullptr; int* ap = nullptr;
     const int myrow = blk * 32 + q * 16 + l15;
-    if (q < 2 && myrow < nrows && rowmap != nullptr) {
-      const int2 ct = rowmap[myrow];
-      op = out_ptrs ? out_ptrs[ct.x] : nullptr;
-      if (op) op += (size_t)ct.y * C;
-      ap = argmax_ptrs ? argmax_ptrs[ct.x] : nullptr;
-      if (ap) ap += ct.y;
-    } else if (q < 2 && myrow < nrows) {
+    if (q < 2 && myrow < nrows && rowmap == nullptr) {
       const int row = row0 + myrow;
       // largest step with rowoff[step] <= row: start at the tabulated step of row 32 * (row / 32) and walk forward (a step holds
       // >= 1 row, typically 128: zero or one hop) - a binary search over the 34 k steps was ~16 dependent L2 round trips per block
@@ -258,6 +274,12 @@ __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
       for (int j = 0; j < NTC; ++j) pw[((q * 2 + 1) * NTC + j) * 64 + lane] = acc[1][j];
     }
     __syncthreads();
+    if (q < 2 && myrow < nrows && rowmap != nullptr) {                        // first use of the table entries: behind the MFMAs
+      op = op_raw;
+      if (op) op += (size_t)ct.y * C;
+      ap = ap_raw;
+      if (ap) ap += ct.y;
+    }
     if (q < 2) {
       float v[NTC][4];
 #pragma unroll
@@ -318,10 +340,12 @@ __global__ __launch_bounds__(256, 1) void head_softmax_v2_kernel(
       if (ap && g == 0) *ap = mi;
     }
     parity ^= 1;
+    __builtin_amdgcn_sched_barrier(0);                                        // the copies wait for the prefetch: last thing of the iteration
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) cur[t][ks] = nxt[t][ks];
+    ct = ctn;
   }
 #undef HEAD_LOAD
 }

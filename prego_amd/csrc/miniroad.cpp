@@ -828,6 +828,34 @@ extern "C" int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n
   return PREGO_OK;
 }
 
+// debug / probe: ONLY the head kernel (relu(h) rows -> probabilities + argmax) over n_slots equal slots x n_steps steps;
+// out [n_slots][n_steps][C] fp32, argmax [n_slots][n_steps].  scripts/probes/head_probe.py
+extern "C" int prego_debug_head_only(prego_miniroad* h, int n_slots, int n_steps, const void* h_relu, float* out, int32_t* argmax,
+                                     const void* rowmap, prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h || !h_relu || !out || !argmax) return fail(PREGO_EINVAL, "NULL argument");
+  if (!h->have_weights || !h->bf16) return fail(PREGO_EINVAL, "debug head: a bf16 / fp16 handle with weights");
+  if (n_slots < 1 || n_slots > max_clips_of(h) || n_steps < 1) return fail(PREGO_EINVAL, "debug head: %d slots, %d steps", n_slots, n_steps);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int32_t> lens((size_t)n_slots, n_steps);
+  int rc = build_plan(h, n_slots, lens.data(), true);
+  if (rc) return rc;
+  const SlotPlan plan = device_plan(h);
+  const int MC = max_clips_of(h);
+  std::vector<const void*> tab((size_t)4 * MC, nullptr);
+  for (int i = 0; i < n_slots; ++i) {
+    tab[2 * MC + i] = out + (size_t)i * n_steps * h->ncls;
+    tab[3 * MC + i] = argmax + (size_t)i * n_steps;
+  }
+  rc = stage_tables(h, tab.data(), tab.size(), s);
+  if (rc) return rc;
+  if (launch_head_softmax(true, h_relu, h->w_c, h->b_c, plan, 0, n_slots * n_steps, h->hid, h->ncls, 1, (float* const*)(h->d_ptrs + 2 * MC),
+                          (int* const*)(h->d_ptrs + 3 * MC), s, rowmap, h->f16))
+    return fail(PREGO_EINVAL, "debug head: unsupported num_classes %d", h->ncls);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
 // debug: per-phase shader-cycle sums of workgroup 0 / wave 0 of the recurrence kernel (PREGO_GRU_STAMPS=1):
 // out[0..4] = poll, mfma, reduce+barrier, gates+publish, outputs; out[5] = poll retry rounds; out[6] = time steps
 extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8) {
