@@ -44,6 +44,15 @@ for steps in (8, 64, 128, 256, 384, 768):
         best = min(best, a.elapsed_time(b) * 1e3)
     xs.append(rows); ys.append(best)
     print(f"{rows} rows: {best:.1f} us ({rows * 2048 / best / 1e6:.2f} TB/s of relu(h) rows)")
+# the two destination paths (row map / plan tables) must agree bit for bit
+o2 = torch.empty_like(out); a2 = torch.empty_like(arg)
+_lib.check(lib.prego_debug_head_only(eng.h, n_slots, steps, C.c_void_p(hr.data_ptr()), C.c_void_p(o2.data_ptr()), C.c_void_p(a2.data_ptr()), None,
+                                     C.c_void_p(s.cuda_stream)))
+_lib.check(lib.prego_debug_head_only(eng.h, n_slots, steps, C.c_void_p(hr.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(arg.data_ptr()),
+                                     C.c_void_p(rowmap.data_ptr()), C.c_void_p(s.cuda_stream)))
+torch.cuda.synchronize()
+print("row map vs plan tables: identical outputs", bool(torch.equal(out, o2) and torch.equal(arg, a2)),
+      "| probabilities sum to 1:", bool(torch.allclose(out.sum(1), torch.ones_like(out[:, 0]), atol=1e-4)))
 A = np.stack([np.array(xs, float), np.ones(len(xs))], 1)
 (slope, icpt), *_ = np.linalg.lstsq(A, np.array(ys), rcond=None)
 print(json.dumps({"us_per_1000_rows": slope * 1000, "us_per_launch": icpt}))
