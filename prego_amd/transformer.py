@@ -182,7 +182,10 @@ class ViTEnc(nn.Module):
         return {"logits": out.unsqueeze(1)}
 
     # -- per-frame inference over whole videos (the eval loop, trainer/eval.py:36-56) ------------------------------------------
-    windows_per_batch = 256          # windows that go through the encoder together (one ViTEnc forward of that batch size)
+    # windows that go through the encoder together (one ViTEnc forward of that batch size).  8 192-frame video, same device:
+    # 128: 221 k frames/s, 256: 275 k, 512: 329 k, 1 024: 347 k, 2 048: 366 k (scripts/probes/vit_wb_sweep.py); 1 024 windows = 2.9 GB
+    # of workspace
+    windows_per_batch = 1024
     max_clips = 64                   # Evaluate batches this many videos per call (each runs on its own: no cross-video batching)
 
     @torch.no_grad()
