@@ -15,7 +15,11 @@ scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 tmp = tempfile.mkdtemp()
 vl = os.path.join(tmp, "vl.json")
 json.dump({"ASSEMBLY101-O": {"class_index": [f"c{i}" for i in range(86)]}}, open(vl, "w"))
-cfg = assembly101_cfg(eval="ckpt.pth", video_list_path=vl, eval_output_dir=os.path.join(tmp, "out"), assume_zero_flow=True)
+extra = {}
+if os.environ.get("E2E_SPLIT"):
+    extra["eval_split_fraction"] = float(os.environ["E2E_SPLIT"])
+half = os.environ.get("E2E_FEATURE_DTYPE") == "fp16"       # the feeder's 16-bit features (cfg['feature_dtype'], prego_amd/data.py)
+cfg = assembly101_cfg(eval="ckpt.pth", video_list_path=vl, eval_output_dir=os.path.join(tmp, "out"), assume_zero_flow=True, **extra)
 sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
 model = build_model(cfg, "cuda:0"); model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); model.eval()
 lens = [max(8, int(l * scale)) for l in assembly101_eval_lengths(seed=20)[:n_clips]]
@@ -23,7 +27,7 @@ g = torch.Generator().manual_seed(5)
 items = []
 for i, T in enumerate(lens):
     tgt = torch.zeros(T, 86); tgt[torch.arange(T), (torch.arange(T) // 97 + i) % 86] = 1
-    items.append((torch.randn((1, T, 2048), generator=g).clamp_(min=0).pin_memory(), torch.zeros(1, 1, 2048).expand(1, T, 2048), tgt[None].pin_memory(), (f"v{i}",),
+    items.append(((torch.randn((1, T, 2048), generator=g).clamp_(min=0).half() if half else torch.randn((1, T, 2048), generator=g).clamp_(min=0)).pin_memory(), torch.zeros(1, 1, 2048).expand(1, T, 2048), tgt[None].pin_memory(), (f"v{i}",),
                   torch.tensor([0]), torch.tensor([T])))
 frames = sum(lens)
 ev = build_eval(cfg)
