@@ -42,7 +42,11 @@ enum {
 /* MFMA operand type of a handle.  Accumulators, GRU state, gate math, LayerNorm statistics and softmax are fp32 in every mode.
  * PREGO_F16: IEEE fp16 operands and 16-bit intermediates - the same matrix rate and bytes as bf16 with 8x less operand rounding
  * (values beyond +-65504 saturate); inference entry points only (forward without PREGO_FWD_KEEP, step). */
-enum { PREGO_F32 = 0, PREGO_BF16 = 1, PREGO_F16 = 2 };
+enum { PREGO_F32 = 0, PREGO_BF16 = 1, PREGO_F16 = 2, PREGO_F16X2 = 3 };
+/* PREGO_F16X2 ("fp16x2", round 4): split operands - every matrix operand travels as two fp16 numbers (hi + lo, ~22 mantissa bits) and
+ * every product is three fp16 MFMA products with fp32 accumulation; intermediates, state and the classifier stay fp32.  The
+ * argmax-identical mode of the north star (rnn.py:58-70: fp32-class results) at 3/16 of the matrix cost of PREGO_F32.  MiniROAD
+ * inference entry point only (prego_miniroad_forward without PREGO_FWD_KEEP / PREGO_FWD_IN16). */
 
 /* forward() flags */
 enum {

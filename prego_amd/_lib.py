@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PREGO_AMD_LIB") or os.path.join(_HERE, "lib", "libprego_amd.so")   # override: A/B builds
 
-PREGO_F32, PREGO_BF16, PREGO_F16 = 0, 1, 2
+PREGO_F32, PREGO_BF16, PREGO_F16, PREGO_F16X2 = 0, 1, 2, 3
 FWD_SOFTMAX, FWD_KEEP, FWD_IN16 = 1, 2, 4
 E_TIMEOUT = -4
 

@@ -69,6 +69,24 @@ template <> struct op16<f16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v_, a), __builtin_bit_cast(f16x8_v_, b), c, 0, 0, 0);
   }
 };
+// ---- split operands ("fp16x2", PREGO_F16X2): a value v travels as TWO fp16 numbers, hi = fp16(v) and lo = fp16(v - hi), i.e. ~22
+// mantissa bits, and a product a.b is taken as a_hi.b_lo + a_lo.b_hi + a_hi.b_hi on the fp16 matrix pipe with fp32 accumulation
+// (the dropped a_lo.b_lo term is 2^-22 relative: fp32 rounding noise).  Three 16-bit MFMA products = 3/16 of the cost of the
+// exact-fp32 MFMA at the same error class: the argmax-identical mode of the north star (rnn.py:58-70) without the 8.6x of
+// compute_dtype = 'fp32'.  Weights are pre-scaled by a power of two (exact) so that their lo halves stay in fp16's normal range
+// (|w| ~ 1e-2 would put w_lo ~ 2^-19 among the subnormals: 18 instead of 22 bits; the fp64-referenced emulation moves from
+// 1.1e-5 to 1.7e-6 worst probability error with the scale, scripts/precision_study.py); the epilogue multiplies the scale out.
+// Memory layout of a split row of n elements: [n hi | n lo] (raw fp16 bits), same bytes as the fp32 row.
+struct x2_t { unsigned v; };                                  // tag type only (sizeof 4 = bytes per split element)
+template <typename T> struct is_x2 { static constexpr bool value = false; };
+template <> struct is_x2<x2_t> { static constexpr bool value = true; };
+// two floats -> (hi pair, lo pair), both as packed fp16x2 words; hi saturates at +-65504
+__device__ __forceinline__ void x2_split2(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = op16<f16_t>::pack2_sat(a, b);
+  const float ra = a - op16<f16_t>::lo(hi), rb = b - op16<f16_t>::hi(hi);
+  lo = op16<f16_t>::pack2_sat(ra, rb);
+}
+
 // operand tag of an output element type: float stays float, 16-bit types name themselves
 template <typename T> struct is_op16 { static constexpr bool value = sizeof(T) == 2; };
 

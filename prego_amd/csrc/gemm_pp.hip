@@ -53,7 +53,11 @@ __device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >>
 // OT = operand type tag (common.h: bf16_t or f16_t): selects the MFMA opcode and the 16-bit output conversion only.
 // WORKER (probe of DESIGN 5c, prego_debug_gemm_worker): a persistent workgroup that leaves at once on XCDs below epi.xcd_lo and
 // otherwise claims tiles from the atomic counter epi.counter until none is left (m-major order: consecutive tiles share A rows).
-template <int EPI, typename OT = bf16_t, bool WORKER = false>
+// SPLIT (fp16x2 operands, common.h): A rows are [K hi | .. | K lo at column epi.split_a_lo], B rows likewise at epi.split_b_lo; the K
+// loop runs 3 K / 64 tiles - A_hi.B_lo, then A_lo.B_hi, then A_hi.B_hi (small terms first) - through the unchanged phase
+// structure: a K tile's column is a scalar function of its index, the LDS ring and every wait count stay as they are.  The
+// epilogue multiplies the weights' power-of-two scale out (epi.acc_scale: device pointer to 1 / scale) before the bias.
+template <int EPI, typename OT = bf16_t, bool WORKER = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
     void* __restrict__ Cv, int M, int N, int K, int lda, int ldb, int ldc, GemmEpi epi) {
@@ -66,7 +70,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   const int ntn = N / PBN;
   const int ntm = (M + PBM - 1) / PBM;
   const int ntiles = ntm * ntn;
-  const int nk = K / PBK;
+  const int nks = K / PBK;                                      // K tiles of one operand segment
+  const int nk = SPLIT ? 3 * nks : nks;
+  // element column of K tile kt in the A / B rows
+  auto acol = [&](int kt) -> int {
+    if constexpr (SPLIT) return kt < nks ? kt * PBK : (kt < 2 * nks ? (kt - nks) * PBK + epi.split_a_lo : (kt - 2 * nks) * PBK);
+    else return kt * PBK;
+  };
+  auto bcol = [&](int kt) -> int {
+    if constexpr (SPLIT) return kt < nks ? kt * PBK + epi.split_b_lo : (kt < 2 * nks ? (kt - nks) * PBK : (kt - 2 * nks) * PBK);
+    else return kt * PBK;
+  };
   int idx = blockIdx.x;
   int tile = WORKER ? 0 : pp_xcd_remap(idx, ntiles);
   int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     return;
 #endif
     char* dst = smem + (kt & 1) * PBUF + hf * PHALF + wave * 2048;
-    const int so = hf * 128 * lda * 2 + kt * (PBK * 2);
+    const int so = hf * 128 * lda * 2 + acol(kt) * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, a_off[i], so, 0, 0);
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     return;
 #endif
     char* dst = smem + (kt & 1) * PBUF + (2 + hf) * PHALF + wave * 2048;
-    const int so = hf * 128 * ldb * 2 + kt * (PBK * 2);
+    const int so = hf * 128 * ldb * 2 + bcol(kt) * 2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, b_off[i], so, 0, 0);
@@ -261,6 +275,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   const unsigned long long t_epi0 = __builtin_amdgcn_s_memtime();
 #endif
   const bool whole = cm0 + PBM <= M;                             // wave-uniform: all the stores of this wave are issued
+  float inv_scale = 1.f;
+  if constexpr (SPLIT) { if (epi.acc_scale) inv_scale = *epi.acc_scale; }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -269,7 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = cm0 + x * 128 + grp * 64 + i * 16 + fr;
-        const f32x4 v0 = acc[x][y][i][0], v1 = acc[x][y][i][1];
+        f32x4 v0 = acc[x][y][i][0], v1 = acc[x][y][i][1];
+        if constexpr (SPLIT) { v0 *= inv_scale; v1 *= inv_scale; }
         if (whole || m < M) {
           float o[8] = {v0[0] + bv[y][0].x, v0[1] + bv[y][0].y, v0[2] + bv[y][0].z, v0[3] + bv[y][0].w,
                         v1[0] + bv[y][1].x, v1[1] + bv[y][1].y, v1[2] + bv[y][1].z, v1[3] + bv[y][1].w};
@@ -407,6 +424,23 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
     default: PPL(EPI_QKV); break;
   }
 #undef PPL
+  return 0;
+}
+
+// split-operand (fp16x2) projection: C[M,N] fp32 = (A_hi + A_lo)[M,K] . (B_hi + B_lo)[N,K]^T * inv_scale + bias, three fp16 products.
+// A rows [.. lda fp16 ..] hold hi at column 0 and lo at column a_lo; B rows hi at 0 and lo at b_lo; any M (rows past M read as zeros).
+int launch_gemm_x2_pingpong(const void* A, int lda, int a_lo, const void* B, int ldb, int b_lo, const float* inv_scale, const float* bias,
+                            float* C, int ldc, int M, int N, int K, hipStream_t s) {
+  if (N % PBN || K % PBK || K < 2 * PBK || !bias || M <= 0) return -1;
+  const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
+  static DeviceOnce once;
+  once.run([&] {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PBUF);
+  });
+  GemmEpi epi{};
+  epi.mode = EPI_STORE; epi.f16 = 1; epi.split_a_lo = a_lo; epi.split_b_lo = b_lo; epi.acc_scale = inv_scale;
+  gemm_bf16_nt_pingpong_kernel<EPI_STORE, f16_t, false, true><<<ntiles, 512, 2 * PBUF, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb,
+                                                                                              ldc, epi);
   return 0;
 }
 

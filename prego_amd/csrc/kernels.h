@@ -100,6 +100,8 @@ struct GemmEpi {
   const float* pe;
   int f16;                     // operands (and every 16-bit output) are IEEE fp16 instead of bf16
   int xcd_lo; unsigned* counter;   // WORKER instantiation (probe): XCDs below xcd_lo leave at once; tiles are claimed from *counter
+  int split_a_lo, split_b_lo;      // SPLIT instantiation (fp16x2 operands): element column of the lo half in the A / B rows
+  const float* acc_scale;          // SPLIT: device pointer to 1 / (power-of-two scale of the weights); NULL = 1
 };
 void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
                              int N, int K, GemmEpi epi, hipStream_t s);
@@ -122,6 +124,17 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
                                   int K, GemmEpi epi, hipStream_t s);
 int launch_gemm_bf16_pingpong_worker(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
                                      int K, int xcd_lo, unsigned* counter, int grid, hipStream_t s, bool out16 = false, bool f16 = false);
+int launch_gemm_x2_pingpong(const void* A, int lda, int a_lo, const void* B, int ldb, int b_lo, const float* inv_scale, const float* bias,
+                            float* C, int ldc, int M, int N, int K, hipStream_t s);
+void launch_x2_weight_split(const float* src, int rows, int cols, void* dst, float* scale2 /* device [2]: scale, 1 / scale */, hipStream_t s);
+void launch_pack_rows_x2(const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan, int row0, int nrows,
+                         int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit = 0, void* rowmap = nullptr);
+void launch_ln_relu_x2(const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps, void* out, hipStream_t s,
+                       const GruArm* arm = nullptr);
+// split-operand recurrence (gru_recurrence_x2.hip): a.whh = [3H][2H] split rows of W_hh * scale, a.gi fp32, a.h_relu_out fp32
+int launch_gru_recurrence_x2(int hid, int nct, GruArgs a, const float* inv_scale, hipStream_t s);
+size_t gru_x2_hx_bytes(int hid, int G);
+GruArm gru_x2_arm_desc(int hid, int G, void* hx, unsigned* sync);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,

@@ -55,6 +55,8 @@ struct prego_miniroad {
   int d_rgb, d_flow, emb, hid, ncls, ncls_pad;
   bool bf16;                    // 16-bit MFMA operands (bf16, or IEEE fp16 when f16 is set as well); false = exact-fp32 MFMA
   bool f16 = false;             // PREGO_F16: the 16-bit operand / intermediate type is fp16 (inference entry points only)
+  bool x2 = false;              // PREGO_F16X2: split fp16 operands (hi + lo, three products; csrc/common.h), fp32 intermediates; bf16 is false
+  float* x2_scale = nullptr;    // device [3][2]: (scale, 1 / scale) of w1, w_ih, w_hh (powers of two chosen by set_weights)
   int n_cu;
   int G, P;                     // recurrence groups / workgroups per group
   // ingested weights (device, handle-owned)
@@ -129,7 +131,8 @@ struct HandleScope {
 };
 extern "C" const char* prego_miniroad_last_error(const prego_miniroad* h) { return h ? h->err.c_str() : "handle is NULL"; }
 
-static int max_slots_of(const prego_miniroad* h) { return h->G * 16 * gru_max_tiles(); }
+// split-operand recurrence: two clip tiles per group at most (the four-tile instantiation would spill: 2 x 96 weight registers)
+static int max_slots_of(const prego_miniroad* h) { return h->G * 16 * (h->x2 ? 2 : gru_max_tiles()); }
 #define PREGO_MAX_CLIPS 8192     // clips per call (continuous batching packs them into <= max_slots slots)
 static int max_clips_of(const prego_miniroad*) { return PREGO_MAX_CLIPS; }
 
@@ -140,7 +143,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
                                      int compute_dtype) {
   if (!out) return fail(PREGO_EINVAL, "out is NULL");
   *out = nullptr;
-  if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16) return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
+  if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16 && compute_dtype != PREGO_F16X2)
+    return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
   if (hid != 1024) return fail(PREGO_EINVAL, "hidden_dim %d unsupported: the register-resident recurrence is built for 1024", hid);
   if (emb <= 0 || emb % 512 || emb > 4096) return fail(PREGO_EINVAL, "embedding_dim %d must be a multiple of 512, <= 4096", emb);
   if (d_rgb < 0 || d_flow < 0 || d_rgb + d_flow <= 0 || (d_rgb % 64) || (d_flow % 64))
@@ -153,8 +157,9 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   prego_miniroad* h = new prego_miniroad();
   h->d_rgb = d_rgb; h->d_flow = d_flow; h->emb = emb; h->hid = hid; h->ncls = n_classes;
   h->ncls_pad = (n_classes + 15) / 16 * 16;
-  h->bf16 = compute_dtype != PREGO_F32;
+  h->bf16 = compute_dtype == PREGO_BF16 || compute_dtype == PREGO_F16;
   h->f16 = compute_dtype == PREGO_F16;
+  h->x2 = compute_dtype == PREGO_F16X2;      // operand storage 4 bytes per element ([hi | lo] fp16), P = 64, G = 4 like fp32 operands
   h->n_cu = prop.multiProcessorCount;
   h->P = h->bf16 ? 32 : 64;
   h->G = std::min(h->bf16 ? 8 : 4, h->n_cu / h->P);
@@ -167,7 +172,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A(&h->w_ih, (size_t)3 * H * emb * es); A(&h->w_hh, (size_t)3 * H * H * es);
   A((void**)&h->bias2, 3 * H * 4); A((void**)&h->b_hn, H * 4);
   A(&h->w_c, (size_t)h->ncls_pad * H * es); A((void**)&h->b_c, h->ncls_pad * 4);
-  A(&h->hx, gru_hx_bytes(h->bf16, H, h->G));
+  A(&h->hx, h->x2 ? gru_x2_hx_bytes(H, h->G) : gru_hx_bytes(h->bf16, H, h->G));
+  if (h->x2) A((void**)&h->x2_scale, 6 * sizeof(float));
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   A((void**)&h->h_state, (size_t)max_slots_of(h) * H * 4);
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
@@ -198,7 +204,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
-  if (e == hipSuccess) e = hipMemset(h->hx, 0, gru_hx_bytes(h->bf16, H, h->G));
+  if (e == hipSuccess) e = hipMemset(h->hx, 0, h->x2 ? gru_x2_hx_bytes(H, h->G) : gru_hx_bytes(h->bf16, H, h->G));
   if (e == hipSuccess) e = hipMemset(h->flags, 0, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   if (e != hipSuccess) { prego_miniroad_destroy(h); return fail(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
   h->abort_word = h->flags + (size_t)h->G * h->P;
@@ -210,7 +216,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->tile_ctr, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
@@ -233,9 +239,15 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
     return fail(PREGO_EINVAL, "set_weights: NULL tensor");
   hipStream_t s = (hipStream_t)stream;
   const int din = h->d_rgb + h->d_flow, E = h->emb, H = h->hid;
-  launch_pad_convert(h->bf16, layer1_w, E, din, din, h->w1, E, din, s, h->f16);
-  launch_pad_convert(h->bf16, w_ih, 3 * H, E, E, h->w_ih, 3 * H, E, s, h->f16);
-  launch_pad_convert(h->bf16, w_hh, 3 * H, H, H, h->w_hh, 3 * H, H, s, h->f16);
+  if (h->x2) {                   // split rows [cols hi | cols lo] of W * 2^k, k per tensor (common.h)
+    launch_x2_weight_split(layer1_w, E, din, h->w1, h->x2_scale + 0, s);
+    launch_x2_weight_split(w_ih, 3 * H, E, h->w_ih, h->x2_scale + 2, s);
+    launch_x2_weight_split(w_hh, 3 * H, H, h->w_hh, h->x2_scale + 4, s);
+  } else {
+    launch_pad_convert(h->bf16, layer1_w, E, din, din, h->w1, E, din, s, h->f16);
+    launch_pad_convert(h->bf16, w_ih, 3 * H, E, E, h->w_ih, 3 * H, E, s, h->f16);
+    launch_pad_convert(h->bf16, w_hh, 3 * H, H, H, h->w_hh, 3 * H, H, s, h->f16);
+  }
   launch_pad_convert(h->bf16, fc_w, h->ncls, H, H, h->w_c, h->ncls_pad, H, s, h->f16);
   launch_pad_convert(false, fc_b, 1, h->ncls, h->ncls, h->b_c, 1, h->ncls_pad, s);
   HIPCHK(hipMemcpyAsync(h->b1, layer1_b, E * 4, hipMemcpyDeviceToDevice, s));
@@ -491,6 +503,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   hipStream_t s = (hipStream_t)stream;
   if (h->f16 && (flags & PREGO_FWD_KEEP))
     return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) on an fp16-operand handle: training runs on bf16 / fp32 handles");
+  if (h->x2 && (flags & PREGO_FWD_KEEP))
+    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) on a split-operand (fp16x2) handle: training runs on bf16 / fp32 handles");
   const bool in16 = (flags & PREGO_FWD_IN16) != 0;
   if (in16 && !h->bf16) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 on an fp32-operand handle (16-bit features go with bf16 / fp16 handles)");
   if (in16 && (flags & PREGO_FWD_KEEP)) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 with PREGO_FWD_KEEP: training takes fp32 features");
@@ -542,6 +556,11 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const bool i16 = inter16(h, flags);
   // projection with fp32 or bf16 output: ping-pong kernel for whole-chip shapes, the 128x128 kernel with a bf16-store epilogue below
   auto proj = [&](const void* A, int lda, const void* Wt, int ldb, const float* bias, void* Cout, int ldc, int M, int N, int K) {
+    if (h->x2) {                    // A rows [K hi | K lo] (lda = K), W rows [ldb hi | ldb lo]: three fp16 products, fp32 C
+      const float* inv = h->x2_scale + (Wt == h->w1 ? 1 : 3);
+      (void)launch_gemm_x2_pingpong(A, 2 * lda, lda, Wt, 2 * ldb, ldb, inv, bias, (float*)Cout, ldc, M, N, K, s);
+      return;
+    }
     if (!h->bf16) { launch_gemm_f32_nt((const float*)A, lda, (const float*)Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
     if (!i16 && !h->f16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
     if (M >= 4096 && launch_gemm_bf16_pingpong_mode(0, A, lda, Wt, ldb, bias, Cout, ldc, M, N, K, i16, s, h->f16) == 0) return;
@@ -582,6 +601,10 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   auto pack_chunk = [&](int t0_, int t1_, hipStream_t st, int ci_) {
     const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
     EventPair* evp = ev_begin(h, 2, st);
+    if (h->x2)
+      launch_pack_rows_x2(d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
+                          st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8);
+    else
     launch_pack_rows(h->bf16, d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
                      st == s ? 0 : h->prefetch_grid, RM + (size_t)(ci_ & 1) * cap_rows * 8, h->f16, in16);
     ev_end(evp, st);
@@ -627,7 +650,10 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     // the LayerNorm launch also re-arms the recurrence's exchange buffers and rendezvous words (it runs after the previous recurrence
     // launch of this stream and before the next): one launch and one launch gap fewer per chunk (PREGO_NO_ARM_FUSE=1: A/B)
     static const bool arm_fuse = getenv("PREGO_NO_ARM_FUSE") == nullptr;
-    const GruArm arm = gru_arm_desc(h->bf16, h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags);
+    const GruArm arm = h->x2 ? gru_x2_arm_desc(h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags)
+                             : gru_arm_desc(h->bf16, h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags);
+    if (h->x2) launch_ln_relu_x2((const float*)Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, s, arm_fuse ? &arm : nullptr);
+    else
     launch_ln_relu(h->bf16, Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, STATS, keep ? h->drop_p : 0.f, h->drop_seed, base, s, 1, i16, h->f16,
                    arm_fuse ? &arm : nullptr);
     ev = ev_begin(h, 0, s);
@@ -681,7 +707,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     // slots have thinned out run the kernels for fewer tiles (fewer registers; one tile = the classic kernel)
     const int live_slots = h->h_nact[t0];
     const int nct_l = std::max(1, std::min(nct, (((live_slots + h->G - 1) / h->G) + 15) / 16));
-    if (launch_gru_recurrence(h->bf16, H, nct_l, ga, s)) return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct_l);
+    if (h->x2 ? launch_gru_recurrence_x2(H, nct_l, ga, h->x2_scale + 5, s) : launch_gru_recurrence(h->bf16, H, nct_l, ga, s))
+      return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct_l);
     ev_end(ev, s);
     if (prefetch_next) {
       // X is dead once the layer1 GEMM of this chunk has run: stream the next chunk's features into it while the recurrence
@@ -721,7 +748,7 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "step before set_weights");
-  if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 / fp16 handles (fp32 operands: use forward() with h0 / h_last)");
+  if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 / fp16 handles (fp32 / fp16x2 operands: use forward() with h0 / h_last)");
   if (n_streams < 1 || n_streams > 16) return fail(PREGO_EINVAL, "step: %d streams (1..16 per call)", n_streams);
   if (!h_state) return fail(PREGO_EINVAL, "step: h_state is NULL");
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "step: rgb is NULL");
@@ -982,7 +1009,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   if (!h || !lens || !dlogits || !fwd_workspace || !bwd_workspace) return fail(PREGO_EINVAL, "backward: NULL argument");
   if (!g_layer1_w || !g_layer1_b || !g_ln_w || !g_ln_b || !g_w_ih || !g_w_hh || !g_b_ih || !g_b_hh || !g_fc_w || !g_fc_b)
     return fail(PREGO_EINVAL, "backward: NULL gradient tensor");
-  if (h->f16) return fail(PREGO_EINVAL, "backward on an fp16-operand handle: training runs on bf16 / fp32 handles");
+  if (h->f16 || h->x2) return fail(PREGO_EINVAL, "backward on an fp16 / fp16x2-operand handle: training runs on bf16 / fp32 handles");
   if ((int)h->plan_lens.size() != n_clips || !std::equal(lens, lens + n_clips, h->plan_lens.begin()) || h->kept_rows == 0)
     return fail(PREGO_EINVAL, "backward must follow a forward(PREGO_FWD_KEEP) of the same clips");
   hipStream_t s = (hipStream_t)stream;
@@ -1153,7 +1180,7 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
   HandleScope scope_(h);
   if (!h || !params || !grads || !exp_avg || !exp_avg_sq) return fail(PREGO_EINVAL, "adamw: NULL argument");
   if (!h->have_weights) return fail(PREGO_EINVAL, "adamw step before set_weights");
-  if (h->f16) return fail(PREGO_EINVAL, "adamw step on an fp16-operand handle: training runs on bf16 / fp32 handles");
+  if (h->f16 || h->x2) return fail(PREGO_EINVAL, "adamw step on an fp16 / fp16x2-operand handle: training runs on bf16 / fp32 handles");
   hipStream_t s = (hipStream_t)stream;
   const long long din = h->d_rgb + h->d_flow, E = h->emb, H = h->hid, C = h->ncls;
   // set_weights order: layer1.0.weight, layer1.0.bias, layer1.1.weight, layer1.1.bias, w_ih, w_hh, b_ih, b_hh, fc.weight, fc.bias

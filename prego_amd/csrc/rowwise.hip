@@ -48,7 +48,14 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
         a = make_float4(0, 0, 0, 0);
         b = a;
       }
-      if constexpr (sizeof(OutT) == 2) {
+      if constexpr (is_x2<OutT>::value) {        // split row [din hi | din lo] of raw fp16 (common.h)
+        uint4 oh, ol;
+        x2_split2(a.x, a.y, oh.x, ol.x); x2_split2(a.z, a.w, oh.y, ol.y);
+        x2_split2(b.x, b.y, oh.z, ol.z); x2_split2(b.z, b.w, oh.w, ol.w);
+        bf16_t* d16 = (bf16_t*)dst;              // dst = X + r * din of 4-byte elements = row start
+        *(uint4*)(d16 + c) = oh;
+        *(uint4*)(d16 + din + c) = ol;
+      } else if constexpr (sizeof(OutT) == 2) {
         uint4 o;
         o.x = op16<OutT>::pack2_sat(a.x, a.y); o.y = op16<OutT>::pack2_sat(a.z, a.w);
         o.z = op16<OutT>::pack2_sat(b.x, b.y); o.w = op16<OutT>::pack2_sat(b.z, b.w);
@@ -129,7 +136,14 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
           if (relu) o[k] = fmaxf(o[k], 0.f);
           if (thresh) o[k] = dropout_keep_(seed, (size_t)(row0_abs + r) * E + c + k, thresh) ? o[k] * keep_scale : 0.f;
         }
-        if constexpr (sizeof(OutT) == 2) {
+        if constexpr (is_x2<OutT>::value) {      // split row [E hi | E lo]: the W_ih GEMM's A operand
+          uint4 wh, wl;
+          x2_split2(o[0], o[1], wh.x, wl.x); x2_split2(o[2], o[3], wh.y, wl.y);
+          x2_split2(o[4], o[5], wh.z, wl.z); x2_split2(o[6], o[7], wh.w, wl.w);
+          bf16_t* o16 = (bf16_t*)out + (size_t)r * 2 * E;
+          *(uint4*)(o16 + c) = wh;
+          *(uint4*)(o16 + E + c) = wl;
+        } else if constexpr (sizeof(OutT) == 2) {
           uint4 w;
           w.x = op16<OutT>::pack2_sat(o[0], o[1]); w.y = op16<OutT>::pack2_sat(o[2], o[3]); w.z = op16<OutT>::pack2_sat(o[4], o[5]); w.w = op16<OutT>::pack2_sat(o[6], o[7]);
           *(uint4*)(out + (size_t)r * E + c) = w;
@@ -160,6 +174,51 @@ __global__ void pad_convert_kernel(const float* __restrict__ src, int rows_src, 
   }
 }
 
+// ---- split-operand weights (fp16x2, common.h): scale = the power of two that puts max|W| in [8192, 16384), then
+// row r of dst = [cols hi | cols lo] of W * scale as raw fp16.  scale_out[0] = scale, [1] = 1 / scale (both exact).
+__global__ void x2_weight_scale_kernel(const float* __restrict__ src, size_t n, float* __restrict__ scale_out) {
+  __shared__ float red[1024];
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(src[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float mx = red[0];
+    int e = 0;
+    float sc = 1.f;
+    if (mx > 0.f && mx < 3.0e38f) {
+      frexpf(mx, &e);                            // mx = f * 2^e, f in [0.5, 1)
+      sc = ldexpf(1.f, 14 - e);                  // mx * sc in [8192, 16384)
+    }
+    scale_out[0] = sc;
+    scale_out[1] = 1.f / sc;
+  }
+}
+__global__ void x2_weight_split_kernel(const float* __restrict__ src, int rows, int cols, const float* __restrict__ scale,
+                                       bf16_t* __restrict__ dst) {
+  const float sc = scale[0];
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols, c = i % cols;
+    const float v = src[i] * sc;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    dst[r * 2 * cols + c] = __builtin_bit_cast(bf16_t, hi);
+    dst[r * 2 * cols + cols + c] = __builtin_bit_cast(bf16_t, lo);
+  }
+}
+void launch_x2_weight_split(const float* src, int rows, int cols, void* dst, float* scale2, hipStream_t s) {
+  x2_weight_scale_kernel<<<1, 1024, 0, s>>>(src, (size_t)rows * cols, scale2);
+  const size_t n = (size_t)rows * cols;
+  int grid = (int)((n + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  x2_weight_split_kernel<<<grid, 256, 0, s>>>(src, rows, cols, scale2, (bf16_t*)dst);
+}
+
 // ------------------------------------------------------------------------------------------
 // host launchers (called from miniroad.cpp)
 // ------------------------------------------------------------------------------------------
@@ -178,6 +237,25 @@ void launch_pack_rows(bool bf16, const float* const* rgb_ptrs, const float* cons
     pack_rows_kernel<bf16_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (bf16_t*)X, (int2*)rowmap);
   else
     pack_rows_kernel<float><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (float*)X, (int2*)rowmap);
+}
+
+// split-operand (fp16x2) feature rows: fp32 features -> [din hi | din lo] fp16 rows
+void launch_pack_rows_x2(const float* const* rgb_ptrs, const float* const* flow_ptrs, const SlotPlan& plan, int row0, int nrows,
+                         int d_rgb, int d_flow, void* X, hipStream_t s, int grid_limit, void* rowmap) {
+  if (nrows <= 0) return;
+  int grid = nrows < 65536 ? nrows : 65536;
+  if (grid_limit > 0 && grid > grid_limit) grid = grid_limit;
+  pack_rows_kernel<x2_t><<<grid, 256, 0, s>>>(rgb_ptrs, flow_ptrs, plan, row0, nrows, d_rgb, d_flow, (x2_t*)X, (int2*)rowmap);
+}
+// LayerNorm + ReLU of fp32 rows -> split rows [E hi | E lo] (inference only: no dropout, no statistics kept)
+void launch_ln_relu_x2(const float* Y, const float* gamma, const float* beta, int nrows, int E, float eps, void* out, hipStream_t s,
+                       const GruArm* armp) {
+  if (nrows <= 0) return;
+  const GruArm arm = armp ? *armp : GruArm{nullptr, 0ull, 0u, nullptr};
+  int grid = (nrows + 3) / 4;
+  if (grid > 16384) grid = 16384;
+  if (E <= 2048) ln_relu_rows_kernel<x2_t, 4><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (x2_t*)out, nullptr, 0.f, 0ull, 0, 1, arm);
+  else ln_relu_rows_kernel<x2_t, 8><<<grid, 256, 0, s>>>(Y, gamma, beta, nrows, E, eps, (x2_t*)out, nullptr, 0.f, 0ull, 0, 1, arm);
 }
 
 void launch_ln_relu(bool bf16, const void* Yv, const float* gamma, const float* beta, int nrows, int E, float eps, void* out,

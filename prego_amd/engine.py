@@ -46,7 +46,7 @@ class MiniRoadEngine:
         self.dims = (d_rgb, d_flow, emb, hid, n_classes)
         self.compute_dtype = compute_dtype
         h = C.c_void_p()
-        codes = {"bf16": _lib.PREGO_BF16, "fp16": _lib.PREGO_F16, "fp32": _lib.PREGO_F32}
+        codes = {"bf16": _lib.PREGO_BF16, "fp16": _lib.PREGO_F16, "fp32": _lib.PREGO_F32, "fp16x2": _lib.PREGO_F16X2}
         if compute_dtype not in codes:
             raise PregoError(f"compute_dtype {compute_dtype!r}: expected one of {sorted(codes)}")
         with torch.cuda.device(self.device):
@@ -106,7 +106,7 @@ class MiniRoadEngine:
         h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
         lens = [int(r.shape[0]) for r in src_list]
         single = h0 is not None or want_h_last
-        for idx in plan_passes(lens, self.max_clips, single, 256 if self.compute_dtype == "fp32" else 512):
+        for idx in plan_passes(lens, self.max_clips, single, {"fp32": 256, "fp16x2": 128}.get(self.compute_dtype, 512)):
             sub_h0 = None if h0 is None else h0[idx].contiguous()
             sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
             sub_out, sub_arg = [None] * len(idx), [None] * len(idx)
@@ -191,7 +191,7 @@ class MiniRoadEngine:
             out = torch.empty((n, ncls), dtype=torch.float32, device=self.device)
         if argmax is None:
             argmax = torch.empty((n,), dtype=torch.int32, device=self.device)
-        if self.compute_dtype == "fp32":
+        if self.compute_dtype in ("fp32", "fp16x2"):
             rl = [rgb[i:i + 1] for i in range(n)] if d_rgb > 0 else None
             fl = [flow[i:i + 1] for i in range(n)] if flow is not None else None
             o, a, hl = self.forward_ragged(rl, fl, softmax=softmax, want_out=True, want_argmax=True, h0=h, want_h_last=True)

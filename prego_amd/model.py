@@ -44,7 +44,7 @@ class MROAD(nn.Module):
         )
         self.f_classification = nn.Sequential(nn.Linear(self.hidden_dim, self.out_dim))
         # build-specific knobs (not reference keys)
-        self.compute_dtype = cfg.get("compute_dtype", "fp16")          # 'fp16' | 'bf16' | 'fp32'
+        self.compute_dtype = cfg.get("compute_dtype", "fp16")          # 'fp16' | 'bf16' | 'fp32' | 'fp16x2' (split operands: fp32-class results)
         self.assume_zero_flow = bool(cfg.get("assume_zero_flow", False))  # dataset.py:69 zeroes the flow half
         self.grad_compress = cfg.get("grad_compress")                    # None | 'bf16': data-parallel gradient all-reduce on bf16 (half the bytes)
         self._engines = {}            # (device, operand dtype) -> [MiniRoadEngine, parameter versions its copies belong to]
@@ -53,6 +53,8 @@ class MROAD(nn.Module):
     def _engine_dtype(self, train: bool) -> str:
         # fp16 operands are an inference mode (same speed as bf16, 8x less operand rounding); the training kernels (kept
         # activations, BPTT, wgrads, fused AdamW copies) take bf16 / fp32 handles
+        if train and self.compute_dtype == "fp16x2":
+            return "fp32"           # the split-operand mode is inference only; its training counterpart is the exact-fp32 engine
         return "bf16" if (train and self.compute_dtype == "fp16") else self.compute_dtype
 
     @property

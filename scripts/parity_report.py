@@ -1,9 +1,9 @@
 """Argmax bookkeeping of the north star ("identical argmax action sequences") against the reference fixtures, kept as data:
 for G1 (cfg1, plain and peaky head), G1c (head gain 32, trained-like), G2 (T = 4096 with flow, T = 31 114) and G7 (Evaluate end
-to end) in fp16, bf16 and fp32 operand modes: frames, argmax mismatches, the LARGEST reference top-1/top-2 margin among the mismatching frames (the
+to end) in fp16, bf16, fp32 and fp16x2 (split-operand) modes: frames, argmax mismatches, the LARGEST reference top-1/top-2 margin among the mismatching frames (the
 "smallest margin that was still violated" bound: every frame whose margin exceeds it agrees), max |dprob|.
 
-    python scripts/parity_report.py gpurun_out/parity_r03.json      # on the GPU box; copy the file to profiles/
+    python scripts/parity_report.py gpurun_out/parity_r04.json [fp16x2,fp32]     # on the GPU box; copy the file to profiles/
 """
 import json
 import os
@@ -36,11 +36,15 @@ def entry(got_arg, ref_arg, margin, dprob):
             "smallest_reference_margin": float(margin.min()), "max_abs_dprob": float(dprob)}
 
 
+DTYPES = ("fp16", "bf16", "fp32", "fp16x2")
+
+
 def main(out_path):
-    rep = {"note": "fp16 / bf16 = 16-bit MFMA operands and 16-bit Y / GI between the kernels, fp32 accumulation; fp32 = exact-fp32 MFMA.  Margins are the reference's top-1 minus "
+    rep = {"note": "fp16 / bf16 = 16-bit MFMA operands and 16-bit Y / GI between the kernels, fp32 accumulation; fp32 = exact-fp32 MFMA; fp16x2 = split fp16 operands "
+                   "(hi + lo, three MFMA products per product), fp32 intermediates.  Margins are the reference's top-1 minus "
                    "top-2 probability at that frame; random-init weights put many frames below any usable margin."}
     cfg = assembly101_cfg()
-    for dtype in ("fp16", "bf16", "fp32"):
+    for dtype in DTYPES:
         g = np.load(os.path.join(G, "g1c_miniroad_eval_gain32.npz"))
         m = model(cfg, W.miniroad_state_dict(cfg, 20, head_gain=32.0), dtype)
         outs, args, _ = m.engine().forward_ragged([torch.from_numpy(W.tsn_features((1024, 2048), 20, "g1c.rgb")).cuda()],
@@ -59,8 +63,6 @@ def main(out_path):
         sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
         m = model(cfg, sd, dtype)
         for T, with_flow in ((4096, True), (31114, False)):
-            if dtype == "fp32" and T == 31114:
-                continue
             g = np.load(os.path.join(G, f"g2_miniroad_longT_{T}.npz"))
             rgb = torch.from_numpy(W.tsn_features((T, 2048), 20, f"g2.rgb.{T}")).cuda()
             flow = [torch.from_numpy(W.tsn_features((T, 2048), 20, f"g2.flow.{T}")).cuda()] if with_flow else None
@@ -96,4 +98,6 @@ def main(out_path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_r03.json")
+    if len(sys.argv) > 2:
+        DTYPES = tuple(sys.argv[2].split(","))
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_r04.json")
