@@ -28,8 +28,10 @@ extern "C" {
 #endif
 
 /* 1: round 1.  2: round 2 entry points (step, adamw, vit, attention layer, window vote) and the grown forward workspace.
- * 3: round 3 (fp16 operand mode, device AP, window_vote marks windows with an id outside [0, n_classes) as -1). */
-#define PREGO_ABI_VERSION 3
+ * 3: round 3 (fp16 operand mode, device AP, window_vote marks windows with an id outside [0, n_classes) as -1).
+ * 4: round 4 (PREGO_F16X2 split-operand mode; the prego_debug_* / _debug_stamps entry points left this header and the product library:
+ *    prego_amd_debug.h / libprego_amd_debug.so). */
+#define PREGO_ABI_VERSION 4
 
 enum {
   PREGO_OK = 0,
@@ -299,41 +301,16 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
                                    float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
                                    prego_stream_t stream);
 
-/* Debug / probe: only the head kernel over n_slots equal slots x n_steps steps of caller-supplied relu(h) rows (16-bit, the handle's
- * operand type, time-major packed [n_steps][n_slots][hidden]); out [n_slots][n_steps][n_classes], argmax [n_slots][n_steps]. */
-int prego_debug_head_only(prego_miniroad* h, int n_slots, int n_steps, const void* h_relu, float* out, int32_t* argmax,
-                          const void* rowmap /* nullable: int32 (clip, frame) per row, as the pack kernel writes it */, prego_stream_t stream);
-
-/* Debug only (env PREGO_GRU_STAMPS=1 at create): per-phase shader-cycle sums of workgroup 0 / wave 0 of the
- * recurrence kernel: out8[0..4] = rest of gather + mfma, step top -> first gather segment valid, reduce+barrier, gates+publish, outputs; [5] = gather retry rounds;
- * [6] = time steps.  Synchronises the device. */
-int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long* out8);
-
-/* Probes of DESIGN.md section 5c (scripts/probes/xcd_overlap_probe.py), not product entry points: ONLY the recurrence kernel over
- * n_steps steps of n_slots equal slots dealt to gd groups (0 = all; gi: device 16-bit [n_steps * n_slots][3 H], h_relu: device 16-bit
- * [rows][H]); and the projection GEMM as a persistent worker that leaves XCDs below xcd_lo at once and claims 256 x 256 tiles from
- * *counter (device word, zero at launch). */
-int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n_steps, int gd, const void* gi, void* h_relu, prego_stream_t stream);
-int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int xcd_lo,
-                            unsigned* counter, int grid, prego_stream_t stream);
-
-/* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
- * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
-int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,
-                          prego_stream_t stream);
-
-/* Debug / unit test only: the attention backward kernels alone.  qs (= q * dh^-0.5), k, v: device bf16 [batch, heads, len, dh];
- * o, dout: device bf16 [batch, len, heads*dh]; lse: device fp32 [batch, heads, len] log-sum-exp of the scaled scores;
- * dqkv: device bf16 [batch*len, 3*heads*dh] (dq | dk | dv, dq wrt the unscaled q).  Synchronises the stream. */
-int prego_debug_attention_bwd(int batch, int len, int heads, int dh, int causal, const void* qs, const void* k, const void* v,
-                              const void* o, const void* dout, const float* lse, void* dqkv, prego_stream_t stream);
-
-/* Debug / unit test only: the attention forward kernel alone (every head-dim / shape variant is reachable from here).
- * qs (= q * dh^-0.5): device bf16 [batch, heads, n_query, dh], queries at sequence positions 0 .. n_query-1; k, v: device bf16
- * [batch, heads, len, dh]; out: device bf16 [batch, n_query, heads*dh]; lse: device fp32 [batch, heads, n_query] or NULL.
- * Synchronises the stream. */
-int prego_debug_attention_fwd(int batch, int n_query, int len, int heads, int dh, int causal, const void* qs, const void* k,
-                              const void* v, void* out, float* lse, prego_stream_t stream);
+/* Environment knobs the library reads (each ONCE, when a handle is created or a launcher is first used; none is needed in
+ * production, every one selects between two code paths that both stay tested - DESIGN.md section 6 says what each measured):
+ *   PREGO_NO_XCD_OVERLAP, PREGO_OVERLAP_NARROW, PREGO_OVERLAP_MAX_GD, PREGO_GRU_COMPACT   layer1 worker on the XCDs the recurrence left
+ *   PREGO_GRU_NO_MT, PREGO_GRU_MT_SPEC, PREGO_GRU_NO_LOCAL, PREGO_GRU_STAMPS, PREGO_NO_ARM_FUSE   recurrence kernel choice / hand-off
+ *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY                     where the next chunk's pack runs
+ *   PREGO_PLAN_SLOTS, PREGO_FP32_INTERMEDIATES                                             planner calibration, fp32 Y / GI in 16-bit modes
+ *   PREGO_GEMM_NO_PINGPONG, PREGO_GEMM_NO_BIG, PREGO_HEAD_V1, PREGO_BPTT_STEPWISE, PREGO_STEP_NO_LN_FUSE, PREGO_VIT_TOKENS_KERNEL,
+ *   PREGO_ATTN_NW                                                                          older kernels kept as A/B references
+ * The probe / unit-test entry points (prego_debug_*, prego_miniroad_debug_stamps) are NOT part of this library: they are declared in
+ * prego_amd_debug.h and exist only in libprego_amd_debug.so (the same sources built with -DPREGO_DEBUG_ABI). */
 
 #ifdef __cplusplus
 }

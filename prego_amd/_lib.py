@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PREGO_AMD_LIB") or os.path.join(_HERE, "lib", "libprego_amd.so")   # override: A/B builds
+DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libprego_amd_debug.so")      # product ABI + the probe / unit-test entry points (prego_amd_debug.h)
+# PREGO_AMD_LIB: an A/B build; PREGO_AMD_DEBUG_LIB=1: the measurement scripts under scripts/ run their engines on the debug library
+LIB_PATH = os.environ.get("PREGO_AMD_LIB") or (DEBUG_LIB_PATH if os.environ.get("PREGO_AMD_DEBUG_LIB") else os.path.join(_HERE, "lib", "libprego_amd.so"))
 
 PREGO_F32, PREGO_BF16, PREGO_F16, PREGO_F16X2 = 0, 1, 2, 3
 FWD_SOFTMAX, FWD_KEEP, FWD_IN16 = 1, 2, 4
@@ -22,7 +24,7 @@ SYMBOLS = [
     "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_last_error", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
-    "prego_miniroad_debug_stamps", "prego_miniroad_set_dropout", "prego_oad_loss",
+    "prego_miniroad_set_dropout", "prego_oad_loss",
     "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
@@ -30,10 +32,13 @@ SYMBOLS = [
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward",
-    "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd", "prego_vit_adamw_step", "prego_miniroad_step",
+    "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events",
-    "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype", "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
+    "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
 ]
+# include/prego_amd_debug.h: only in libprego_amd_debug.so
+DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
+                 "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only"]
 
 
 class PregoError(RuntimeError):
@@ -43,18 +48,15 @@ class PregoError(RuntimeError):
 _lib = None
 
 
-def load() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(path: str, debug: bool) -> C.CDLL:
+    if not os.path.exists(path):
         raise PregoError(
-            f"{LIB_PATH} not found: the HIP library has not been built. Run `python -m prego_amd.build` "
+            f"{path} not found: the HIP library has not been built. Run `python -m prego_amd.build` "
             "(needs hipcc; cross-compiles gfx950 without a GPU). There is no CPU fallback.")
     # torch ships its own libamdhip64; import it first so that the one HIP runtime in the process is
     # torch's (loading ours first makes torch's copy fail with "no ROCm-capable device")
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, i64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
     lib.prego_abi_version.restype = i32
     lib.prego_last_error.restype = C.c_char_p
@@ -75,7 +77,6 @@ def load() -> C.CDLL:
     lib.prego_miniroad_timing_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                                C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                                C.POINTER(i64), C.POINTER(C.c_double)]
-    lib.prego_miniroad_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.prego_miniroad_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
     lib.prego_oad_loss.argtypes = [i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), i32, vp, C.POINTER(vp),
                                    C.c_float, vp]
@@ -119,20 +120,43 @@ def load() -> C.CDLL:
     lib.prego_attention_layer_handle_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_handle_workspace_bytes.restype = sz
     lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
-    lib.prego_debug_head_only.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     lib.prego_attention_layer_train_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_train_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward_train.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
     lib.prego_attention_layer_backward.argtypes = [vp, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]
-    lib.prego_debug_attention_bwd.argtypes = [i32] * 5 + [vp] * 7 + [vp]
-    lib.prego_debug_attention_fwd.argtypes = [i32] * 6 + [vp] * 5 + [vp]
-    lib.prego_debug_recurrence_only.argtypes = [vp, i32, i32, i32, vp, vp, vp]
-    lib.prego_debug_gemm_worker.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
-    lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     for name in SYMBOLS:          # fail loudly at load time if the library is stale
         getattr(lib, name)
-    _lib = lib
+    if debug:
+        lib.prego_miniroad_debug_stamps.argtypes = [vp, C.POINTER(C.c_uint64)]
+        lib.prego_debug_head_only.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+        lib.prego_debug_attention_bwd.argtypes = [i32] * 5 + [vp] * 7 + [vp]
+        lib.prego_debug_attention_fwd.argtypes = [i32] * 6 + [vp] * 5 + [vp]
+        lib.prego_debug_recurrence_only.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+        lib.prego_debug_gemm_worker.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
+        lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
     return lib
+
+
+def load() -> C.CDLL:
+    """the product library (include/prego_amd.h): what every module under prego_amd/ runs on"""
+    global _lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, debug=LIB_PATH == DEBUG_LIB_PATH)
+    return _lib
+
+
+_dbg = None
+
+
+def load_debug() -> C.CDLL:
+    """libprego_amd_debug.so: the product ABI plus the probe / unit-test entry points of include/prego_amd_debug.h.  Used by the
+    kernel-level GPU tests and the scripts under scripts/; never by the product path."""
+    global _dbg
+    if _dbg is None:
+        _dbg = load() if LIB_PATH == DEBUG_LIB_PATH else _open(DEBUG_LIB_PATH, debug=True)
+    return _dbg
+
+
 
 
 def check(rc: int):

@@ -27,18 +27,54 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+DEBUG_LIB = os.path.join(LIBDIR, "libprego_amd_debug.so")
+DEBUG_ABI_SOURCES = ("miniroad.cpp", "vit_host.cpp")       # the only files that define prego_debug_* entry points (include/prego_amd_debug.h)
+
+
+def _tree_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources() + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    for f in sorted(os.listdir(inc)):
+        h.update(open(os.path.join(inc, f), "rb").read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
+    """Builds libprego_amd.so (the product ABI, include/prego_amd.h) and libprego_amd_debug.so (the same objects plus the probe /
+    unit-test entry points of include/prego_amd_debug.h: the two host files compiled again with -DPREGO_DEBUG_ABI).  An object is
+    recompiled when it is older than its source or a header; EVERYTHING is rebuilt when the library's recorded sources_sha256 differs
+    from the tree (a prebuilt library shipped with an edited tree, or clock skew between hosts, cannot pass as current)."""
     os.makedirs(LIBDIR, exist_ok=True)
+    info_path = os.path.join(LIBDIR, "build_info.json")
+    stale = True
+    if os.path.exists(info_path) and os.path.exists(LIB) and os.path.exists(DEBUG_LIB):
+        try:
+            import json
+            stale = json.load(open(info_path)).get("sources_sha256") != _tree_hash()
+        except Exception:
+            stale = True
+    force = force or (stale and os.path.exists(info_path))       # hash mismatch of an existing build: rebuild every object
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "prego_amd.h"))
-    objs, jobs = [], []
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc)]
+    objs, dbg_objs, jobs = [], [], []
     for src in sources():
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIBDIR, src.replace(".", "_") + ".o")
         objs.append(op)
-        if force or _newer(sp, op) or any(_newer(h, op) for h in hdrs):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
-            jobs.append(cmd)
+        variants = [(op, [])]
+        if src in DEBUG_ABI_SOURCES:
+            dop = os.path.join(LIBDIR, src.replace(".", "_") + "_dbg.o")
+            variants.append((dop, ["-DPREGO_DEBUG_ABI"]))
+            dbg_objs.append(dop)
+        else:
+            dbg_objs.append(op)
+        for o, extra in variants:
+            if force or _newer(sp, o) or any(_newer(h, o) for h in hdrs):
+                jobs.append([HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -50,8 +86,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
+    if jobs or stale or not os.path.exists(LIB) or not os.path.exists(DEBUG_LIB):
         run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs)
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", DEBUG_LIB] + dbg_objs)
         _write_build_info(len(jobs))
     return LIB
 
@@ -60,13 +97,9 @@ def _write_build_info(n_compiled: int):
     """provenance of the shared library next to it (prego_amd/lib/build_info.json, travels with the .so): where and when it was
     built, by which compiler, from which tree - `build_info()` / bench.py report it, so a run can tell a library built on its own box
     from one shipped prebuilt"""
-    import hashlib
     import json
     import platform
     import time
-    h = hashlib.sha256()
-    for f in sources() + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
-        h.update(open(os.path.join(CSRC, f), "rb").read())
     try:
         ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout.splitlines()[0]
     except Exception:
@@ -76,25 +109,23 @@ def _write_build_info(n_compiled: int):
     except Exception:
         git = None
     info = {"built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()), "host": platform.node(), "hipcc": ver, "arch": ARCH,
-            "flags": FLAGS, "sources_sha256": h.hexdigest(), "git_head_at_build": git, "objects_compiled_in_this_call": n_compiled,
+            "flags": FLAGS, "sources_sha256": _tree_hash(), "git_head_at_build": git, "objects_compiled_in_this_call": n_compiled,
             "sources": len(sources())}
     json.dump(info, open(os.path.join(LIBDIR, "build_info.json"), "w"), indent=1)
 
 
 def build_info() -> dict:
     """build_info.json of the library in use + whether it matches the sources in this tree and was built on this host"""
-    import hashlib
     import json
     import platform
     p = os.path.join(LIBDIR, "build_info.json")
     if not os.path.exists(p):
         return {"build_mode": "unknown (no build_info.json beside the library)"}
     info = json.load(open(p))
-    h = hashlib.sha256()
-    for f in sources() + sorted(x for x in os.listdir(CSRC) if x.endswith(".h")):
-        h.update(open(os.path.join(CSRC, f), "rb").read())
-    info["sources_match_tree"] = h.hexdigest() == info.get("sources_sha256")
-    info["build_mode"] = "built on this host" if info.get("host") == platform.node() else "prebuilt elsewhere, shipped with the tree"
+    info["sources_match_tree"] = _tree_hash() == info.get("sources_sha256")
+    same_host = info.get("host") == platform.node()
+    info["build_mode"] = ("built on this host" if same_host else "prebuilt elsewhere, shipped with the tree") + \
+        ("" if info["sources_match_tree"] else " - STALE: sources differ from the tree it was built from")
     return info
 
 

@@ -975,7 +975,7 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
   const int grid = a.G * P;
   const bool train = a.keep_r != nullptr || a.h_raw_out != nullptr;
   // two or more clip tiles per group, inference: the software-pipelined multi-tile kernel (PREGO_GRU_NO_MT=1: the classic kernel, A/B)
-  static const bool no_mt = getenv("PREGO_GRU_NO_MT") != nullptr;
+  const bool no_mt = a.no_mt != 0;
 #ifdef GRU_MT_STAMPS
   const bool stamps_ok = true;
 #else

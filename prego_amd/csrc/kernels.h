@@ -55,6 +55,7 @@ struct GruArgs {
   int Gd;                      // groups the slots are dealt to (0 = G); one-tile kernel only
   int rows;                    // packed rows this launch covers (rowoff[t1] - row_base); 0 = unknown
   int armed;                   // 1: hx / sync were re-armed by an earlier kernel of this stream (launch_ln_relu with a GruArm): no arm launch
+  int no_mt;                   // 1: never the software-pipelined multi-tile kernel (handle created under PREGO_GRU_NO_MT=1: A/B and the bit-identity test)
 };
 // what a recurrence launch needs re-armed before it starts (gru_recurrence.hip: buffer 0 := tag 1 everywhere, buffer 1 := 0,
 // sync[0..15] := 0).  A LayerNorm launch that runs between two recurrence launches of a stream can do it on the side (one launch

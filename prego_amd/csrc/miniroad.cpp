@@ -3,6 +3,9 @@
 // carving, weight ingestion, and the per-chunk launch sequence
 //   pack -> GEMM(layer1) -> LayerNorm+ReLU -> GEMM(W_ih) -> persistent GRU recurrence -> head+softmax+argmax.
 #include "../../include/prego_amd.h"
+#ifdef PREGO_DEBUG_ABI
+#include "../../include/prego_amd_debug.h"
+#endif
 #include "kernels.h"
 
 #include <algorithm>
@@ -107,6 +110,7 @@ struct prego_miniroad {
   char* pin = nullptr; size_t pin_bytes = 0; hipEvent_t pin_ev = nullptr; bool pin_busy = false;
   bool plan_dirty = false;      // host plan arrays changed, device copies pending
   bool no_local = false;        // PREGO_GRU_NO_LOCAL (read once at create): skip the XCD-local hand-off fast path
+  bool no_mt = false;           // PREGO_GRU_NO_MT (read once at create): multi-tile steps on the classic kernel
   // feature streaming of chunk c+1 under the recurrence of chunk c: the pack kernel (22 registers, no LDS) fits beside a
   // recurrence workgroup on every CU, so it runs on a handle-owned side stream, forked from and joined to the caller's stream
   // by events (the caller still sees one in-order stream)
@@ -190,6 +194,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin, h->pin_bytes, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
   h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
+  h->no_mt = getenv("PREGO_GRU_NO_MT") != nullptr;
   h->pack_prefetch = getenv("PREGO_NO_PACK_PREFETCH") == nullptr;
   // the pack beside the recurrence slows its L2 hand-off; capped at 512 workgroups it still ends inside a 49 152-row launch and
   // costs the pass 0.9 ms less than unthrottled (sweep: scripts/probes/env_sweep.sh, 128: +10 ms, 256: +1, 512: -0.9, 1024: 0)
@@ -670,6 +675,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = h->use_stamps ? h->stamps : nullptr;
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
     ga.armed = (arm_fuse && rows > 0) ? 1 : 0;
+    ga.no_mt = h->no_mt ? 1 : 0;
     {
       // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
       // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)
@@ -827,6 +833,7 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
   return PREGO_OK;
 }
 
+#ifdef PREGO_DEBUG_ABI
 // debug / probe: ONLY the recurrence kernel, one launch over n_steps steps of n_slots equally long slots dealt to `gd` groups
 // (0 = all), on caller-supplied gi rows [n_steps * n_slots][3H] (16-bit, the handle's operand type) -> relu(h) [rows][H].
 // scripts/probes/xcd_overlap_probe.py runs it beside an XCD-filtered GEMM worker.
@@ -892,6 +899,8 @@ extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long
   HIPCHK(hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long)));
   return PREGO_OK;
 }
+
+#endif  // PREGO_DEBUG_ABI
 
 // ================================================================================================
 // training: dropout control, loss, backward
@@ -1208,6 +1217,7 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
   return PREGO_OK;
 }
 
+#ifdef PREGO_DEBUG_ABI
 // probe: the ping-pong GEMM as a persistent worker that only runs on XCDs >= xcd_lo and claims tiles from `counter`
 // (device word, zeroed by the caller in stream order); grid = workgroups launched (256 = one per CU)
 extern "C" int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int xcd_lo,
@@ -1230,3 +1240,4 @@ extern "C" int prego_debug_gemm_bf16(int variant, const void* A, const void* B, 
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
+#endif  // PREGO_DEBUG_ABI

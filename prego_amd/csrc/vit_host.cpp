@@ -1,6 +1,9 @@
 // C ABI of the "Transformer" (ViTEnc) path and of the causal AttentionLayer op (include/prego_amd.h).
 // bf16 (or, inference only, IEEE fp16) MFMA operands, fp32 accumulation / residual stream / LayerNorm / softmax.
 #include "../../include/prego_amd.h"
+#ifdef PREGO_DEBUG_ABI
+#include "../../include/prego_amd_debug.h"
+#endif
 #include "kernels.h"
 
 #include <algorithm>
@@ -597,6 +600,7 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
   return PREGO_OK;
 }
 
+#ifdef PREGO_DEBUG_ABI
 // debug / unit test: the attention backward kernels alone (tests/test_gpu_vit_train.py)
 extern "C" int prego_debug_attention_bwd(int batch, int len, int heads, int dh, int causal, const void* qs, const void* k, const void* v,
                                          const void* o, const void* dout, const float* lse, void* dqkv, prego_stream_t stream) {
@@ -622,6 +626,8 @@ extern "C" int prego_debug_attention_fwd(int batch, int n_query, int len, int he
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
+
+#endif  // PREGO_DEBUG_ABI
 
 // ---- AttentionLayer(FullAttention(mask_flag)) of attn.py:139-170,35-57 ---------------------------------------------
 // the attention arithmetic shared by the stateless op and the handle: wqkv bf16 [3D][D] (rows q | k | v), bqkv fp32 [3D],

@@ -95,12 +95,17 @@ class StepRecognitionDataset(data.Dataset):
                 self.inputs.append((vid, 0, n))
 
     def __getitem__(self, index):
-        vid, start, end = self.inputs[index]
+        # index >= len: a PAD entry of EpochWindowSampler (short last global batch of a data-parallel epoch) = window index - len
+        # with an all-zero target, i.e. zero loss and zero gradient under OadLoss (loss.py:28-29)
+        pad = index >= len(self.inputs)
+        vid, start, end = self.inputs[index - len(self.inputs) if pad else index]
         as_t = (lambda a: a) if self.feature_dtype != torch.float32 else torch.from_numpy
         rgb = as_t(self.rgb_inputs[vid][start:end])
         flow = self.flow_inputs[vid]
         flow = self._zero_row.expand(end - start, -1) if flow is None else as_t(flow[start:end])
         target = torch.from_numpy(self.target_all[vid][start:end])
+        if pad:
+            target = torch.zeros_like(target)
         return rgb, flow, target, vid, start, end
 
     def __len__(self):
@@ -120,7 +125,7 @@ def build_data_loader(cfg, mode):
     ds = DATA_LAYERS[cfg["data_name"]](cfg, mode)
     sampler = None
     if mode == "train" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        sampler = EpochWindowSampler(ds)
+        sampler = EpochWindowSampler(ds, cfg["batch_size"])
     return data.DataLoader(dataset=ds, batch_size=cfg["batch_size"] if mode == "train" else cfg["test_batch_size"],
                            shuffle=(mode == "train" and sampler is None), sampler=sampler,
                            num_workers=cfg["num_workers"], pin_memory=True)
@@ -130,31 +135,53 @@ class EpochWindowSampler(data.Sampler):
     """DistributedSampler for a dataset whose length changes every epoch (`_init_features()` re-draws the window phase,
     main.py:100, so len(dataset) moves by a few windows): the permutation, the padding and the per-rank share are
     recomputed from the CURRENT dataset length at every `__iter__`, and the epoch number seeds the shuffle
-    (`set_epoch`, called by train_one_epoch).  Every rank takes ceil(len / world) windows (the tail is padded by wrapping
-    around), so all ranks run the same number of steps."""
+    (`set_epoch`, called by train_one_epoch).
 
-    def __init__(self, dataset, seed: int = 0):
+    Global step j takes windows order[j * Bg : (j + 1) * Bg] (Bg = world * batch_size); rank r its contiguous block of batch_size
+    of them, so all ranks run the same number of steps.  The reference's DataLoader has no drop_last (dataset_builder.py:17-23): its
+    last batch is SHORT and its loss is the mean over the windows that exist.  Here the short last global batch is filled up with
+    PAD entries - index + len(dataset), which StepRecognitionDataset turns into that window with an all-zero target: zero loss and
+    zero gradient under OadLoss (loss.py:28-29, F.normalize of a zero row) - and `step_weight(j)` = Bg / (real windows of step j)
+    is what the trainer multiplies the averaged gradient (and the logged loss) with, so the step equals the reference's mean over
+    the real windows.  No window is counted twice."""
+
+    def __init__(self, dataset, batch_size: int = 1, seed: int = 0):
         import torch.distributed as dist
         self.dataset = dataset
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        self.batch_size = int(batch_size)
         self.seed = seed
         self.epoch = 0
 
     def set_epoch(self, epoch: int):
         self.epoch = int(epoch)
 
+    def _steps(self, n):
+        bg = self.world * self.batch_size
+        return (n + bg - 1) // bg
+
     def __len__(self):
-        return (len(self.dataset) + self.world - 1) // self.world
+        return self._steps(len(self.dataset)) * self.batch_size
+
+    def step_weight(self, step: int) -> float:
+        """global batch size / number of real (non-pad) windows in global step `step` of the current epoch"""
+        n, bg = len(self.dataset), self.world * self.batch_size
+        real = min(bg, n - step * bg)
+        return bg / real if real > 0 else 1.0
 
     def __iter__(self):
         n = len(self.dataset)
         g = torch.Generator()
         g.manual_seed(self.seed + self.epoch)
         order = torch.randperm(n, generator=g).tolist()
-        per = (n + self.world - 1) // self.world
-        order += order[: per * self.world - n]
-        return iter(order[self.rank: per * self.world: self.world])
+        bg, b = self.world * self.batch_size, self.batch_size
+        total = self._steps(n) * bg
+        order += [i + n for i in order[: total - n]]              # pads: index + n = "that window, zero target"
+        mine = []
+        for j in range(0, total, bg):
+            mine += order[j + self.rank * b: j + (self.rank + 1) * b]
+        return iter(mine)
 
 
 # ---- clip sharding for data-parallel inference (SURVEY.md section 8e) --------------------------------

@@ -60,25 +60,37 @@ def sharded_predict(run_clips: Callable[[List[int]], List], lengths: Sequence[in
     return out
 
 
-def allreduce_mean_(flat: torch.Tensor, world: int):
+def _scale_(view: torch.Tensor, world: int, weight: float):
+    """sum over ranks -> weighted mean: / world (bit-compatible with the unweighted path) or * weight / world"""
+    if weight == 1.0:
+        view.div_(world)
+    else:
+        view.mul_(weight / world)
+
+
+def allreduce_mean_(flat: torch.Tensor, world: int, weight: float = 1.0, force: bool = False):
     """gradient averaging for clip-sharded data-parallel training: loss is a mean over the batch
-    (criterions/loss.py:30-31), so grads are summed over ranks and divided by the world size."""
-    if world > 1:
+    (criterions/loss.py:30-31), so grads are summed over ranks and divided by the world size.  `weight` (>= 1) re-weights a step
+    whose global batch is short (the last batch of an epoch: the reference's DataLoader has no drop_last, dataset_builder.py:17-23;
+    data.EpochWindowSampler pads it with zero-loss windows and says how many were real).  force: run the collective for world == 1
+    too (a one-rank process group: the GPU test of this path on a one-GPU box)."""
+    if world > 1 or force:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(world)
+        _scale_(flat, world, weight)
     return flat
 
 
 _COMM_STREAMS = {}
 
 
-def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None, compress: str | None = None):
+def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None, compress: str | None = None, weight: float = 1.0,
+                            force: bool = False):
     """Gradient averaging of the flat bucket in sub-buckets `bounds` = [(lo, hi), ...] given in the order the backward finishes
     them.  On a GPU every sub-bucket is reduced on a side stream as soon as its event (events[i]; None = "final in stream order")
     has fired, i.e. under the rest of the backward; the caller's stream waits for the side stream at the end.  compress='bf16'
     sends bf16 (half the bytes over the xGMI ring; the sum runs in bf16 on the wire, the average and everything after it in fp32).
-    On CPU tensors (gloo tests) the same sub-buckets are reduced one after the other."""
-    if world <= 1:
+    On CPU tensors (gloo tests) the same sub-buckets are reduced one after the other.  weight / force: see allreduce_mean_."""
+    if world <= 1 and not force:
         return flat
     if compress not in (None, "bf16"):
         raise ValueError(f"compress {compress!r}: expected None or 'bf16'")
@@ -91,7 +103,7 @@ def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None,
             view.copy_(buf)
         else:
             dist.all_reduce(view, op=dist.ReduceOp.SUM)
-        view.div_(world)
+        _scale_(view, world, weight)
 
     if not flat.is_cuda:
         for lo, hi in bounds:

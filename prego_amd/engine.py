@@ -3,6 +3,7 @@ the arithmetic runs in libprego_amd.so."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -264,7 +265,8 @@ class MiniRoadEngine:
         o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
         self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]
         self._grad_events = None
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        dp = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if dp and (torch.distributed.get_world_size() > 1 or os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1"):
             if getattr(self, "_bwd_events", None) is None:
                 evs = [torch.cuda.Event(), torch.cuda.Event()]
                 with torch.cuda.device(self.device):

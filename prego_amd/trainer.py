@@ -11,9 +11,16 @@ from .distributed import allreduce_mean_, allreduce_mean_buckets_
 from .registry import TRAINER
 
 
-def _allreduce_grads(model):
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    if world == 1:
+def _allreduce_grads(model, weight: float = 1.0):
+    """sum the gradients over the ranks and average them; `weight` re-weights a short global batch (EpochWindowSampler.step_weight).
+    Everything here is ENQUEUED (collectives on a side stream behind the backward's events): no host synchronisation, so the head and
+    GRU sub-buckets travel under the rest of the backward.  PREGO_DP_FORCE_COLLECTIVE=1 runs the collective path in a one-rank
+    process group as well (GPU test of this path on a one-GPU box)."""
+    import os
+    init = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if init else 1
+    force = init and os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1"
+    if world == 1 and not force:
         return
     ps = [p for p in model.parameters() if p.grad is not None]
     eng = getattr(model, "_engine", None)
@@ -23,12 +30,13 @@ def _allreduce_grads(model):
         # finishes one after the other (head, GRU, layer1 + LayerNorm) - the first two start under the rest of the backward
         bounds = getattr(eng, "_grad_bounds", None)
         if bounds:
-            allreduce_mean_buckets_(flat, bounds, world, getattr(eng, "_grad_events", None), getattr(model, "grad_compress", None))
+            allreduce_mean_buckets_(flat, bounds, world, getattr(eng, "_grad_events", None), getattr(model, "grad_compress", None),
+                                    weight=weight, force=force)
         else:
-            allreduce_mean_(flat, world)
+            allreduce_mean_(flat, world, weight, force)
         return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])        # generic modules: gather, reduce, scatter
-    allreduce_mean_(flat, world)
+    allreduce_mean_(flat, world, weight, force)
     o = 0
     for p in ps:
         n = p.numel()
@@ -51,7 +59,9 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
     sampler = getattr(trainloader, "sampler", None)
     if hasattr(sampler, "set_epoch"):          # data-parallel runs: a different permutation every epoch
         sampler.set_epoch(epoch)
+    step_weight = getattr(sampler, "step_weight", None)       # data.EpochWindowSampler: global batch / real windows of a step (1.0 but for a short last batch)
     for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(trainloader):
+        w = float(step_weight(it)) if step_weight is not None else 1.0
         rgb_input, flow_input, target = rgb_input.to(device), flow_input.to(device), target.to(device)
         model.train()
         if scaler is not None:
@@ -63,8 +73,8 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
                 loss = criterion(out_dict, target)
             optimizer.zero_grad(set_to_none=True)
             scaler.scale(loss).backward()
-            _check_engine(model)
-            _allreduce_grads(model)
+            _allreduce_grads(model, w)         # enqueued behind the backward's events, BEFORE the host waits for anything
+            _check_engine(model)               # synchronises; only gates optimizer.step()
             scaler.step(optimizer)
             scaler.update()
         else:
@@ -72,10 +82,10 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
             loss = criterion(out_dict, target)
             optimizer.zero_grad(set_to_none=True)
             loss.backward()
-            _check_engine(model)
-            _allreduce_grads(model)
+            _allreduce_grads(model, w)         # enqueued behind the backward's events, BEFORE the host waits for anything
+            _check_engine(model)               # synchronises; only gates optimizer.step()
             optimizer.step()
-        epoch_loss += loss.item()
+        epoch_loss += loss.item() * w
         if writer is not None:
-            writer.add_scalar("Train Loss", loss.item(), it + epoch * len(trainloader))
+            writer.add_scalar("Train Loss", loss.item() * w, it + epoch * len(trainloader))
     return epoch_loss

@@ -1,6 +1,8 @@
 """bf16 NT GEMM microbenchmark: variants interleaved in ONE process (cdna_hip_programming.md rule 24), random data,
 checked against torch.  usage: python scripts/gemm_bench.py [variants e.g. 9,13] [M] [N] [K]
 variants: 0 = 128x128 two-stage, 1 = 256x128 three-stage counted-vmcnt, 9 = 256x256 two-stage (previous production), 12 = ping-pong (production)"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

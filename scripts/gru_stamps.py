@@ -1,4 +1,6 @@
 """per-phase cycle breakdown of the recurrence kernel (debug build knobs: PREGO_GRU_STAMPS=1)"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import os, sys, ctypes as C
 os.environ["PREGO_GRU_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,8 @@
 """How much of the recurrence phase's idle CU time can other kernels use?  Runs the BASELINE pass on one stream and a
 loop of feed-forward-sized GEMMs on a second stream, alone and together (same process, interleaved).
 usage: python scripts/overlap_probe.py [n_gemms]"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -8,11 +8,12 @@ in the kernels) of the HIP path with one precision switch per stage:
     gi  input projection as stored              h    state as the W_hh operand (every step)    whh  W_hh operand
     hr  relu(h) as the classifier operand       wc   classifier weight operand
 
-Each switch is one of f32 / bf16 / f16 (round to nearest even).  The reference is the fp64 oracle on the same weights.
+Each switch is one of f32 / bf16 / f16 (round to nearest even) or a split kind f16x2 / bf16x2 (hi + lo of that type, products as
+a_hi.b_lo + a_lo.b_hi + a_hi.b_hi: what the fp16x2 kernels of round 4 compute).  The reference is the fp64 oracle on the same weights.
 Output: argmax mismatches, the largest reference margin among them, mismatches above a 1e-3 margin, max |dprob| per
 configuration -> profiles/precision_study_r03.json.  Test infrastructure: imports the oracle, runs on the CPU only.
 
-    python scripts/precision_study.py [out.json] [--long]      # --long adds G2 T = 31 114
+    python scripts/precision_study.py [out.json] [--long] [--only-x2] [--no-scale]     # --long adds G2 T = 31 114; --no-scale: split weights unscaled
 """
 import json
 import os
@@ -27,6 +28,34 @@ from prego_amd import weights as W
 from prego_amd.config import assembly101_cfg, epic_tent_cfg
 
 STAGES = ("x", "w1", "y", "e", "wih", "gi", "h", "whh", "hr", "wc")
+
+
+def split(t, kind, scale=1.0):
+    """(hi, lo) of t * scale in the 16-bit type of a split-operand kind ('f16x2' / 'bf16x2'), both as fp32 tensors"""
+    dt = torch.float16 if kind == "f16x2" else torch.bfloat16
+    ts = t * scale
+    hi = ts.to(dt).to(torch.float32)
+    lo = (ts - hi).to(dt).to(torch.float32)
+    return hi, lo
+
+
+def p2scale(t):
+    """the power of two that puts max|t| in [8192, 16384) (csrc/rowwise.hip: x2_weight_scale_kernel)"""
+    import math
+    return 2.0 ** math.floor(math.log2(16384.0 / float(t.abs().max())))
+
+
+SCALE_W = True       # split-operand weights are pre-scaled by a power of two (their lo halves stay out of fp16's subnormals)
+
+
+def mm(a, ka, b, kb):
+    """a [M, K] (kind ka) times b [N, K]^T (kind kb); split kinds take the three-product form a_hi.b_lo + a_lo.b_hi + a_hi.b_hi"""
+    if ka in ("f16x2", "bf16x2"):
+        ah, al = split(a, ka)
+        s = p2scale(b) if SCALE_W else 1.0
+        bh, bl = split(b, kb, s)
+        return (ah @ bh.T + (ah @ bl.T + al @ bh.T)) / s
+    return rnd(a, ka) @ rnd(b, kb).T
 
 
 def rnd(t, kind):
@@ -49,29 +78,39 @@ def forward(sd, rgb, flow, cfgp):
     else:
         w1 = w1[:, : x.shape[1]]
     H = p["gru.weight_hh_l0"].shape[1]
-    y = rnd(x, cfgp["x"]) @ rnd(w1, cfgp["w1"]).T + p["layer1.0.bias"]
+    y = mm(x, cfgp["x"], w1, cfgp["w1"]) + p["layer1.0.bias"]
     y = rnd(y, cfgp["y"])
     mu = y.mean(1, keepdim=True)
     var = ((y - mu) ** 2).mean(1, keepdim=True)
     e = torch.relu((y - mu) / torch.sqrt(var + 1e-5) * p["layer1.1.weight"] + p["layer1.1.bias"])
-    gi = rnd(e, cfgp["e"]) @ rnd(p["gru.weight_ih_l0"], cfgp["wih"]).T
+    gi = mm(e, cfgp["e"], p["gru.weight_ih_l0"], cfgp["wih"])
     b_ih, b_hh = p["gru.bias_ih_l0"], p["gru.bias_hh_l0"]
     bias2 = b_ih.clone()
     bias2[: 2 * H] += b_hh[: 2 * H]                       # the kernels fold b_hh of the r, z rows into the projection's bias
     gi = rnd(gi + bias2, cfgp["gi"])
-    whh = rnd(p["gru.weight_hh_l0"], cfgp["whh"]).T.contiguous()
+    x2h = cfgp["h"] in ("f16x2", "bf16x2")
+    if x2h:
+        sw = p2scale(p["gru.weight_hh_l0"]) if SCALE_W else 1.0
+        wh, wl = split(p["gru.weight_hh_l0"], cfgp["whh"], sw)
+        wh, wl = wh.T.contiguous(), wl.T.contiguous()
+    else:
+        whh = rnd(p["gru.weight_hh_l0"], cfgp["whh"]).T.contiguous()
     bhn = b_hh[2 * H:]
     T = x.shape[0]
     h = torch.zeros(H)
     hs = torch.empty(T, H)
     for t in range(T):
-        gh = rnd(h, cfgp["h"]) @ whh
+        if x2h:
+            hh, hl = split(h, cfgp["h"])
+            gh = (hh @ wh + (hh @ wl + hl @ wh)) / sw
+        else:
+            gh = rnd(h, cfgp["h"]) @ whh
         r = torch.sigmoid(gi[t, :H] + gh[:H])
         z = torch.sigmoid(gi[t, H:2 * H] + gh[H:2 * H])
         n = torch.tanh(gi[t, 2 * H:] + r * (gh[2 * H:] + bhn))
         h = (1.0 - z) * n + z * h
         hs[t] = h
-    logits = rnd(torch.relu(hs), cfgp["hr"]) @ rnd(p["f_classification.0.weight"], cfgp["wc"]).T + p["f_classification.0.bias"]
+    logits = mm(torch.relu(hs), cfgp["hr"], p["f_classification.0.weight"], cfgp["wc"]) + p["f_classification.0.bias"]
     return O.softmax(logits.numpy().astype(np.float64))
 
 
@@ -100,12 +139,19 @@ def configs():
     out["bf16_with_h_f16"] = dict(cur, h="f16", whh="f16")
     out["bf16_with_ff_f16"] = dict(cur, x="f16", w1="f16", y="f16", e="f16", wih="f16", gi="f16")
     out["bf16_with_head_f32"] = dict(cur, hr="f32", wc="f32")
+    # round 4: split operands (hi + lo of the 16-bit type, three products).  (a) the classifier alone on split operands under 16-bit
+    # everything else - the cheap fix the round-3 verdict proposed for the bf16 head; (b) the whole path on fp16 pairs = fp16x2
+    out["bf16_with_head_bf16x2"] = dict(cur, hr="bf16x2", wc="bf16x2")
+    out["f16_with_head_f16x2"] = dict(allk("f16"), hr="f16x2", wc="f16x2")
+    out["f16_with_head_f32"] = dict(allk("f16"), hr="f32", wc="f32")
+    out["fp16x2 (all operands split, Y / GI / relu(h) / W_c fp32)"] = dict(allk("f16x2"), y="f32", gi="f32", hr="f32", wc="f32")
+    out["fp16x2_with_split_head"] = dict(allk("f16x2"), y="f32", gi="f32")
     return out
 
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    out_path = args[0] if args else "profiles/precision_study_r03.json"
+    out_path = args[0] if args else "profiles/precision_study_r04.json"
     long_t = "--long" in sys.argv
     torch.set_num_threads(8)
     cases = []
@@ -127,7 +173,12 @@ def main():
     refs = {}
     for name, sd, rgb, flow in cases:
         refs[name] = O.miniroad_forward(sd, rgb[None], None if flow is None else flow[None])["logits"][0]
-    for cname, cfgp in configs().items():
+    global SCALE_W
+    SCALE_W = "--no-scale" not in sys.argv
+    allc = configs()
+    if "--only-x2" in sys.argv:
+        allc = {k: v for k, v in allc.items() if "x2" in k or k in ("all_f32", "all_f16", "r02_default(all bf16, Y/GI stored bf16)", "bf16_with_head_f32", "f16_with_head_f32")}
+    for cname, cfgp in allc.items():
         tot = None
         per = {}
         for name, sd, rgb, flow in cases:

@@ -1,6 +1,8 @@
 """Race screen for the ping-pong GEMM (a new synchronisation structure must be screened over many runs at several sizes):
 every run must be bit-identical to the plain 128x128 kernel on fresh random operands.
 usage: python scripts/probes/gemm_race_screen.py [runs_per_shape]"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

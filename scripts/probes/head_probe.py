@@ -1,5 +1,7 @@
 """The head kernel alone (prego_debug_head_only): time against the number of rows - what is fixed per launch, what per row.
     python scripts/probes/head_probe.py"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C
 import json
 import os

@@ -1,6 +1,8 @@
 """(needs a diagnostic build: HIPCC flags += -DGRU_MT_STAMPS; the stamp branches cost the kernel ~8 %)
 per-phase cycles of a tile-slot of the pipelined multi-tile recurrence kernel (PREGO_GRU_STAMPS=1): 512 clips x 512 frames in
 256 / 512 slots (2 / 4 tiles per group); workgroup 0, wave 0"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import os, sys, ctypes as C
 os.environ["PREGO_GRU_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

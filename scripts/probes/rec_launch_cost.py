@@ -1,6 +1,8 @@
 """Fixed cost of one recurrence launch: prego_debug_recurrence_only over 128 equal slots (8 groups x 16 columns) for several step
 counts, alone on the device; least-squares intercept = what a launch costs before / after its steps.
     python scripts/probes/rec_launch_cost.py"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C
 import json
 import os

@@ -1,4 +1,6 @@
 """one long clip (recurrence on ONE group = 32 CUs for ~40 ms) on stream A, feed-forward-sized GEMMs on stream B"""
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch

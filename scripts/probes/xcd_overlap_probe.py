@@ -12,6 +12,8 @@ OTHER 8 - Gd XCDs, alone and together.
 Prints per Gd: recurrence us per step alone / beside the worker, GEMM TFLOP/s on 8 - Gd XCDs alone / beside the recurrence, and
 the whole-chip GEMM rate for scale.        python scripts/probes/xcd_overlap_probe.py [steps]
 """
+import os
+os.environ.setdefault("PREGO_AMD_DEBUG_LIB", "1")      # the prego_debug_* hooks live in libprego_amd_debug.so (include/prego_amd_debug.h)
 import ctypes as C
 import json
 import os

@@ -281,19 +281,88 @@ def test_epoch_window_sampler_partitions_and_reshuffles():
     class _DS(list):
         pass
 
-    class _FakeDist:
-        pass
-    import prego_amd.data as data_mod
     ds = _DS(range(103))
     parts = {}
     for rank in range(4):
         s = EpochWindowSampler.__new__(EpochWindowSampler)
-        s.dataset, s.world, s.rank, s.seed, s.epoch = ds, 4, rank, 0, 0
+        s.dataset, s.world, s.rank, s.batch_size, s.seed, s.epoch = ds, 4, rank, 2, 0, 0
         parts[rank] = list(iter(s))
-        assert len(parts[rank]) == len(s) == 26
-    flat = sorted(i for p in parts.values() for i in p)
-    assert set(flat) == set(range(103)) and len(flat) == 104           # one wrapped-around pad
+        assert len(parts[rank]) == len(s) == 26                       # 13 global steps of 8 windows, 2 per rank
+    flat = [i for p in parts.values() for i in p]
+    real = sorted(i for i in flat if i < 103)
+    pads = [i for i in flat if i >= 103]
+    assert real == list(range(103)) and len(pads) == 1 and 0 <= pads[0] - 103 < 103      # every window once; one PAD (index + len)
+    # the pad sits in the LAST global step, whose weight makes the weighted mean a mean over the 7 real windows
+    assert all(s.step_weight(j) == 1.0 for j in range(12)) and s.step_weight(12) == 8 / 7
+    last = [i for r in range(4) for i in parts[r][24:26]]
+    assert pads[0] in last
     s.set_epoch(1)
     assert list(iter(s)) != parts[3]
     ds.extend(range(5))                                               # _init_features() changed the window count
-    assert len(s) == 27 and len(list(iter(s))) == 27
+    assert len(s) == 28 and len(list(iter(s))) == 28                  # 108 windows: 14 global steps
+
+
+def _short_batch_worker(rank, world, port, q):
+    """n = 11 windows, local batch 2: world 2 -> 3 global steps of 4 (the last one has 3 real windows + 1 pad); world 1 with batch 4
+    is the reference loop (DataLoader without drop_last: batches of 4, 4, 3).  Same permutation in both."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from prego_amd import distributed as D
+    from prego_amd.data import EpochWindowSampler
+    from prego_amd.trainer import train_one_epoch
+    if world > 1:
+        D.init_from_env("gloo")
+    g = torch.Generator().manual_seed(11)
+    n, T = 11, 5
+    rgb, flow = torch.randn(n, T, 6, generator=g), torch.randn(n, T, 6, generator=g)
+    tgt = torch.nn.functional.one_hot(torch.randint(0, 5, (n, T), generator=g), 5).float()
+
+    class _DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):                       # the StepRecognitionDataset contract for PAD entries: zero target
+            pad = i >= n
+            i = i - n if pad else i
+            return rgb[i], flow[i], (torch.zeros_like(tgt[i]) if pad else tgt[i]), "v", 0, T
+
+    ds = _DS()
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0 + 3)).tolist()      # seed + epoch of the sampler below
+    if world > 1:
+        sampler = EpochWindowSampler(ds, batch_size=2, seed=0)
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, sampler=sampler)
+    else:
+        loader = torch.utils.data.DataLoader(ds, batch_size=4, sampler=perm)               # the reference loop on the same order
+    model = _TinyMROAD()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    loss = train_one_epoch(loader, model, _oad_loss_torch, opt, None, 3, "cpu")
+    if world > 1:
+        t = torch.tensor([loss], dtype=torch.float64)
+        dist.all_reduce(t)
+        loss = float(t.item()) / world                   # mean over ranks of the weighted local losses = the reference's epoch loss
+    if rank == 0:
+        q.put((float(loss), [p.detach().numpy().tolist() for p in model.parameters()]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_short_last_batch_is_weighted_not_duplicated():
+    """the reference's DataLoader has no drop_last; a data-parallel epoch must reproduce its short last batch (mean over the
+    windows that exist), not count wrapped-around windows twice.  Three optimizer steps on two ranks == the single-process epoch."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_short_batch_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res[world] = q.get(timeout=300)
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    assert abs(res[1][0] - res[2][0]) < 1e-5, (res[1][0], res[2][0])
+    for a, b in zip(res[1][1], res[2][1]):
+        a, b = torch.tensor(a), torch.tensor(b)
+        assert torch.allclose(a, b, atol=2e-6), (a - b).abs().max()

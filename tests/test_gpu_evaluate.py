@@ -35,7 +35,7 @@ class _Loader:
         return iter(self.items)
 
 
-@pytest.mark.parametrize("dtype,assume_zero", [("fp16", False), ("bf16", False), ("bf16", True), ("fp32", False)])
+@pytest.mark.parametrize("dtype,assume_zero", [("fp16", False), ("bf16", False), ("bf16", True), ("fp32", False), ("fp16x2", False)])
 def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     from prego_amd.registry import build_model, build_eval
     import prego_amd.model, prego_amd.evaluate  # noqa: F401
@@ -51,7 +51,8 @@ def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     mAP = ev(model, _Loader(g["lens"], 12, 20), logging.getLogger("t"), "cuda:0")
     js = json.load(open(tmp_path / "output_miniRoad" / "output_miniROAD.json"))
     assert set(js.keys()) == set(g["output"].keys())
-    tol = {"bf16": 1e-2, "fp16": 3e-3, "fp32": 1e-3}[dtype]
+    tol = {"bf16": 1e-2, "fp16": 3e-3, "fp32": 1e-3, "fp16x2": 1e-4}[dtype]
+    exact = dtype in ("fp32", "fp16x2")        # the fp32-class modes reproduce the reference's pred lists entry for entry
     total_mism = 0
     for i, T in enumerate(g["lens"]):
         vid = f"synth_video_{i}"
@@ -61,6 +62,7 @@ def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
         safe = (srt[:, -1] - srt[:, -2]) > 2 * tol
         mism = np.array(js[vid]["pred"]) != np.array(g["output"][vid]["pred"])
         assert not np.any(mism & safe)
+        assert not (exact and mism.any()), (vid, int(mism.sum()))
         total_mism += int(mism.sum())
     assert abs(mAP - g["mAP"]) < 5e-3
     assert ev.last_fps and ev.last_fps > 0

@@ -23,7 +23,7 @@ def _gemm(lib, variant, A, B, bias, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (4113, 512, 1024), (70001, 256, 192), (65536, 2048, 256)])
 def test_pingpong_gemm_matches_plain_kernel_and_fp32(M, N, K):
     from prego_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_debug()          # kernel-level hook prego_debug_gemm_bf16: only in libprego_amd_debug.so
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = (torch.rand((M, K), device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)
     B = (torch.rand((N, K), device="cuda", generator=g) * 2 - 1).to(torch.bfloat16)

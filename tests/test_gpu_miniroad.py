@@ -17,8 +17,13 @@ from prego_amd import weights as W           # noqa: E402
 from prego_amd.config import assembly101_cfg, epic_tent_cfg  # noqa: E402
 
 G = os.path.join(os.path.dirname(__file__), "golden")
-TOL = {"bf16": 1e-2, "fp16": 3e-3, "fp32": 1e-3}     # fp16 operands: not a north-star tier; held to 3e-3 (measured 1.7e-3)
+# fp16 operands: not a north-star tier; held to 3e-3 (measured 1.7e-3).  fp16x2 (split operands, round 4) is the fp32-class mode
+# on the 16-bit matrix pipe: held to 1e-4 (measured <= 5.2e-6 on every fixture)
+TOL = {"bf16": 1e-2, "fp16": 3e-3, "fp32": 1e-3, "fp16x2": 1e-4}
 DT16 = ("bf16", "fp16")
+EXACT = ("fp32", "fp16x2")        # modes held to the reference's argmax on EVERY frame of a reference fixture (north star: identical sequences)
+ALL_DT = ["bf16", "fp16", "fp32", "fp16x2"]
+HL_TOL = {"bf16": 3e-2, "fp16": 4e-3, "fp32": 1e-3, "fp16x2": 1e-4}
 
 
 def _model(cfg, sd, dtype):
@@ -30,19 +35,25 @@ def _model(cfg, sd, dtype):
     return m.eval()
 
 
-def _check_probs(got, ref, dtype, what=""):
+def _check_probs(got, ref, dtype, what="", exact=None):
+    """exact: argmax must equal the reference's on EVERY frame (default for fp32 / fp16x2 against a fixture written by the reference
+    itself; the numpy-oracle comparisons pass exact=False and keep a 1e-5 margin: the oracle is fp64, the reference fp32)"""
     tol = TOL[dtype]
     err = np.abs(got - ref).max()
     assert err < tol, f"{what}: max |dprob| {err:.3e} >= {tol}"
     srt = np.sort(ref, 1)
     margin = srt[:, -1] - srt[:, -2]
-    safe = margin > 2 * tol
+    if exact is None:
+        exact = dtype in EXACT
+    safe = margin > (0.0 if exact else (1e-5 if dtype in EXACT else 2 * tol))
+    if exact:
+        safe = np.ones_like(margin, dtype=bool)
     mism = (got.argmax(1) != ref.argmax(1))
-    assert not np.any(mism & safe), f"{what}: argmax differs on {int(np.sum(mism & safe))} frames with margin > {2*tol}"
+    assert not np.any(mism & safe), f"{what}: argmax differs on {int(np.sum(mism & safe))} frames (largest margin {float(margin[mism].max()):.2e})"
     return err, int(mism.sum()), int((~safe).sum())
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ALL_DT)
 @pytest.mark.parametrize("tag,gain", [("plain", 1.0), ("peaky", 8.0)])
 def test_g1_cfg1_golden(dtype, tag, gain):
     """BASELINE config 1 shape (1 clip x 256 frames x 2048-d, zero flow) against the reference's output."""
@@ -65,10 +76,10 @@ def test_g1_cfg1_golden(dtype, tag, gain):
     o2 = outs[0].cpu().numpy()
     assert np.abs(o2 - out[0].cpu().numpy()).max() < (2e-3 if dtype in DT16 else 1e-5)
     assert np.array_equal(args[0].cpu().numpy(), o2.argmax(1))
-    assert np.abs(hl[0].cpu().numpy() - g["h_last"]).max() < (3e-2 if dtype == "bf16" else 4e-3 if dtype == "fp16" else 1e-3)
+    assert np.abs(hl[0].cpu().numpy() - g["h_last"]).max() < HL_TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ALL_DT)
 def test_g3_nonzero_flow_T8(dtype):
     g = np.load(os.path.join(G, "g3_miniroad_intermediates.npz"))
     cfg = assembly101_cfg()
@@ -82,11 +93,11 @@ def test_g3_nonzero_flow_T8(dtype):
     _check_probs(out, g["probs"], dtype, "g3")
     # raw logits (training-mode output convention) through the ragged API
     outs, _, _ = m.engine().forward_ragged([rgb[0]], [flow[0]], softmax=False)
-    tol = 5e-2 if dtype == "bf16" else 8e-3 if dtype == "fp16" else 2e-3
+    tol = {"bf16": 5e-2, "fp16": 8e-3, "fp32": 2e-3, "fp16x2": 2e-4}[dtype]
     assert np.abs(outs[0].cpu().numpy() - g["raw_logits"]).max() < tol
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ALL_DT)
 def test_g2_long_T_4096(dtype):
     g = np.load(os.path.join(G, "g2_miniroad_longT_4096.npz"))
     cfg = assembly101_cfg()
@@ -100,17 +111,13 @@ def test_g2_long_T_4096(dtype):
     got = outs[0].cpu().numpy()
     tol = TOL[dtype]
     assert np.abs(got[g["sample_idx"]] - g["sample_probs"]).max() < tol
-    safe = g["margin"] > 2 * tol
+    safe = g["margin"] > (-1.0 if dtype in EXACT else 2 * tol)          # fp32 / fp16x2: every frame
     mism = args[0].cpu().numpy() != g["argmax"].astype(np.int32)
     assert not np.any(mism & safe)
     print(f"g2 T=4096 {dtype}: argmax mismatches {int(mism.sum())} of {T}, all under margin; unsafe frames {int((~safe).sum())}")
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
-def test_g1c_trained_like_head_gain32(dtype):
-    """head gain 32 (the reference's top-1 probability is ~0.8 in the median): fp32 and fp16 operands stay within their
-    tolerances and keep every argmax above a 1e-3 margin; bf16 operands are held to the north star's 1e-2 ... which a x32 head does not
-    grant them (measured 1.7e-2 in the CPU emulation), so for bf16 this test records the error and checks the 2e-2 bound only."""
+def _run_g1c(dtype):
     g = np.load(os.path.join(G, "g1c_miniroad_eval_gain32.npz"))
     cfg = assembly101_cfg()
     sd = W.miniroad_state_dict(cfg, 20, head_gain=32.0)
@@ -124,11 +131,30 @@ def test_g1c_trained_like_head_gain32(dtype):
     mism = args[0].cpu().numpy() != g["argmax"]
     worst = float(g["margin"][mism].max()) if mism.any() else 0.0
     print(f"g1c gain32 {dtype}: max|dprob| {err:.2e}, argmax mismatches {int(mism.sum())}, largest violated margin {worst:.2e}")
-    if dtype == "bf16":
-        assert err < 3e-2 and worst < 3e-2
+    return g, err, mism, worst
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32", "fp16x2"])
+def test_g1c_trained_like_head_gain32(dtype):
+    """head gain 32 (the reference's top-1 probability is ~0.8 in the median): fp32 and fp16x2 operands reproduce EVERY argmax and
+    stay within 1e-3 / 1e-4; fp16 operands stay within 5e-3 and keep every argmax above a 1e-3 margin."""
+    g, err, mism, worst = _run_g1c(dtype)
+    if dtype in EXACT:
+        assert err < TOL[dtype] and not mism.any(), (err, int(mism.sum()), worst)
     else:
-        assert err < (5e-3 if dtype == "fp16" else 1e-3)
+        assert err < 5e-3
         assert not np.any(mism & (g["margin"] > 1e-3))
+
+
+def test_g1c_bf16_operands_are_outside_the_1e2_tier_on_a_gain32_head():
+    """NOT a parity claim: a record of where bf16 operands stand on the trained-like fixture.  A x32 head multiplies every upstream
+    rounding by 32; the CPU emulation with one precision switch per stage (profiles/precision_study_r04.json) puts bf16 at 1.7e-2
+    with ten stages of 3.5e-3 .. 8.7e-3 each, and at 1.12e-2 even with the classifier on split (bf16 hi + lo) or fp32 operands - the fix
+    the round-3 verdict proposed - so no single-stage repair brings bf16 inside the north star's 1e-2 here.  The modes that are
+    inside a tier on this fixture are fp16 (2e-3, the default), fp16x2 and fp32 (test above).  This test pins the measured envelope
+    (2.3e-2 on the GPU) so that a regression of the bf16 path still shows."""
+    g, err, mism, worst = _run_g1c("bf16")
+    assert err < 3e-2 and worst < 3e-2
 
 
 def test_g2_long_T_31114_bf16():
@@ -149,7 +175,26 @@ def test_g2_long_T_31114_bf16():
     print(f"g2 T=31114 bf16: argmax mismatches {int(mism.sum())} of {T} (frames under margin {int((~safe).sum())})")
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ["fp32", "fp16x2"])
+def test_g2_long_T_31114_exact_argmax(dtype):
+    """the longest Epic-tent-O video length in the two fp32-class modes: all 31 114 argmaxes equal the reference's (smallest
+    reference margin on this fixture: 2.8e-6) and the sampled probabilities agree to 1e-3 / 1e-4 (round-3 verdict items 1, 3)."""
+    g = np.load(os.path.join(G, "g2_miniroad_longT_31114.npz"))
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    m = _model(cfg, sd, dtype)
+    T = 31114
+    rgb = torch.from_numpy(W.tsn_features((T, 2048), 20, f"g2.rgb.{T}")).cuda()
+    outs, args, _ = m.engine().forward_ragged([rgb], None, want_argmax=True)
+    m.engine().check()
+    got = outs[0].cpu().numpy()
+    err = float(np.abs(got[g["sample_idx"]] - g["sample_probs"]).max())
+    mism = args[0].cpu().numpy() != g["argmax"].astype(np.int32)
+    print(f"g2 T=31114 {dtype}: max|dprob| {err:.2e}, argmax mismatches {int(mism.sum())}")
+    assert err < TOL[dtype] and not mism.any()
+
+
+@pytest.mark.parametrize("dtype", ALL_DT)
 def test_ragged_vs_oracle(dtype):
     """ragged clips incl. T=1, lengths around tile edges; some with flow, some zero-flow"""
     cfg = epic_tent_cfg()
@@ -165,9 +210,9 @@ def test_ragged_vs_oracle(dtype):
     for i, T in enumerate(lens):
         f = flow[i] if flow[i] is not None else np.zeros_like(rgb[i])
         ref = O.miniroad_forward(sd, rgb[i][None], f[None], keep=True)
-        _check_probs(outs[i].cpu().numpy(), ref["logits"][0], dtype, f"clip{i}")
+        _check_probs(outs[i].cpu().numpy(), ref["logits"][0], dtype, f"clip{i}", exact=False)
         assert np.array_equal(args[i].cpu().numpy(), outs[i].cpu().numpy().argmax(1))
-        assert np.abs(hl[i].cpu().numpy() - ref["h_last"][0]).max() < (3e-2 if dtype == "bf16" else 4e-3 if dtype == "fp16" else 1e-3)
+        assert np.abs(hl[i].cpu().numpy() - ref["h_last"][0]).max() < HL_TOL[dtype]
 
 
 def test_g2_long_T_31114_fp16_argmax_above_1e3_margin():
@@ -245,7 +290,7 @@ def test_many_clips_all_tile_counts(nclips):
         assert np.abs(outs[i].cpu().numpy() - ref[i, :lens[i]]).max() < 1e-2, i
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ALL_DT)
 def test_chunking_and_streaming_are_bit_exact(dtype):
     """properties: (a) the result does not depend on the chunk size of the packed pipeline;
     (b) two half-clips chained through h_last -> h0 equal one full pass (streaming mode)."""
@@ -277,7 +322,7 @@ def test_chunking_and_streaming_are_bit_exact(dtype):
     assert torch.equal(h2, ha)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+@pytest.mark.parametrize("dtype", ALL_DT)
 def test_continuous_batching_matches_per_clip_results(dtype):
     """more clips than recurrence slots: several clips share a slot back to back (h restarts at 0 at every clip
     boundary, chunk boundaries fall anywhere).  Every clip must come out exactly as when it is run alone."""
@@ -285,7 +330,7 @@ def test_continuous_batching_matches_per_clip_results(dtype):
     sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
     m = _model(cfg, sd, dtype)
     eng = m.engine()
-    n = 300 if dtype in DT16 else 150                      # > 128 (bf16) / 64 (fp32) slots of one tile layer
+    n = 300 if dtype in DT16 else 150                      # > 128 (bf16) / 64 (fp32, fp16x2) slots of one tile layer
     lens = [3 + (i * 7) % 40 for i in range(n)]
     lens[5] = 200                                            # one long clip sets the number of sequential steps
     rgb = [torch.from_numpy(W.tsn_features((T, 2048), 13, f"cb.{i}")).cuda() for i, T in enumerate(lens)]

@@ -346,3 +346,25 @@ def test_data_parallel_bucket_path_on_one_gpu_with_a_stand_in_collective(monkeyp
         else:
             err = (got[k] - ref[k]).abs().max().item()
             assert err <= 2.0 ** -7 * ref[k].abs().max().item() + 1e-12, (k, err)
+
+
+def test_rccl_allreduce_of_the_real_gradient_bucket_in_a_one_rank_group():
+    """BASELINE configs[2] ("DP with RCCL grad all-reduce", trainer/train.py:20-24): on the one-GPU test box the collective path can
+    only run in a one-rank group - but it does run: a fresh child process (tests/helpers/nccl_world1_child.py; this pytest process
+    is never re-exec'ed) initialises RCCL, and with PREGO_DP_FORCE_COLLECTIVE=1 the trainer pushes the real 71.7 MB bucket through
+    ncclAllReduce in three sub-buckets on the comm stream behind the backward's events, in fp32 and bf16 wire formats, then runs two
+    optimizer steps with the all-reduce enqueued before the engine check.  (Round 3 only ever met a monkeypatched all_reduce.)"""
+    import json
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(__file__), "helpers", "nccl_world1_child.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PREGO_DP_FORCE_COLLECTIVE", None)
+    r = subprocess.run([sys.executable, child], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rep = json.loads(line)
+    print(line)
+    assert rep["ok"] and rep["backend"] == "nccl" and rep["bucket_bytes"] >= 71_704_920
+    assert rep["allreduce_fp32"]["wire_dtype"] == "torch.float32" and rep["allreduce_bf16"]["wire_dtype"] == "torch.bfloat16"
+    assert rep["trainer_two_steps_identical"]

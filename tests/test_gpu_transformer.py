@@ -304,7 +304,7 @@ def test_attention_forward_kernel_vs_fp64(Nq, N, dh, causal):
     Inputs are bf16-exact, so only the kernel's own rounding shows (P and the output are rounded to bf16)."""
     import ctypes as C
     from prego_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_debug()          # prego_debug_attention_fwd: only in libprego_amd_debug.so
     B, h = 2, 3
     rng = np.random.default_rng(Nq * 7 + N + dh + causal)
 

@@ -100,7 +100,7 @@ def test_attention_backward_kernel_vs_oracle(N, dh, causal):
     """dq, dk, dv of softmax(q k^T dh^-0.5 [+ causal mask]) v against the fp64 formulas (oracle_np.vit_loss_and_grads uses the
     same ones); inputs bf16-exact so that only the kernel's own rounding shows."""
     from prego_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_debug()          # prego_debug_attention_bwd: only in libprego_amd_debug.so
     lib.prego_debug_attention_bwd.argtypes = [C.c_int] * 5 + [C.c_void_p] * 7 + [C.c_void_p]
     B, h = 2, 2
     E = h * dh

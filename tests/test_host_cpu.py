@@ -18,13 +18,42 @@ def test_abi_library_builds_loads_and_exports_every_declared_symbol():
     ge.build()
     from prego_amd import _lib
     lib = _lib.load()
-    assert lib.prego_abi_version() == 3
+    assert lib.prego_abi_version() == 4
     hdr = open(os.path.join(ROOT, "include", "prego_amd.h")).read()
     declared = sorted(set(re.findall(r"\b(prego_[a-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations found"
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/prego_amd.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared
+    # the probe / unit-test entry points are NOT in the product library; the debug library has both sets
+    dhdr = open(os.path.join(ROOT, "include", "prego_amd_debug.h")).read()
+    ddecl = sorted(set(re.findall(r"\b(prego_[a-z0-9_]+)\s*\(", dhdr)))
+    assert ddecl == sorted(_lib.DEBUG_SYMBOLS)
+    assert not any("debug" in n for n in declared)
+    for name in ddecl:
+        assert not hasattr(lib, name), f"{name} is a debug entry point but the product library exports it"
+    dbg = _lib.load_debug()
+    for name in declared + ddecl:
+        assert hasattr(dbg, name), f"{name} missing from libprego_amd_debug.so"
+
+
+def test_build_rebuilds_when_the_recorded_source_hash_differs_from_the_tree(tmp_path):
+    """a prebuilt library that does not belong to this tree must not pass as current: build() compares build_info.json's
+    sources_sha256 with the tree and build_info() says so"""
+    import json
+    from prego_amd import build as B
+    B.build()
+    info = B.build_info()
+    assert info["sources_match_tree"] and "STALE" not in info["build_mode"]
+    p = os.path.join(B.LIBDIR, "build_info.json")
+    saved = open(p).read()
+    try:
+        d = json.loads(saved)
+        d["sources_sha256"] = "0" * 64
+        json.dump(d, open(p, "w"))
+        assert not B.build_info()["sources_match_tree"] and "STALE" in B.build_info()["build_mode"]
+    finally:
+        open(p, "w").write(saved)
 
 
 def test_product_path_fails_loudly_without_gpu():
