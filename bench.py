@@ -167,6 +167,8 @@ def train_mode(args, rank, world, dev, dist):
                        "local_batch": Bl, "parallelism": f"window-sharded dp{world}, one gradient all-reduce per step in 3 sub-buckets (RCCL)",
                        "weights": "random init, seed 20"},
             "grad_bucket_bytes": bucket, "grad_wire_bytes": wire, "grad_compress": args.grad_compress,
+            # PREGO_DP_FORCE_COLLECTIVE=1 in a one-rank process group (RANK=0 WORLD_SIZE=1 in the environment): the RCCL path runs at N = 1
+            "collective_ran": bool(dist is not None and (world > 1 or os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1")),
             "ring_allreduce_floor_ms": (2.0 * (world - 1) / world * wire / 153e9 * 1e3) if world > 1 else 0.0,
             "roofline": {"bound": "mfma", "achieved": fl / step_ms / 1e9 / world, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / step_ms / 1e9 / world / PEAK_BF16_TFLOPS,

@@ -156,6 +156,13 @@ int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits,
  * final - so the caller can all-reduce those buckets on another stream under the rest of the backward (layer1's weight gradient,
  * 47 % of the bytes, is final only when backward returns).  The events stay owned by the caller. */
 int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_done, void* ev_gru_done);
+/* Optional host callback of backward(): fn(user, bucket) is called on the calling thread, from inside prego_miniroad_backward, right after
+ * the launches that make a group of gradient tensors final have been ENQUEUED and its event (above) recorded - bucket 0: f_classification,
+ * bucket 1: the four GRU tensors.  A data-parallel caller enqueues that bucket's all-reduce there (behind the event, on its own
+ * stream), i.e. ahead of the ~30 launches of the rest of the backward instead of behind them.  The callback must not call back into
+ * this handle.  fn = NULL removes it. */
+typedef void (*prego_bucket_fn)(void* user, int bucket);
+int prego_miniroad_backward_callback(prego_miniroad* h, prego_bucket_fn fn, void* user);
 size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens);
 int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* dlogits,
                             float* g_layer1_w, float* g_layer1_b, float* g_ln_w, float* g_ln_b, float* g_w_ih,

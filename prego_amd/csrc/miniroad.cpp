@@ -90,6 +90,7 @@ struct prego_miniroad {
   // data-parallel training: events the NEXT backward records when a group of gradient tensors is final (prego_miniroad_backward_events),
   // so that the caller can start reducing that bucket on another stream while the rest of the backward runs
   hipEvent_t bwd_ev[2] = {nullptr, nullptr};
+  prego_bucket_fn bwd_cb = nullptr; void* bwd_cb_user = nullptr;     // prego_miniroad_backward_callback: called right behind each event record
   // plan cache
   std::vector<int32_t> plan_lens;
   std::vector<int> h_rowoff, h_nact, h_sorted;      // h_sorted: first clip of each slot (slot order)
@@ -996,6 +997,14 @@ extern "C" int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_d
   return PREGO_OK;
 }
 
+extern "C" int prego_miniroad_backward_callback(prego_miniroad* h, prego_bucket_fn fn, void* user) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  h->bwd_cb = fn;
+  h->bwd_cb_user = user;
+  return PREGO_OK;
+}
+
 extern "C" size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens) {
   if (!h || n_clips <= 0 || !lens) return 0;
   long long total = 0;
@@ -1064,6 +1073,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   gemm_nt(h, bw + L.dLt, Rp, bw + L.HRt, Rp, nullptr, (float*)(bw + L.dWc), H, Cp, H, Rp, s);   // dWc[Cp][H]
   HIPCHK(hipMemcpyAsync(g_fc_w, bw + L.dWc, (size_t)C * H * 4, hipMemcpyDeviceToDevice, s));
   if (h->bwd_ev[0]) HIPCHK(hipEventRecord(h->bwd_ev[0], s));            // f_classification gradients are final
+  if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 0);
   launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
   gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
   launch_relu_mask((const float*)(bw + L.dHR), HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);
@@ -1113,6 +1123,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
   gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
   if (h->bwd_ev[1]) HIPCHK(hipEventRecord(h->bwd_ev[1], s));            // all four GRU gradients are final (layer1 / LayerNorm follow)
+  if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 1);
   // d e = dGI . W_ih
   launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
   gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);

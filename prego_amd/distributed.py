@@ -83,19 +83,14 @@ def allreduce_mean_(flat: torch.Tensor, world: int, weight: float = 1.0, force: 
 _COMM_STREAMS = {}
 
 
-def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None, compress: str | None = None, weight: float = 1.0,
-                            force: bool = False):
-    """Gradient averaging of the flat bucket in sub-buckets `bounds` = [(lo, hi), ...] given in the order the backward finishes
-    them.  On a GPU every sub-bucket is reduced on a side stream as soon as its event (events[i]; None = "final in stream order")
-    has fired, i.e. under the rest of the backward; the caller's stream waits for the side stream at the end.  compress='bf16'
-    sends bf16 (half the bytes over the xGMI ring; the sum runs in bf16 on the wire, the average and everything after it in fp32).
-    On CPU tensors (gloo tests) the same sub-buckets are reduced one after the other.  weight / force: see allreduce_mean_."""
-    if world <= 1 and not force:
-        return flat
+def allreduce_bucket_(flat: torch.Tensor, lo: int, hi: int, world: int, event=None, compress: str | None = None, weight: float = 1.0):
+    """ENQUEUE the averaging all-reduce of flat[lo:hi] (no host wait).  GPU tensors: on the device's comm stream, behind `event` (the
+    moment the backward made this sub-bucket final) or, with event = None, behind everything enqueued on the current stream so far;
+    the caller joins with allreduce_join_ before it reads the gradients.  CPU tensors (gloo tests): the collective runs here."""
     if compress not in (None, "bf16"):
         raise ValueError(f"compress {compress!r}: expected None or 'bf16'")
 
-    def one(lo, hi):
+    def one():
         view = flat[lo:hi]
         if compress == "bf16":
             buf = view.to(torch.bfloat16)
@@ -106,22 +101,42 @@ def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None,
         _scale_(view, world, weight)
 
     if not flat.is_cuda:
-        for lo, hi in bounds:
-            one(lo, hi)
-        return flat
+        one()
+        return
     dev = flat.device
     comm = _COMM_STREAMS.get(dev)
     if comm is None:
         comm = _COMM_STREAMS[dev] = torch.cuda.Stream(dev)
-    cur = torch.cuda.current_stream(dev)
     flat.record_stream(comm)
+    if event is not None:
+        comm.wait_event(event)           # recorded inside prego_miniroad_backward when this sub-bucket became final
+    else:
+        comm.wait_stream(torch.cuda.current_stream(dev))      # final once everything enqueued so far has run
+    with torch.cuda.stream(comm):
+        one()
+
+
+def allreduce_join_(flat: torch.Tensor):
+    """the current stream waits for every sub-bucket enqueued on the comm stream (before optimizer.step reads the gradients)"""
+    if flat.is_cuda:
+        comm = _COMM_STREAMS.get(flat.device)
+        if comm is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(comm)
+
+
+def allreduce_mean_buckets_(flat: torch.Tensor, bounds, world: int, events=None, compress: str | None = None, weight: float = 1.0,
+                            force: bool = False, skip=()):
+    """Gradient averaging of the flat bucket in sub-buckets `bounds` = [(lo, hi), ...] given in the order the backward finishes
+    them.  On a GPU every sub-bucket is reduced on a side stream as soon as its event (events[i]; None = "final in stream order")
+    has fired, i.e. under the rest of the backward; the caller's stream waits for the side stream at the end.  compress='bf16'
+    sends bf16 (half the bytes over the xGMI ring; the sum runs in bf16 on the wire, the average and everything after it in fp32).
+    On CPU tensors (gloo tests) the same sub-buckets are reduced one after the other.  weight / force: see allreduce_mean_.
+    skip: indices of sub-buckets that were already enqueued from inside the backward (engine bucket hook)."""
+    if world <= 1 and not force:
+        return flat
     for i, (lo, hi) in enumerate(bounds):
-        ev = events[i] if events is not None else None
-        if ev is not None:
-            comm.wait_event(ev)          # recorded inside prego_miniroad_backward when this sub-bucket became final
-        else:
-            comm.wait_stream(cur)        # final once everything enqueued so far has run
-        with torch.cuda.stream(comm):
-            one(lo, hi)
-    cur.wait_stream(comm)
+        if i in skip:
+            continue
+        allreduce_bucket_(flat, lo, hi, world, events[i] if events is not None else None, compress, weight)
+    allreduce_join_(flat)
     return flat

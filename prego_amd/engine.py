@@ -239,6 +239,26 @@ class MiniRoadEngine:
         self._train_ctx = (B, T, lens_arr, rgb, flow)
         return out
 
+    _CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+
+    def set_bucket_hook(self, fn):
+        """fn(engine, i) is called from INSIDE backward(), on the calling thread, right after the launches that make sub-bucket i of the flat
+        gradient final have been enqueued and its event recorded (i = 0 head, 1 GRU; bucket 2 is final when backward returns): the
+        data-parallel trainer enqueues that sub-bucket's all-reduce there.  None removes the hook."""
+        self._bucket_hook = fn
+        if fn is None:
+            self._cb = None
+            check(self.lib.prego_miniroad_backward_callback(self.h, None, None))
+            return
+
+        def tramp(_user, i):
+            try:
+                fn(self, int(i))
+            except BaseException as e:          # never unwind through the C frames: surface it after the call
+                self._cb_error = e
+        self._cb = self._CB(tramp)
+        check(self.lib.prego_miniroad_backward_callback(self.h, self._cb, None))
+
     def backward(self, dlogits: torch.Tensor) -> dict:
         """gradients of the ten parameters (reference state_dict names) for the last forward_train()."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
@@ -265,6 +285,8 @@ class MiniRoadEngine:
         o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
         self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]
         self._grad_events = None
+        self._early_done = set()
+        self._cb_error = None
         dp = torch.distributed.is_available() and torch.distributed.is_initialized()
         if dp and (torch.distributed.get_world_size() > 1 or os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1"):
             if getattr(self, "_bwd_events", None) is None:
@@ -281,6 +303,11 @@ class MiniRoadEngine:
                 self.h, B, lens_arr, dl_p, *[C.c_void_p(grads[k].data_ptr()) for k in _PARAM_ORDER],
                 C.c_void_p(self._ws_train.data_ptr()), self._ws_train.numel(),
                 C.c_void_p(self._ws_bwd.data_ptr()), self._ws_bwd.numel(), C.c_void_p(_stream_ptr(self.device))))
+        if self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise e
+        if getattr(self, "_bucket_hook", None) is not None and self._grad_events is None:
+            self._early_done = set()            # hook armed without a process group: nothing was reduced
         return grads
 
     def check(self):

@@ -7,8 +7,41 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
-from .distributed import allreduce_mean_, allreduce_mean_buckets_
+from .distributed import allreduce_bucket_, allreduce_mean_, allreduce_mean_buckets_
 from .registry import TRAINER
+
+
+def _dp_state():
+    import os
+    init = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if init else 1
+    force = init and os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1"
+    return world, force
+
+
+def _arm_early_allreduce(model, weight: float = 1.0):
+    """Before loss.backward(): let the HIP backward hand every sub-bucket to the collective AT THE MOMENT ITS LAUNCHES ARE ENQUEUED
+    (prego_miniroad_backward_callback -> engine bucket hook), not after backward() has returned on the host.  The backward is ~50
+    launches; enqueuing the head / GRU all-reduce only behind all of them left them 30-70 us of the backward to hide under (rocprof
+    trace of round 4, profiles/r04_train_overlap_trace.json), from inside the backward the GRU bucket gets the whole layer1 / LayerNorm
+    tail and the head bucket the BPTT as well."""
+    world, force = _dp_state()
+    eng_of = getattr(model, "engine", None)
+    if (world == 1 and not force) or eng_of is None:
+        return
+    try:
+        eng = model.engine(train=True)
+    except TypeError:
+        return
+    if not hasattr(eng, "set_bucket_hook"):
+        return
+    compress = getattr(model, "grad_compress", None)
+
+    def hook(e, i):
+        lo, hi = e._grad_bounds[i]
+        allreduce_bucket_(e._grad_flat, lo, hi, world, e._grad_events[i], compress, weight)
+        e._early_done.add(i)
+    eng.set_bucket_hook(hook)
 
 
 def _allreduce_grads(model, weight: float = 1.0):
@@ -16,10 +49,7 @@ def _allreduce_grads(model, weight: float = 1.0):
     Everything here is ENQUEUED (collectives on a side stream behind the backward's events): no host synchronisation, so the head and
     GRU sub-buckets travel under the rest of the backward.  PREGO_DP_FORCE_COLLECTIVE=1 runs the collective path in a one-rank
     process group as well (GPU test of this path on a one-GPU box)."""
-    import os
-    init = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size() if init else 1
-    force = init and os.environ.get("PREGO_DP_FORCE_COLLECTIVE") == "1"
+    world, force = _dp_state()
     if world == 1 and not force:
         return
     ps = [p for p in model.parameters() if p.grad is not None]
@@ -31,7 +61,7 @@ def _allreduce_grads(model, weight: float = 1.0):
         bounds = getattr(eng, "_grad_bounds", None)
         if bounds:
             allreduce_mean_buckets_(flat, bounds, world, getattr(eng, "_grad_events", None), getattr(model, "grad_compress", None),
-                                    weight=weight, force=force)
+                                    weight=weight, force=force, skip=getattr(eng, "_early_done", ()))
         else:
             allreduce_mean_(flat, world, weight, force)
         return
@@ -72,6 +102,7 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
                 out_dict = model(rgb_input, flow_input)
                 loss = criterion(out_dict, target)
             optimizer.zero_grad(set_to_none=True)
+            _arm_early_allreduce(model, w)
             scaler.scale(loss).backward()
             _allreduce_grads(model, w)         # enqueued behind the backward's events, BEFORE the host waits for anything
             _check_engine(model)               # synchronises; only gates optimizer.step()
@@ -81,6 +112,7 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
             out_dict = model(rgb_input, flow_input)
             loss = criterion(out_dict, target)
             optimizer.zero_grad(set_to_none=True)
+            _arm_early_allreduce(model, w)
             loss.backward()
             _allreduce_grads(model, w)         # enqueued behind the backward's events, BEFORE the host waits for anything
             _check_engine(model)               # synchronises; only gates optimizer.step()
