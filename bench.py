@@ -5,7 +5,10 @@
 
 One "step" = one pass of the MiniROAD eval path (features -> per-frame probabilities + argmax) over one
 Assembly101-O-test-split-sized set of whole videos (BASELINE.json configs[1]): 182 clips, ragged lengths,
-fp32 [T,2048] rgb and [T,2048] flow features already resident in HBM, bf16 MFMA operands / fp32 accumulate.
+fp32 [T,2048] rgb and [T,2048] flow features already resident in HBM, 16-bit MFMA operands / fp32 accumulate: IEEE fp16 by
+default (`dtype` in the line; the same width, bytes and matrix rate as the bf16 configs[1] names, 8x less operand rounding -
+DESIGN.md section 3); the same line carries `value_bf16`, `value_fp16x2` (split operands: argmax-identical to the reference)
+and `value_fp32`.
 With --gpus N every rank owns its own clip set of that size (clip-sharded data parallel, no collective on the
 data path): weak scaling.  Rank 0 prints ONE JSON line.
 """
@@ -358,6 +361,7 @@ def main():
             torch.cuda.empty_cache()
             line["secondary"] = secondary(dev, lens, sd, args.dtype)
             line["value_fp32"] = line["secondary"].get("value_fp32")
+            line["value_fp16x2"] = line["secondary"].get("value_fp16x2")
             other = "bf16" if args.dtype == "fp16" else "fp16"
             line[f"value_{other}"] = line["secondary"].get(f"value_{other}")
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
@@ -482,6 +486,30 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
     res["vit"] = {"shape": "256 windows x 128 frames, heads 8, 1 layer", "ms": ms,
                   "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "SURVEY 8d: 7.69 GFLOP per window (algorithmic)"}}
+    # BASELINE configs[3]: the LONG window - ViTEnc(window_size = 1024) = 1 025 tokens, 12 classes (Epic-tent-O), non-causal as the
+    # reference's SelfAttention is (Attention.py:21-41) and with the causal_attention extension; 32 windows per call
+    for causal_ in (False, True):
+        lcfg = assembly101_cfg(model="Transformer", window_size=1024, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0,
+                               num_classes=12, causal_attention=causal_)
+        lm = build_model(lcfg, dev)
+        lm.load_state_dict({k: torch.from_numpy(v) for k, v in W.vit_state_dict(lcfg, 20).items()})
+        lm.eval()
+        Bl_ = 32
+        lr_ = torch.randn(Bl_, 1024, 2048, device=dev)
+        lf_ = torch.randn(Bl_, 1024, 2048, device=dev)
+        with torch.no_grad():
+            ms = _time_ms(lambda: lm(lr_, lf_), n=5, warm=2)
+        # SURVEY 8d per window of T = 1024 (N = 1025, one layer, last block for token 0 only is NOT discounted: algorithmic work)
+        N_ = 1025
+        att = 4 * 8 * N_ * N_ * 256 * (0.5 if causal_ else 1.0)
+        flw = 2 * 1024 * 4096 * 2048 + 2 * N_ * 2048 * 6144 + att + 2 * N_ * 2048 * 2048 + 4 * N_ * 2048 * 1024 + 2 * 2048 * 12
+        key = "vit_w1024_causal" if causal_ else "vit_w1024"
+        res[key] = {"shape": f"{Bl_} windows x 1024 frames (1 025 tokens), heads 8 x 256, 1 layer, C = 12" + (", causal" if causal_ else ""),
+                    "ms": ms, "windows_per_s": Bl_ / ms * 1e3, "frames_per_s": Bl_ * 1024 / ms * 1e3,
+                    "roofline": {"bound": "mfma", "achieved": Bl_ * flw / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": Bl_ * flw / ms / 1e9 / PEAK_BF16_TFLOPS, "note": "SURVEY 8d algorithmic FLOPs per window: %.1f G" % (flw / 1e9)}}
+        del lm, lr_, lf_
+        torch.cuda.empty_cache()
     # online use of the Transformer entry: one 128-frame window per call (a new window per incoming frame)
     x1r, x1f = xr[:1].contiguous(), xf[:1].contiguous()
     with torch.no_grad():
@@ -537,7 +565,8 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
     rgb = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
     flow = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
     other = "bf16" if head_dtype == "fp16" else "fp16"
-    for dt_, n_, warm_ in ((other, 5, 2), ("fp32", 2, 1)):
+    # ... and with split fp16 operands (fp16x2: three fp16 products per product, fp32-class results - the argmax-identical mode)
+    for dt_, n_, warm_ in ((other, 5, 2), ("fp16x2", 4, 1), ("fp32", 2, 1)):
         mx = build_model(assembly101_cfg(compute_dtype=dt_), dev)
         mx.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         mx.eval()

@@ -226,6 +226,30 @@ def g5():
     print("g5 logits", out.shape, float(np.abs(out).max()))
 
 
+def g5c():
+    """ViTEnc at the LONG window of BASELINE configs[3] (Epic-tent-O: window 1024 -> N = 1025 tokens, 12 classes, 8 heads of 256):
+    logits of 2 windows + rows of the first block's LayerNorm / attention / FFN outputs from the reference itself."""
+    from model import build_model
+    cfg = _vit_cfg(window=1024, classes=12)
+    sd = W.vit_state_dict(cfg, seed=20)
+    model = _load(build_model(cfg, "cpu"), sd).eval()
+    B, T = 2, 1024
+    rgb = W.tsn_features((B, T, 2048), 20, "g5c.rgb")
+    flow = W.tsn_features((B, T, 2048), 20, "g5c.flow")
+    cap = {}
+    hooks = [
+        model.encoder.net[0].fn.fn.register_forward_hook(lambda m, i, o: cap.__setitem__("attn", o.detach().numpy().copy())),
+        model.encoder.net[1].fn.fn.register_forward_hook(lambda m, i, o: cap.__setitem__("ffn", o.detach().numpy().copy())),
+    ]
+    with torch.no_grad():
+        out = model(torch.from_numpy(rgb), torch.from_numpy(flow))["logits"].numpy()
+    for h in hooks:
+        h.remove()
+    rows = np.array([0, 1, 511, 1023, 1024])
+    np.savez_compressed(os.path.join(OUT, "g5c_vit_forward_w1024.npz"), logits=out, rows=rows, **{k: v[:, rows] for k, v in cap.items()})
+    print("g5c logits", out.shape, float(np.abs(out).max()))
+
+
 def g6():
     """Causal attention: AttentionLayer(FullAttention(mask_flag=True, attention_dropout=0)) - dead code in the
     reference (attn.py:35-57,139-170) but the only causal definition."""
@@ -458,7 +482,7 @@ def g9():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-GROUPS = {"g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
+GROUPS = {"g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

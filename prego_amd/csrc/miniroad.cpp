@@ -273,6 +273,12 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
 // Round 3: two or more tiles run on the software-pipelined kernel (gru_recurrence_mt_kernel): 2.0 / 3.84 / 7.41 us per step for
 // 1 / 2 / 4 tiles (scripts/probes/mt_ab2.sh; the classic kernel: 2.0 / 3.99 / 8.47 on the same device).
 static const double kStepCost[5] = {0.0, 2.0, 3.84, 5.7, 7.41};
+// Round 4, the 64-workgroup groups (G = 4): split fp16 operands 3.14 / 4.64 us for 1 / 2 tiles (two tiles at most), exact-fp32 operands
+// 6.89 / 9.25 (bench workload forced into 64 / 128 slots, PREGO_PLAN_SLOTS; three and four tiles extrapolated): a second tile costs
+// less than the first there (its gather rides under the first tile's MFMAs), so equal-length batches prefer more slots than the
+// 16-bit table would choose
+static const double kStepCostX2[5] = {0.0, 3.14, 4.64, 1e9, 1e9};
+static const double kStepCostF32[5] = {0.0, 6.89, 9.25, 11.6, 14.0};
 
 // Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
 // backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
@@ -317,7 +323,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
     const int layers = (S + per_layer - 1) / per_layer;
     for (int k = layers - 1; k >= 0; --k) {            // layer k lives as long as its most loaded slot = sorted_load[k*per_layer]
       const long long life = sorted_load[(size_t)k * per_layer];
-      cost += (double)(life - prev) * kStepCost[std::min(4, k + 1)];
+      cost += (double)(life - prev) * (h->x2 ? kStepCostX2 : h->bf16 ? kStepCost : kStepCostF32)[std::min(4, k + 1)];
       prev = life;
     }
     c.cost = cost;

@@ -47,6 +47,49 @@ def test_g5_vit_forward_matches_reference(dtype):
     assert np.array_equal(got.argmax(-1), g["logits"].argmax(-1))
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
+def test_g5c_vit_long_window_1024_matches_reference(dtype):
+    """BASELINE configs[3] sizes the transformer path at the LONG window: ViTEnc(window_size = 1024) = 1 025 tokens per window
+    (ViT.py:117-143, learned positional table of 1 025 rows: PositionalEncoding.py:25-41), 8 heads of 256, 12 classes (Epic-tent-O).
+    Against the reference's own logits (fixture G5c), and - the causal_attention extension on - against the numpy oracle; four
+    windows so that the 4 100 token rows take the ping-pong GEMM epilogues and the 8-wave attention kernel's long-sequence form."""
+    from prego_amd.registry import build_model
+    import prego_amd.transformer  # noqa: F401
+    g = np.load(os.path.join(G, "g5c_vit_forward_w1024.npz"))
+    cfg = assembly101_cfg(model="Transformer", window_size=1024, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, num_classes=12,
+                          compute_dtype=dtype)
+    sd = W.vit_state_dict(cfg, 20)
+    assert sd["position_encoding.pe.weight"].shape == (1025, 2048)
+    m = build_model(cfg, "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    rgb = W.tsn_features((4, 1024, 2048), 21, "g5c.more.rgb")
+    flow = W.tsn_features((4, 1024, 2048), 21, "g5c.more.flow")
+    rgb[:2] = W.tsn_features((2, 1024, 2048), 20, "g5c.rgb")
+    flow[:2] = W.tsn_features((2, 1024, 2048), 20, "g5c.flow")
+    trgb, tflow = torch.from_numpy(rgb).cuda(), torch.from_numpy(flow).cuda()
+    with torch.no_grad():
+        out = m(trgb, tflow)["logits"].cpu().numpy()
+    assert out.shape == (4, 1, 12)
+    scale = max(1.0, float(np.abs(g["logits"]).max()))
+    err = float(np.abs(out[:2] - g["logits"]).max())
+    print(f"vit window 1024 {dtype}: max abs err {err:.2e} (scale {scale:.2f})")
+    assert err < VTOL[dtype] * scale
+    assert np.array_equal(out[:2].argmax(-1), g["logits"].argmax(-1))
+    if dtype == "fp32":
+        return                                      # the fp32-operand mode has no causal attention kernel (DESIGN section 8)
+    # causal_attention (extension): token i attends to tokens <= i; the cls token sits at the END, token 0 is what the head reads
+    mc = build_model(dict(cfg, causal_attention=True), "cuda:0")
+    mc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    mc.eval()
+    with torch.no_grad():
+        outc = mc(trgb[2:], tflow[2:])["logits"].cpu().numpy()
+    ref = O.vit_forward(sd, rgb[2:], flow[2:], heads=8, causal=True)["logits"]
+    errc = float(np.abs(outc - ref).max())
+    print(f"vit window 1024 causal {dtype}: max abs err {errc:.2e}")
+    assert errc < VTOL[dtype] * max(1.0, float(np.abs(ref).max()))
+
+
 def test_fp32_operand_mode_two_layers_noncausal_and_its_limits():
     """compute_dtype='fp32' (parity mode): ViTEnc with two layers against G5b's reference logits, the unmasked AttentionLayer at a
     ragged length against the numpy oracle, and the entry points the mode does not cover fail loudly"""

@@ -143,6 +143,20 @@ def test_g5_vit_forward():
         assert np.abs(out[k][:, g["rows"]] - g[k]).max() < 5e-5, k
 
 
+def test_g5c_vit_forward_long_window_1024():
+    """the oracle at BASELINE configs[3]'s long window (N = 1025 tokens, 12 classes) against the reference's own output"""
+    g = _ld("g5c_vit_forward_w1024.npz")
+    cfg = assembly101_cfg(model="Transformer", window_size=1024, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, num_classes=12)
+    sd = W.vit_state_dict(cfg, 20)
+    rgb = W.tsn_features((2, 1024, 2048), 20, "g5c.rgb")
+    flow = W.tsn_features((2, 1024, 2048), 20, "g5c.flow")
+    out = O.vit_forward(sd, rgb, flow, heads=8, keep=True)
+    assert out["logits"].shape == (2, 1, 12)
+    assert np.abs(out["logits"] - g["logits"]).max() < 2e-5
+    for k in ("attn", "ffn"):
+        assert np.abs(out[k][:, g["rows"]] - g[k]).max() < 5e-5, k
+
+
 @pytest.mark.parametrize("L", [128, 1024])
 def test_g6_causal_attention(L):
     g = _ld(f"g6_causal_attention_L{L}.npz")
