@@ -127,6 +127,18 @@ int prego_miniroad_step(prego_miniroad* h, int n_streams, const float* rgb, cons
 /* Synchronises `stream` and reports a recurrence timeout (PREGO_ETIMEOUT) or HIP error since the last check. */
 int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream);
 
+/* Link-fed inference (the eval loop of trainer/eval.py:36-56 with features in host memory): let the H2D copy of a batch run UNDER its
+ * forward instead of in front of it.
+ *   plan_starts       the slot schedule the next forward of exactly these clips will use, costed for features that arrive at link speed
+ *                     (link_row_bytes = bytes one frame moves over the link; 0 = features already in HBM): start_step[i] = the step at
+ *                     which frame 0 of clip i is consumed, so frame a of clip i is needed at step start_step[i] + a; *n_steps = steps.
+ *   set_feed_events   for the NEXT forward only: rows needed at steps < upto_step[j] are valid in the rgb / flow arrays once
+ *                     events[0..j] (hipEvent_t recorded by the caller behind its copies, upto_step ascending) have fired; the last
+ *                     upto_step must be >= *n_steps.  The library makes its packing stream wait for the events a chunk needs - the
+ *                     caller copies in need order and never waits on the host.  Plain inference calls only (no h0 / h_last / KEEP). */
+int prego_miniroad_plan_starts(prego_miniroad* h, int n_clips, const int32_t* lens, int link_row_bytes, int32_t* start_step, int32_t* n_steps);
+int prego_miniroad_set_feed_events(prego_miniroad* h, int n_events, const int32_t* upto_step, void* const* events, int link_row_bytes);
+
 /* Kernel-level timing hooks for bench.py's roofline leg: when enabled, forward() brackets its GEMM launches and
  * its recurrence launches with HIP events on the caller's stream; read() synchronises and returns the summed
  * milliseconds and launch counts since enable. */

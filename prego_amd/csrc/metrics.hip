@@ -20,7 +20,7 @@
 
 #define AP_TILE 4096          // elements per radix tile (one wave, 64 steps of 64)
 #define AP_RADIX 256
-#define AP_PASSES 5           // key bits [1, 41)
+#define AP_PASSES 4           // key bits [1, 33): the key is the 32-bit score key << 1 | label, bits above 32 are zero (a fifth pass only copied)
 
 // order-reversing key of a float score: larger score -> smaller key; -0.0 == +0.0 (sklearn compares values, not bits)
 __device__ __forceinline__ unsigned ap_desc_key(float s) {

@@ -100,6 +100,9 @@ struct prego_miniroad {
   int n_slots = 0;
   bool plan_single = true;       // one clip per slot (required for h0 / h_last / training)
   bool plan_want_single = false;
+  int plan_host_row_bytes = 0;   // PCIe bytes per packed row the cached plan was costed with (0 = features in HBM)
+  // feed events of the NEXT forward (prego_miniroad_set_feed_events): rows of steps < feed_upto[j] are valid once feed_ev[0..j] have fired
+  std::vector<int> feed_upto; std::vector<hipEvent_t> feed_ev; size_t feed_pos = 0; int feed_row_bytes = 0;
   int t_max = 0;
   int* d_rowoff = nullptr; int* d_nact = nullptr; int* d_sorted = nullptr;
   int* d_seg_off = nullptr; int* d_seg_clip = nullptr; int* d_seg_start = nullptr;
@@ -283,8 +286,13 @@ static const double kStepCostF32[5] = {0.0, 6.89, 9.25, 11.6, 14.0};
 // Slot schedule.  want_single: one clip per slot (needed when the caller passes h0 / h_last or keeps activations for
 // backward); otherwise the clips are packed longest-first into the number of slots (128 / 256 / 512 for bf16) that
 // minimises the estimated recurrence time: sequential steps = max(longest clip, frames / slots).
-static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single) {
-  if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin()) && h->plan_want_single == want_single)
+// host_row_bytes > 0: the features live in pinned HOST memory and every packed row costs that many bytes over PCIe (PREGO_FWD_HOSTFEAT):
+// a step can then be bound by the link - live slots x row bytes at ~50 GB/s - instead of by the recurrence, and the slot count that
+// minimises the pass is the one that keeps the link evenly busy for the whole run (about frames / longest clip slots: every slot
+// alive to the end), not the one that minimises the number of steps.
+static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single, int host_row_bytes = 0) {
+  if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin()) && h->plan_want_single == want_single &&
+      h->plan_host_row_bytes == host_row_bytes)
     return PREGO_OK;
   long long total = 0;
   int lmax = 0;
@@ -319,27 +327,46 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
     }
     std::vector<long long> sorted_load = c.load;
     std::sort(sorted_load.begin(), sorted_load.end(), std::greater<long long>());
+    const double* tab = h->x2 ? kStepCostX2 : h->bf16 ? kStepCost : kStepCostF32;
     double cost = 0; long long prev = 0;
-    const int layers = (S + per_layer - 1) / per_layer;
-    for (int k = layers - 1; k >= 0; --k) {            // layer k lives as long as its most loaded slot = sorted_load[k*per_layer]
-      const long long life = sorted_load[(size_t)k * per_layer];
-      cost += (double)(life - prev) * (h->x2 ? kStepCostX2 : h->bf16 ? kStepCost : kStepCostF32)[std::min(4, k + 1)];
-      prev = life;
+    if (host_row_bytes <= 0) {
+      const int layers = (S + per_layer - 1) / per_layer;
+      for (int k = layers - 1; k >= 0; --k) {            // layer k lives as long as its most loaded slot = sorted_load[k*per_layer]
+        const long long life = sorted_load[(size_t)k * per_layer];
+        cost += (double)(life - prev) * tab[std::min(4, k + 1)];
+        prev = life;
+      }
+    } else {
+      // steps (sorted_load[k + 1], sorted_load[k]] have k + 1 live slots: the step costs what the slower of the recurrence and the
+      // link needs (us; 50 GB/s = 50 000 bytes per us: what a throttled pack kernel pulls from pinned memory, h2d copies reach 57)
+      for (int k = S - 1; k >= 0; --k) {
+        const long long life = sorted_load[(size_t)k];
+        if (life <= prev) continue;
+        const double rec = tab[std::min(4, k / per_layer + 1)];
+        const double link = (double)(k + 1) * host_row_bytes / 50000.0;
+        cost += (double)(life - prev) * std::max(rec, link);
+        prev = life;
+      }
     }
     c.cost = cost;
     return c;
   };
   Cand best;
   static const int force_slots = getenv("PREGO_PLAN_SLOTS") ? atoi(getenv("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
-  if (want_single || n <= per_layer) best = pack(n);
+  if (want_single || (n <= per_layer && host_row_bytes <= 0)) best = pack(n);
   else if (force_slots > 0) best = pack(std::min(n, std::min(force_slots, max_slots)));
   else {
     best = pack(std::min(n, per_layer));
-    for (int S = 2 * per_layer; S <= max_slots; S *= 2) {
+    for (int S = 2 * per_layer; S <= max_slots && n > per_layer; S *= 2) {
       Cand c = pack(std::min(n, S));
       if (c.cost < best.cost) best = std::move(c);
       if (S >= n) break;
     }
+    if (host_row_bytes > 0)                              // link-bound candidates: fewer slots than one tile layer, in steps of 8
+      for (int S = 8; S < std::min(n, per_layer); S += 8) {
+        Cand c = pack(S);
+        if (c.cost < best.cost) best = std::move(c);
+      }
   }
   const int S = best.S;
   std::vector<int> slot_order(S);
@@ -378,6 +405,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   h->n_slots = S;
   h->plan_single = single;
   h->plan_want_single = want_single;
+  h->plan_host_row_bytes = host_row_bytes;
   h->plan_lens.assign(lens, lens + n);
   return PREGO_OK;
 }
@@ -442,6 +470,40 @@ static int stage_tables(prego_miniroad* h, const void* const* tab4, size_t tab_c
   }
   HIPCHK(hipEventRecord(h->pin_ev, s));
   h->pin_busy = true;
+  return PREGO_OK;
+}
+
+// ---- link-fed inference: features arrive over the host link WHILE the forward runs ---------------------------------------------
+// The eval loop's H2D copy of a batch (57 GB/s) and its forward (bound by the longest video's recurrence) are each ~60 ms for the
+// bench's 60 videos; run one after the other they are the 46 % of the PCIe floor the round-3 verdict measured.  The caller copies the
+// features in the order the packed pipeline NEEDS them (piece (clip, frames [a, b)) is needed at step start_step[clip] + a) and
+// records events along the way; the pack of each chunk waits for the events that cover its steps.  plan_starts reports the schedule
+// (costed for a link-bound feed: fewer slots than clips, so that rows are needed at the rate the link delivers them).
+extern "C" int prego_miniroad_plan_starts(prego_miniroad* h, int n_clips, const int32_t* lens, int link_row_bytes, int32_t* start_step,
+                                          int32_t* n_steps) {
+  HandleScope scope_(h);
+  if (!h || !lens || !start_step || n_clips <= 0) return fail(PREGO_EINVAL, "plan_starts: bad arguments");
+  if (n_clips > max_clips_of(h)) return fail(PREGO_EINVAL, "%d clips > max_clips %d per call", n_clips, max_clips_of(h));
+  const int rc = build_plan(h, n_clips, lens, false, link_row_bytes > 0 ? link_row_bytes : 0);
+  if (rc) return rc;
+  for (size_t k = 0; k < h->h_seg_clip.size(); ++k) start_step[h->h_seg_clip[k]] = h->h_seg_start[k];
+  if (n_steps) *n_steps = h->t_max;
+  return PREGO_OK;
+}
+
+extern "C" int prego_miniroad_set_feed_events(prego_miniroad* h, int n_events, const int32_t* upto_step, void* const* events,
+                                              int link_row_bytes) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  h->feed_ev.clear(); h->feed_upto.clear(); h->feed_pos = 0; h->feed_row_bytes = 0;
+  if (n_events == 0) return PREGO_OK;
+  if (n_events < 0 || !upto_step || !events || link_row_bytes <= 0) return fail(PREGO_EINVAL, "set_feed_events: bad arguments");
+  for (int j = 0; j < n_events; ++j) {
+    if (!events[j] || (j > 0 && upto_step[j] < upto_step[j - 1])) { h->feed_ev.clear(); h->feed_upto.clear(); return fail(PREGO_EINVAL, "set_feed_events: event %d", j); }
+    h->feed_ev.push_back((hipEvent_t)events[j]);
+    h->feed_upto.push_back(upto_step[j]);
+  }
+  h->feed_row_bytes = link_row_bytes;
   return PREGO_OK;
 }
 
@@ -521,7 +583,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (in16 && !h->bf16) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 on an fp32-operand handle (16-bit features go with bf16 / fp16 handles)");
   if (in16 && (flags & PREGO_FWD_KEEP)) return fail(PREGO_EINVAL, "PREGO_FWD_IN16 with PREGO_FWD_KEEP: training takes fp32 features");
   const bool want_single = h0 != nullptr || h_last != nullptr || (flags & PREGO_FWD_KEEP) != 0;
-  int rc = build_plan(h, n_clips, lens, want_single);
+  // link-fed call (prego_miniroad_set_feed_events): the feature arrays are being filled over the host link while this call runs
+  const bool hostfeat = !h->feed_ev.empty();
+  if (hostfeat && want_single) { h->feed_ev.clear(); return fail(PREGO_EINVAL, "feed events with h0 / h_last / PREGO_FWD_KEEP: link-fed calls are plain inference"); }
+  const int host_row_bytes = hostfeat ? h->feed_row_bytes : 0;
+  struct FeedClear { prego_miniroad* h; ~FeedClear() { h->feed_ev.clear(); h->feed_upto.clear(); h->feed_pos = 0; } } feed_clear{h};   // one call only
+  int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes);
   if (rc) return rc;
   const SlotPlan plan = device_plan(h);
   const int n_slots = h->n_slots;
@@ -612,6 +679,11 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   };
   auto pack_chunk = [&](int t0_, int t1_, hipStream_t st, int ci_) {
     const int base_ = h->h_rowoff[t0_], rows_ = h->h_rowoff[t1_] - base_;
+    // link-fed call: this chunk reads rows of steps < t1_; make the packing stream wait for every feed event that covers them
+    while (h->feed_pos < h->feed_ev.size() && (h->feed_pos == 0 || h->feed_upto[h->feed_pos - 1] < t1_)) {
+      (void)hipStreamWaitEvent(st, h->feed_ev[h->feed_pos], 0);
+      ++h->feed_pos;
+    }
     EventPair* evp = ev_begin(h, 2, st);
     if (h->x2)
       launch_pack_rows_x2(d_rgb_ptrs, d_flow_ptrs, plan, base_, rows_, h->d_rgb, with_flow ? h->d_flow : 0, X, st,
@@ -751,6 +823,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ++ci;
   }
   if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
+  if (hostfeat && (h->feed_upto.empty() || h->feed_upto.back() < h->t_max))
+    return fail(PREGO_EINVAL, "feed events cover steps < %d, the call has %d", h->feed_upto.empty() ? 0 : h->feed_upto.back(), h->t_max);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

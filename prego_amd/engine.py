@@ -30,6 +30,14 @@ def plan_passes(lens, max_clips: int, single: bool = False, max_slots: int = 512
     return [order[s:s + cap] for s in range(0, n, cap)]
 
 
+def _dev_readable(t: torch.Tensor) -> bool:
+    """feature tensors the pack kernel can read: device memory, or PINNED host memory (hipHostMalloc: mapped into the device's address
+    space at the same address) - the kernel then pulls the rows over PCIe itself, chunk by chunk, under the previous chunk's recurrence
+    (zero-copy feeding of Evaluate: no staging copy, no H2D in front of the forward).  The caller keeps a pinned tensor alive until
+    the stream has run the call."""
+    return t.is_cuda or (t.device.type == "cpu" and t.is_pinned())
+
+
 def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
@@ -91,7 +99,7 @@ class MiniRoadEngine:
     def forward_ragged(self, rgb: Sequence[torch.Tensor], flow: Optional[Sequence[Optional[torch.Tensor]]],
                        softmax: bool = True, want_out: bool = True, want_argmax: bool = False,
                        h0: Optional[torch.Tensor] = None, want_h_last: bool = False):
-        """rgb[i]: fp32 cuda [T_i, d_rgb] contiguous; flow[i] likewise or None (= zeros).
+        """rgb[i]: fp32 cuda (or pinned host, see _dev_readable) [T_i, d_rgb] contiguous; flow[i] likewise or None (= zeros).
         Returns (outs list of [T_i, C] or None, argmax list of int32 [T_i] or None, h_last or None)."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
         if d_rgb == 0:                  # --no_rgb (rnn.py:23-29,54-57): the model's only input is the flow stream
@@ -119,6 +127,24 @@ class MiniRoadEngine:
                 h_last[idx] = sub_hl
         return (outs if want_out else None), (args if want_argmax else None), h_last
 
+    # -- link-fed inference (Evaluate: the H2D copy of a batch under its forward) ------------------------------------------
+    def plan_starts(self, lens: Sequence[int], link_row_bytes: int):
+        """(start_step per clip, number of steps) of the schedule the next forward_ragged of exactly these clips will use when its
+        features arrive over the link at `link_row_bytes` per frame: frame a of clip i is consumed at step start_step[i] + a"""
+        n = len(lens)
+        arr = (C.c_int32 * n)(*[int(l) for l in lens])
+        out = (C.c_int32 * n)()
+        ns = C.c_int32(0)
+        check(self.lib.prego_miniroad_plan_starts(self.h, n, arr, int(link_row_bytes), out, C.byref(ns)))
+        return list(out), int(ns.value)
+
+    def set_feed_events(self, upto_steps: Sequence[int], events: Sequence["torch.cuda.Event"], link_row_bytes: int):
+        """for the NEXT forward_ragged call: rows needed at steps < upto_steps[j] are valid once events[0..j] have fired"""
+        n = len(events)
+        up = (C.c_int32 * n)(*[int(min(u, 2**31 - 1)) for u in upto_steps])
+        ev = (C.c_void_p * n)(*[e.cuda_event for e in events])
+        check(self.lib.prego_miniroad_set_feed_events(self.h, n, up, ev, int(link_row_bytes)))
+
     def _forward_pass(self, rgb, flow, softmax, want_out, want_argmax, h0, h_last, outs, args, base):
         d_rgb, d_flow, emb, hid, ncls = self.dims
         n = len(rgb) if rgb is not None else len(flow)
@@ -132,14 +158,15 @@ class MiniRoadEngine:
             raise PregoError(f"features are {dt}: a {self.compute_dtype} engine takes fp32" + (f" or {op_dt}" if op_dt else "") + " tensors")
         for i, r in enumerate(rgb if rgb is not None else flow):
             want = d_rgb if rgb is not None else d_flow
-            if r.dtype != dt or not r.is_cuda or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != want:
-                raise PregoError(f"{'rgb' if rgb is not None else 'flow'}[{i}] must be a contiguous {dt} cuda tensor [T, {want}], got {tuple(r.shape)} {r.dtype}")
+            if r.dtype != dt or not _dev_readable(r) or not r.is_contiguous() or r.dim() != 2 or r.shape[1] != want:
+                raise PregoError(f"{'rgb' if rgb is not None else 'flow'}[{i}] must be a contiguous {dt} cuda (or pinned host) tensor [T, {want}], "
+                                 f"got {tuple(r.shape)} {r.dtype} on {r.device}")
             lens.append(r.shape[0])
         if flow is not None:
             for i, f in enumerate(flow):
                 if f is None:
                     continue
-                if f.dtype != dt or not f.is_cuda or not f.is_contiguous() or tuple(f.shape) != (lens[i], d_flow):
+                if f.dtype != dt or not _dev_readable(f) or not f.is_contiguous() or tuple(f.shape) != (lens[i], d_flow):
                     raise PregoError(f"flow[{i}] must be a contiguous {dt} cuda tensor [{lens[i]}, {d_flow}]")
         lens_arr = (C.c_int32 * n)(*lens)
         flags = (_lib.FWD_SOFTMAX if softmax else 0) | (_lib.FWD_IN16 if dt != torch.float32 else 0)

@@ -19,7 +19,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .metrics import perframe_average_precision, perframe_average_precision_device
+from .metrics import (perframe_ap_raw, perframe_ap_raw_device, perframe_average_precision, perframe_average_precision_device,
+                      report_from_raw)
 from .registry import EVAL
 
 
@@ -31,6 +32,8 @@ class Evaluate(nn.Module):
         if "THUMOS" in cfg["data_name"]:
             raise NotImplementedError("THUMOS post-processing is outside the PREGO datasets")
         self.metric = cfg["metric"]
+        if self.metric not in ("AP", "cAP"):          # known before the eval pass runs, not after it (utils/metrics.py:38-44)
+            raise RuntimeError(f"Unknown metrics: {self.metric}")
         self.cfg = cfg
         self.all_class_names = json.load(open(cfg["video_list_path"]))[cfg["data_name"].split("_")[0]]["class_index"]
         self.max_frames_per_batch = int(cfg.get("eval_frames_per_batch", 4_000_000))
@@ -38,11 +41,20 @@ class Evaluate(nn.Module):
         self.last_fps = None
         self._copy_stream = None             # side stream for the H2D feature copies (double buffering against the compute stream)
 
-    def _zero_flow(self, model) -> bool:
-        """the flow half is identically zero - never shipped, its half of layer1's K never multiplied (exact): the model was told so
-        (cfg['assume_zero_flow']), or the config names the flow type the reference's loader overwrites with zeros (dataset.py:63-69)"""
-        known_zero = bool(getattr(model, "assume_zero_flow", False)) or self.cfg.get("flow_type") == "flow_anet_resnet50"
+    def _zero_flow(self, model, dataloader=None) -> bool:
+        """the flow half of EVERY video is identically zero - never shipped, its half of layer1's K never multiplied (exact).  Known
+        from what the data IS, not from a config string: the model was told so (cfg['assume_zero_flow']), or the loader's dataset
+        says it zeroes the flow stream (StepRecognitionDataset.zero_flow = the reference's dataset.py:63-69 behaviour).  A loader
+        that supplies real flow under the same flow_type name has its flow used.  Single tensors are also checked, see _flow_zero."""
+        known_zero = bool(getattr(model, "assume_zero_flow", False)) or bool(getattr(getattr(dataloader, "dataset", None), "zero_flow", False))
         return known_zero and bool(getattr(model, "use_rgb", True)) and bool(self.cfg.get("eval_skip_zero_flow", True))
+
+    def _flow_zero(self, model, flow) -> bool:
+        """one video's flow tensor [T, D] is provably all zeros at no cost: a stride-0 expansion of a zero row (what a dataset that
+        zeroes the flow stream hands out before collation)"""
+        if not (bool(getattr(model, "use_rgb", True)) and bool(self.cfg.get("eval_skip_zero_flow", True))):
+            return False
+        return flow.dim() == 2 and flow.shape[0] > 0 and flow.stride(0) == 0 and not bool(flow[0].any())
 
     @staticmethod
     def _features(model, x):
@@ -73,8 +85,10 @@ class Evaluate(nn.Module):
 
     def _enqueue(self, model, sub, device):
         """H2D of one sub-batch on the copy stream + its forward on the compute stream; nothing here waits for the GPU"""
-        zero_flow = self._zero_flow(model)
         dev = torch.device(device)
+        flows = [b[1] for b in sub]
+        if all(f is None for f in flows):
+            flows = None
         if dev.type == "cuda":
             # H2D on a side stream: these copies run while whatever was enqueued before is still computing (the loader's
             # pin_memory=True makes them true async DMA); the compute stream waits on one event per sub-batch
@@ -83,30 +97,86 @@ class Evaluate(nn.Module):
             cur = torch.cuda.current_stream(dev)
             with torch.cuda.stream(self._copy_stream):
                 rgb = [b[0].to(dev, non_blocking=True) for b in sub]
-                flow = None if zero_flow else [b[1].to(dev, non_blocking=True) for b in sub]
+                flow = None if flows is None else [None if f is None else f.to(dev, non_blocking=True) for f in flows]
                 tgt = [b[2].to(dev, non_blocking=True) for b in sub]
                 ready = torch.cuda.Event()
                 ready.record(self._copy_stream)
             cur.wait_event(ready)
-            for t in rgb + (flow or []) + tgt:
+            for t in rgb + [f for f in (flow or []) if f is not None] + tgt:
                 t.record_stream(cur)         # allocated on the copy stream, consumed on the compute stream
         else:
             rgb = [b[0].to(device) for b in sub]
-            flow = None if zero_flow else [b[1].to(device) for b in sub]
+            flow = None if flows is None else [None if f is None else f.to(device) for f in flows]
             tgt = [b[2].to(device) for b in sub]
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        return probs, args, tgt
+
+    PIECE_FRAMES = 2048          # link-fed eval: frames per H2D piece (8 MB of fp16 rgb); one feed event per ~EVENT_BYTES copied
+    EVENT_BYTES = 64 << 20
+
+    def _enqueue_link_fed(self, model, batch, device):
+        """ONE forward over the whole batch while its features are still arriving (MROAD.link_fed_eval; pinned host features).
+        The engine says at which step every video starts in its recurrence slot (plan_starts: a schedule costed for a link-bound
+        feed - about frames / longest-video slots, every slot alive to the end, so rows are needed at the rate the link delivers
+        them); the features are cut into pieces of PIECE_FRAMES frames, copied in the order the packed pipeline needs them
+        (piece (video, a) at step start[video] + a), and a feed event is recorded every EVENT_BYTES; the library's packing stream waits
+        for the events a chunk needs (set_feed_events).  The recurrence's critical path - the longest video - is paid once, with the
+        copy under it, instead of copy + forward one after the other (round 3: 46 % of the PCIe floor)."""
+        dev = torch.device(device)
+        eng = model.engine()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        lens = [int(b[0].shape[0]) for b in batch]
+        any_flow = any(b[1] is not None for b in batch)
+        row_bytes = sum(int(t.shape[1]) * t.element_size() for t in (batch[0][0],) + ((next(b[1] for b in batch if b[1] is not None),) if any_flow else ()))
+        start, n_steps = eng.plan_starts(lens, row_bytes)
+        rgb = [torch.empty(b[0].shape, dtype=b[0].dtype, device=dev) for b in batch]
+        flow = [None if b[1] is None else torch.empty(b[1].shape, dtype=b[1].dtype, device=dev) for b in batch] if any_flow else None
+        P = self.PIECE_FRAMES
+        pieces = sorted((start[i] + a, i, a) for i, T in enumerate(lens) for a in range(0, T, P))
+        upto, events, acc = [], [], 0
+        self._copy_stream.wait_stream(cur)                 # the destination tensors exist in stream order of `cur`
+        with torch.cuda.stream(self._copy_stream):
+            for k, (need, i, a) in enumerate(pieces):
+                b = min(a + P, lens[i])
+                rgb[i][a:b].copy_(batch[i][0][a:b], non_blocking=True)
+                acc += (b - a) * int(rgb[i].shape[1]) * rgb[i].element_size()
+                if flow is not None and flow[i] is not None:
+                    flow[i][a:b].copy_(batch[i][1][a:b], non_blocking=True)
+                    acc += (b - a) * int(flow[i].shape[1]) * flow[i].element_size()
+                last = k + 1 == len(pieces)
+                if acc >= self.EVENT_BYTES or last:
+                    ev = torch.cuda.Event()
+                    ev.record(self._copy_stream)
+                    events.append(ev)
+                    upto.append(2 ** 31 - 1 if last else pieces[k + 1][0])      # every piece needed before that step has been copied
+                    acc = 0
+            tgt = [b[2].to(dev, non_blocking=True) for b in batch]                   # only needed behind the forward
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        for t in rgb + [f for f in (flow or []) if f is not None] + tgt:
+            t.record_stream(self._copy_stream)
+        self._feed_events = events                           # keep the hipEvent_t objects alive until the stream has used them
+        eng.set_feed_events(upto, events, row_bytes)
+        probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        cur.wait_event(ready)
         return probs, args, tgt
 
     def _flush(self, model, batch, pred_scores, gt_targets, output, device):
         if not batch:
             return
-        # A batch runs as long as its longest video's recurrence; its H2D copy would sit in front of that.  Large batches go in two
+        # Pinned host features + a model that can be fed while it runs: ONE link-fed forward (_enqueue_link_fed).  Otherwise a batch
+        # runs as long as its longest video's recurrence and its H2D copy would sit in front of that, so large batches go in two
         # sub-batches ordered by length: the few longest videos first (little to copy, the long critical path), then the bulk of
         # the bytes, whose copy runs under the first sub-batch's recurrence.  Results return to the loader's order below.
         order = list(range(len(batch)))
         parts = [order]
         frames = [int(b[0].shape[0]) for b in batch]
-        if len(batch) >= 16 and torch.device(device).type == "cuda" and self.cfg.get("eval_split_by_length", True):
+        on_gpu = torch.device(device).type == "cuda"
+        link_fed = on_gpu and bool(getattr(model, "link_fed_eval", False)) and bool(self.cfg.get("eval_link_fed", True)) and len(batch) >= 2 and \
+            all(b[0].device.type == "cpu" and b[0].is_pinned() and (b[1] is None or (b[1].device.type == "cpu" and b[1].is_pinned())) for b in batch)
+        if len(batch) >= 16 and on_gpu and not link_fed and self.cfg.get("eval_split_by_length", True):
             order.sort(key=lambda i: -frames[i])
             # share of the frames in the first part: its forward should last about as long as the second part's copy.  Measured on
             # the 60-video bench set (scripts/eval_e2e_bench.py): fp32 features 0.2: 4.23, 0.5: 4.72, 0.6: 4.41 M frames/s;
@@ -121,13 +191,26 @@ class Evaluate(nn.Module):
             if k >= 1:
                 parts = [order[:k], order[k:]]
         res = {}
-        for part in parts:
-            probs, args, tgt = self._enqueue(model, [batch[i] for i in part], device)
-            for i, p, a, t in zip(part, probs, args, tgt):
+        if link_fed:
+            probs, args, tgt = self._enqueue_link_fed(model, batch, device)
+            for i, (p, a, t) in enumerate(zip(probs, args, tgt)):
                 res[i] = (p, a, t)
+        else:
+            for part in parts:
+                probs, args, tgt = self._enqueue(model, [batch[i] for i in part], device)
+                for i, p, a, t in zip(part, probs, args, tgt):
+                    res[i] = (p, a, t)
         want_json = self.cfg["eval"] is not None
-        # ONE device -> host copy of the whole batch's argmax, after everything has been enqueued (the first wait for the GPU)
-        arg_host = torch.cat([res[i][1] for i in range(len(batch))]).cpu().numpy() if want_json else None
+        # np.argmax of the one-hot targets (eval.py:55) on the device, where they are anyway for the AP kernel (on the host it reads
+        # frames x classes floats through one core: 25 ms for the bench set); then ONE device -> host copy of the whole batch's
+        # pred and gt ids, after everything has been enqueued (the first wait for the GPU)
+        ids_host = None
+        if want_json:
+            pred_ids = torch.cat([res[i][1] for i in range(len(batch))])
+            gt_ids = torch.cat([torch.argmax(res[i][2], dim=1) for i in range(len(batch))]).to(pred_ids.dtype)
+            ids_host = torch.stack([pred_ids, gt_ids]).cpu().numpy()
+        elif link_fed:
+            self._copy_stream.synchronize()      # the copies read the loader's pinned tensors: keep them alive until then
         o = 0
         for i, (r, f, target, vid) in enumerate(batch):
             p, a, t = res[i]
@@ -137,7 +220,7 @@ class Evaluate(nn.Module):
             gt_targets.append(t)
             if want_json:
                 n = int(a.shape[0])
-                output[vid] = {"pred": arg_host[o:o + n], "gt": torch.argmax(target, dim=1).numpy()}      # int arrays; text only at the end
+                output[vid] = {"pred": ids_host[0, o:o + n], "gt": ids_host[1, o:o + n]}      # int arrays; text only at the end
                 o += n
                 self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
         batch.clear()
@@ -151,7 +234,7 @@ class Evaluate(nn.Module):
         # the loader's order (no data-path collective); rank 0 gathers the per-video results once at the end
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank() if world > 1 else 0
-        skip_flow = self._zero_flow(model)
+        skip_flow = self._zero_flow(model, dataloader)
         with torch.no_grad():
             pred_scores, gt_targets = [], []
             per_video = []                       # (loader position, n_frames) to restore the loader's order on rank 0
@@ -165,8 +248,8 @@ class Evaluate(nn.Module):
                     if not mine:
                         continue
                     name = vid[b] if isinstance(vid, (list, tuple)) else vid
-                    batch.append((self._features(model, rgb_input[b]), None if skip_flow else self._features(model, flow_input[b]),
-                                  target[b], name))
+                    fl = None if (skip_flow or self._flow_zero(model, flow_input[b])) else self._features(model, flow_input[b])
+                    batch.append((self._features(model, rgb_input[b]), fl, target[b], name))
                     per_video.append((pos - 1, int(rgb_input.shape[1])))
                     frames += rgb_input.shape[1]
                 if len(batch) >= max_clips or frames >= self.max_frames_per_batch:
@@ -175,39 +258,94 @@ class Evaluate(nn.Module):
             self._flush(model, batch, pred_scores, gt_targets, output, device)
             model.check()
             if world > 1:
+                # the small things go to rank 0 as objects: per-video frame counts and the pred / gt id arrays of the output file
+                # (8 bytes per frame).  The [frames x classes] score and target matrices do NOT travel whole (round 3 pickled 0.8 GB of
+                # them through gather_object): the metric is computed class-sharded, see _sharded_ap
                 gathered = [None] * world if rank == 0 else None
-                dist.gather_object((per_video, [p.cpu().numpy() for p in pred_scores], [g.cpu().numpy() for g in gt_targets], output),
-                                   gathered, dst=0)
-                if rank != 0:
-                    return float("nan")          # only rank 0 reports (main.py logs / checkpoints on rank 0)
-                chunks = []
-                output = {}
-                for pv, ps, gs, out in gathered:
-                    for (p_idx, n), pm, gm in zip(pv, ps, gs):       # one [n, C] matrix per video
-                        chunks.append((p_idx, torch.from_numpy(pm), torch.from_numpy(gm)))
-                    output.update(out)
-                chunks.sort(key=lambda c: c[0])
-                pred_scores = [c[1] for c in chunks]
-                gt_targets = [c[2] for c in chunks]
+                dist.gather_object((per_video, output), gathered, dst=0)
+                if rank == 0:                       # back into the loader's order (a rank's dict is in the order of its per_video list)
+                    entries = []
+                    for pv, out in gathered:
+                        entries += [(p_idx, vid, ent) for (p_idx, _n), (vid, ent) in zip(pv, out.items())]
+                    output = {vid: ent for _p, vid, ent in sorted(entries, key=lambda e: e[0])}
+                pred_local = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)), device=device)
+                gt_local = torch.cat(gt_targets, 0).to(pred_local.device) if gt_targets else torch.zeros_like(pred_local)
+                result = self._sharded_ap(pred_local, gt_local, world, rank)
+                if rank == 0 and self.cfg["eval"] is not None:
+                    os.makedirs(self.output_dir, exist_ok=True)
+                    with open(os.path.join(self.output_dir, "output_miniROAD.json"), "wb") as file:
+                        file.write(self._json_int_lists(output))
+                t_end = time.time()
+                nf = torch.tensor([int(pred_local.shape[0])], dtype=torch.int64, device=pred_local.device)
+                dist.all_reduce(nf)
+                num_frames = int(nf.item())
+                self.last_fps = num_frames / max(t_end - t_begin, 1e-9)
+                if rank == 0:
+                    logger.info(f"Processed {num_frames} frames in {t_end - t_begin:.1f} seconds ({self.last_fps:.1f} FPS)")
+                return result["mean_AP"]
+            pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
+            gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
+            num_frames = int(gt_all.shape[0])
+            finish_ap = None
+            if torch.device(device).type == "cuda" and self.metric == "AP":
+                # sort + scan per class in libprego_amd.so (prego_perframe_ap), ENQUEUED here and collected behind the output file:
+                # the host formats the JSON while the GPU sorts.  After a multi-rank gather the matrices are host tensors on rank 0
+                # and go back to its GPU first
+                finish_ap = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
+                                                              self.data_processing, self.metric, defer=True)
             if self.cfg["eval"] is not None:
                 os.makedirs(self.output_dir, exist_ok=True)
                 with open(os.path.join(self.output_dir, "output_miniROAD.json"), "wb") as file:
                     file.write(self._json_int_lists(output))
+            if finish_ap is not None:
+                result = finish_ap()
+            else:       # a stand-in model on a CPU box (the gloo tests of the sharding logic), or metric 'cAP' (TVSeries' calibrated variant: host path only)
+                result = perframe_average_precision(pred_all.cpu().numpy(), gt_all.cpu().numpy(), self.all_class_names, self.data_processing, self.metric)
             t_end = time.time()
-            pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
-            gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
-            num_frames = int(gt_all.shape[0])
-            if torch.device(device).type == "cuda":
-                # sort + scan per class in libprego_amd.so (prego_perframe_ap); after a multi-rank gather the matrices are host
-                # tensors on rank 0 and go back to its GPU first
-                result = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
-                                                           self.data_processing, self.metric)
-            else:       # only reachable with a stand-in model on a CPU box (the gloo tests of the sharding logic)
-                result = perframe_average_precision(pred_all.numpy(), gt_all.numpy(), self.all_class_names, self.data_processing, self.metric)
             time_taken = max(t_end - t_begin, 1e-9)
             self.last_fps = num_frames / time_taken
             logger.info(f"Processed {num_frames} frames in {time_taken:.1f} seconds ({self.last_fps:.1f} FPS)")
         return result["mean_AP"]
+
+    def _sharded_ap(self, pred, gt, world, rank):
+        """per-frame AP over the frames of ALL ranks without gathering the [frames x classes] matrices anywhere: rank q owns the classes
+        [C q / world, C (q + 1) / world) of every frame - one all_to_all_single per matrix brings it those columns from every rank
+        (each rank sends (world - 1) / world of its matrix once, RCCL over xGMI on a GPU node) -, runs the AP kernel on them, and only
+        the three per-class vectors (AP, positives, score mass) are all-gathered: 24 bytes per class.  AP per class does not depend
+        on the order of the frames (exact integer ranks, ties share a threshold), so the result equals the single-process one."""
+        C_ = len(self.all_class_names)
+        cb = [C_ * q // world for q in range(world + 1)]
+        n_local = torch.tensor([int(pred.shape[0])], dtype=torch.int64, device=pred.device)
+        ns = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(ns, n_local)
+        ns = [int(x.item()) for x in ns]
+        mine = cb[rank + 1] - cb[rank]
+
+        def exchange(m):
+            m = m.to(torch.float32)
+            send = torch.cat([m[:, cb[q]:cb[q + 1]].contiguous().reshape(-1) for q in range(world)]) if m.numel() else m.reshape(-1)
+            recv = torch.empty(sum(ns) * mine, dtype=torch.float32, device=m.device)
+            dist.all_to_all_single(recv, send, output_split_sizes=[n * mine for n in ns],
+                                   input_split_sizes=[int(m.shape[0]) * (cb[q + 1] - cb[q]) for q in range(world)])
+            return recv.reshape(sum(ns), mine) if mine else recv.reshape(sum(ns), 0)
+        p_cols, g_cols = exchange(pred), exchange(gt)
+        if mine == 0:
+            raw = (np.zeros(0), np.zeros(0, np.int64), np.zeros(0))
+        elif p_cols.is_cuda and self.metric == "AP":
+            raw = perframe_ap_raw_device(p_cols, g_cols)
+        else:
+            raw = perframe_ap_raw(p_cols.cpu().numpy(), g_cols.cpu().numpy(), self.metric)
+        width = max(cb[q + 1] - cb[q] for q in range(world))
+        pack = torch.zeros((3, width), dtype=torch.float64, device=pred.device)
+        pack[0, :mine] = torch.from_numpy(np.asarray(raw[0], dtype=np.float64))
+        pack[1, :mine] = torch.from_numpy(np.asarray(raw[1], dtype=np.float64))          # counts < 2^53: exact in fp64
+        pack[2, :mine] = torch.from_numpy(np.asarray(raw[2], dtype=np.float64))
+        parts = [torch.zeros_like(pack) for _ in range(world)]
+        dist.all_gather(parts, pack)
+        ap = np.concatenate([parts[q][0, :cb[q + 1] - cb[q]].cpu().numpy() for q in range(world)])
+        npos = np.concatenate([parts[q][1, :cb[q + 1] - cb[q]].cpu().numpy() for q in range(world)]).astype(np.int64)
+        ssum = np.concatenate([parts[q][2, :cb[q + 1] - cb[q]].cpu().numpy() for q in range(world)])
+        return report_from_raw(ap, npos, ssum, self.all_class_names)
 
     def aggregate_last(self, output_path=None, window_size: int = 200):
         """utils/aggregate.py:46-90 on the per-frame argmax the last eval left in HBM (`last_device_argmax`), with this config's

@@ -11,7 +11,8 @@ reference always treats as background (metrics.py:44-48).  Two routes to the sam
                                            segment per class), used by `Evaluate` so that the [frames x classes] score matrix of
                                            an eval pass never leaves the device.  No CPU fallback.
 
-Only `metric: 'AP'` exists here: the reference's calibrated variant (cAP) is unreachable from the shipped configs."""
+`metric: 'cAP'` (the reference's calibrated variant for TVSeries, metrics.py:10-22; unreachable from the shipped configs) runs on the
+host path only; `Evaluate` moves the matrices to the host for it."""
 from __future__ import annotations
 
 from collections import OrderedDict
@@ -41,6 +42,25 @@ def average_precision_columns(scores: np.ndarray, positive: np.ndarray) -> np.nd
     return np.where(total > 0, ap, np.nan)
 
 
+def calibrated_average_precision_columns(scores: np.ndarray, positive: np.ndarray) -> np.ndarray:
+    """cAP of every column (metrics.py:10-22 of the reference, all classes at once): precision re-weighted by the negative /
+    positive ratio w, cprec_k = TP_k / (TP_k + FP_k / (w + eps) + eps), averaged over the ranks that hold a positive.  Rows of equal
+    score keep their input order (stable sort; the reference's unstable argsort leaves ties to chance)."""
+    scores = np.asarray(scores)
+    positive = np.asarray(positive, dtype=bool)
+    eps = np.finfo(float).eps
+    order = np.argsort(-scores, axis=0, kind="stable")
+    tp = np.take_along_axis(positive, order, axis=0).astype(np.float64)
+    tps = np.cumsum(tp, axis=0)
+    fps = np.cumsum(1.0 - tp, axis=0)
+    total = tp.sum(axis=0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ratio = (tp.shape[0] - total) / total
+        cprec = tps / (tps + fps / (ratio + eps) + eps)
+        cap = (cprec * tp).sum(axis=0) / total
+    return np.where(total > 0, cap, np.nan)
+
+
 def _report(ap, n_true, score_sum, class_names):
     """the reference's result dict: per-class AP (classes 1.. that have a positive), its log strings, and their mean"""
     res = OrderedDict(per_class_AP=OrderedDict(), num=OrderedDict())
@@ -49,24 +69,54 @@ def _report(ap, n_true, score_sum, class_names):
             name = class_names[c]
             res["per_class_AP"][name] = float(ap[c])
             res["num"][name] = f"[true: {int(n_true[c])}, pred:{int(score_sum[c])}, AP:{ap[c] * 100:.1f}]"
-    res["mean_AP"] = np.mean(list(res["per_class_AP"].values()))
+    with np.errstate(invalid="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            res["mean_AP"] = np.mean(list(res["per_class_AP"].values())) if res["per_class_AP"] else float("nan")
     return res
+
+
+def perframe_ap_raw(pred: np.ndarray, truth: np.ndarray, metrics="AP"):
+    """(AP or cAP per column, positives per column, score mass per column) of host matrices [frames, classes]: the three vectors the
+    report is built from (class-sharded multi-rank eval computes them for its own columns and gathers only these)"""
+    cols = average_precision_columns if metrics == "AP" else calibrated_average_precision_columns
+    if pred.shape[0] == 0:
+        z = np.zeros(pred.shape[1])
+        return z, z.astype(np.int64), z.copy()
+    return cols(pred, truth != 0), (truth != 0).sum(0), pred.sum(0, dtype=np.float64)
+
+
+def report_from_raw(ap, n_true, score_sum, class_names):
+    return _report(np.asarray(ap), np.asarray(n_true), np.asarray(score_sum), class_names)
 
 
 def perframe_average_precision(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
     """Host path: prediction / ground_truth [frames, classes] (lists of rows or arrays, as trainer/eval.py collects them)."""
-    if metrics != "AP":
-        raise RuntimeError(f"Unknown metrics: {metrics} (prego_amd implements 'AP', the metric of the shipped configs)")
+    if metrics not in ("AP", "cAP"):
+        raise RuntimeError(f"Unknown metrics: {metrics}")
     truth = np.asarray(ground_truth)
     pred = np.asarray(prediction)
     if postprocessing is not None:
         truth, pred = postprocessing(truth, pred)
-    return _report(average_precision_columns(pred, truth != 0), (truth != 0).sum(0), pred.sum(0, dtype=np.float64), class_names)
+    if truth.ndim != 2 or truth.shape[0] == 0:          # an empty eval set: the reference's np.mean([]) = nan, no per-class entries
+        return _report(np.zeros(len(class_names)), np.zeros(len(class_names), np.int64), np.zeros(len(class_names)), class_names)
+    cols = average_precision_columns if metrics == "AP" else calibrated_average_precision_columns
+    return _report(cols(pred, truth != 0), (truth != 0).sum(0), pred.sum(0, dtype=np.float64), class_names)
 
 
-def perframe_average_precision_device(prediction, ground_truth, class_names, postprocessing=None, metrics="AP"):
+def perframe_ap_raw_device(pred, truth):
+    """device counterpart of perframe_ap_raw (metric 'AP'): fp32 CUDA matrices [frames, classes] -> three host vectors"""
+    ncls = int(pred.shape[1])
+    fin = perframe_average_precision_device(pred, truth, [str(i) for i in range(ncls)], None, "AP", defer=True, raw=True)
+    return fin()
+
+
+def perframe_average_precision_device(prediction, ground_truth, class_names, postprocessing=None, metrics="AP", defer=False, raw=False):
     """Device path: prediction / ground_truth fp32 CUDA tensors [frames, classes]; the sort and the scan run in
-    libprego_amd.so (`prego_perframe_ap`), one small device -> host transfer brings back AP, positives and score mass."""
+    libprego_amd.so (`prego_perframe_ap`), one small device -> host transfer brings back AP, positives and score mass.
+    defer=True: the kernels are only ENQUEUED and a function is returned that waits for them and builds the report (Evaluate writes
+    its output file while the GPU sorts)."""
     import ctypes as C
 
     import torch
@@ -83,6 +133,10 @@ def perframe_average_precision_device(prediction, ground_truth, class_names, pos
     if pred.dim() != 2 or pred.shape != truth.shape or pred.shape[1] != len(class_names):
         raise PregoError(f"perframe_average_precision_device: shapes {tuple(pred.shape)} / {tuple(truth.shape)} for {len(class_names)} classes")
     n, ncls = pred.shape
+    if n == 0:                                          # an empty eval set: same empty report as the host path
+        z = (np.zeros(ncls), np.zeros(ncls, np.int64), np.zeros(ncls))
+        rep = z if raw else _report(*z, class_names)
+        return (lambda: rep) if defer else rep
     lib = _lib.load()
     dev = pred.device
     ws = torch.empty(lib.prego_perframe_ap_workspace_bytes(n, ncls), dtype=torch.uint8, device=dev)
@@ -91,5 +145,9 @@ def perframe_average_precision_device(prediction, ground_truth, class_names, pos
         check(lib.prego_perframe_ap(C.c_void_p(pred.data_ptr()), C.c_void_p(truth.data_ptr()), n, ncls, C.c_void_p(out[0].data_ptr()),
                                     C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
                                     C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    host = out.cpu().numpy()
-    return _report(host[0], host[1].view(np.int64), host[2], class_names)
+    def finish(_keep=(pred, truth, ws)):
+        host = out.cpu().numpy()
+        if raw:
+            return host[0].copy(), host[1].view(np.int64).copy(), host[2].copy()
+        return _report(host[0], host[1].view(np.int64), host[2], class_names)
+    return finish if defer else finish()

@@ -107,6 +107,8 @@ class MROAD(nn.Module):
         eng = self.engine()
         return eng.forward_ragged(rgb_list, flow_list, softmax=True, want_out=want_probs, want_argmax=want_argmax)
 
+    link_fed_eval = True           # Evaluate may feed forward_clips while it runs (engine().plan_starts / set_feed_events)
+
     @property
     def max_clips(self) -> int:
         """videos `Evaluate` may hand to one forward_clips call"""

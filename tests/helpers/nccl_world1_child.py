@@ -106,6 +106,23 @@ def main():
     for k in params[True][1]:
         assert torch.equal(params[True][1][k], params[False][1][k]), k
     out["trainer_two_steps_identical"] = True
+    # (4) the class-sharded AP of a multi-rank eval (Evaluate._sharded_ap: all_gather + all_to_all_single + device AP kernel) over RCCL,
+    # against the single-process device AP on the same matrices
+    import tempfile
+    from prego_amd.evaluate import Evaluate
+    from prego_amd.metrics import perframe_average_precision_device
+    tmp = tempfile.mkdtemp()
+    vl = os.path.join(tmp, "vl.json")
+    json.dump({"ASSEMBLY101-O": {"class_index": [f"c{i}" for i in range(86)]}}, open(vl, "w"))
+    ev = Evaluate(assembly101_cfg(eval=None, video_list_path=vl))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 50_000
+    pred = torch.rand((n, 86), device="cuda", generator=g)
+    gt = torch.nn.functional.one_hot(torch.randint(0, 86, (n,), device="cuda", generator=g), 86).float()
+    sharded = ev._sharded_ap(pred, gt, 1, 0)
+    single = perframe_average_precision_device(pred, gt, ev.all_class_names)
+    assert sharded["mean_AP"] == single["mean_AP"] and sharded["per_class_AP"] == single["per_class_AP"]
+    out["sharded_ap_equals_single_process"] = True
     out["backend"] = dist.get_backend()
     out["nccl_version"] = list(torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None
     dist.barrier()

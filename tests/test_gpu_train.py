@@ -367,4 +367,4 @@ def test_rccl_allreduce_of_the_real_gradient_bucket_in_a_one_rank_group():
     print(line)
     assert rep["ok"] and rep["backend"] == "nccl" and rep["bucket_bytes"] >= 71_704_920
     assert rep["allreduce_fp32"]["wire_dtype"] == "torch.float32" and rep["allreduce_bf16"]["wire_dtype"] == "torch.bfloat16"
-    assert rep["trainer_two_steps_identical"]
+    assert rep["trainer_two_steps_identical"] and rep["sharded_ap_equals_single_process"]

@@ -178,7 +178,31 @@ def test_host_average_precision_matches_sklearn_with_ties():
     res = perframe_average_precision(pr, gt, names)
     assert "c0" not in res["per_class_AP"] and "c6" not in res["per_class_AP"] and len(res["per_class_AP"]) == Cn - 2
     with pytest.raises(RuntimeError):
-        perframe_average_precision(pr, gt, names, metrics="cAP")
+        perframe_average_precision(pr, gt, names, metrics="mAP@k")
+
+
+def test_calibrated_ap_matches_the_reference_formula_and_empty_sets_report_nan():
+    """metric 'cAP' (utils/metrics.py:10-22: TVSeries' calibrated AP) restated for all classes at once, against the formula
+    evaluated class by class on tie-free scores; an empty eval set gives an empty report with a NaN mean (np.mean([]) in the
+    reference), not an exception."""
+    from prego_amd.metrics import perframe_average_precision
+    rng = np.random.default_rng(4)
+    T, Cn = 3000, 7
+    pr = rng.random((T, Cn))
+    gt = np.zeros((T, Cn))
+    gt[np.arange(T), rng.integers(0, Cn, T)] = 1
+    names = [f"c{i}" for i in range(Cn)]
+    res = perframe_average_precision(pr, gt, names, metrics="cAP")
+    eps = np.finfo(float).eps
+    for c in range(1, Cn):
+        y = gt[np.argsort(-pr[:, c]), c]
+        tps, fps = np.cumsum(y), np.cumsum(1 - y)
+        ratio = np.sum(y == 0) / np.sum(y)
+        want = np.sum((tps / (tps + fps / (ratio + eps) + eps))[y == 1]) / np.sum(y)
+        assert abs(res["per_class_AP"][f"c{c}"] - want) < 1e-12
+    for m in ("AP", "cAP"):
+        empty = perframe_average_precision(np.zeros((0, Cn)), np.zeros((0, Cn)), names, metrics=m)
+        assert empty["per_class_AP"] == {} and np.isnan(empty["mean_AP"])
 
 
 def test_bench_gpus_n_spawns_n_ranks_dry_run():
