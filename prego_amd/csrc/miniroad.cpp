@@ -122,6 +122,11 @@ struct prego_miniroad {
   // layer1 GEMM of chunk c + 1 on the XCDs the (compacted) recurrence of chunk c does not hold (off: PREGO_NO_XCD_OVERLAP=1):
   // one tile counter per chunk, zeroed once per forward
   unsigned* tile_ctr = nullptr; bool xcd_overlap = false;
+  // host mirror of the kernel's verified-placement word (rendezvous word 20: 1 = an earlier full-width launch found exactly 32 workgroups
+  // on every XCD).  The device decides whether a launch is really compacted; the host only launches the layer1 worker beside a
+  // recurrence it KNOWS will be compacted (advisor, round 3: with word 20 != 1 the recurrence ran full width while the persistent
+  // worker competed for the same CUs).  -1 = not read yet: copied out behind the first full-width launch, read when that copy is done
+  int placement = -1; unsigned* pin_place = nullptr; hipEvent_t ev_place = nullptr; bool place_pending = false;
   int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
   // timing
@@ -209,6 +214,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));
   A((void**)&h->tile_ctr, 4096 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin_place, 64, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_place, hipEventDisableTiming);
   h->xcd_overlap = getenv("PREGO_NO_XCD_OVERLAP") == nullptr;       // A/B knob: PREGO_NO_XCD_OVERLAP=1 = the serial pass of round 2
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
@@ -233,6 +240,8 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_place) (void)hipEventDestroy(h->ev_place);
+  if (h->pin_place) (void)hipHostFree(h->pin_place);
   delete h;
 }
 
@@ -697,7 +706,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
   bool l1_done = false;           // Y already holds layer1 of this chunk (XCD overlap: the worker GEMM ran under the previous recurrence)
-  const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8;
+  if (h->placement < 0 && h->place_pending && hipEventQuery(h->ev_place) == hipSuccess) {
+    const int v = (int)*h->pin_place;             // 1: group := XCD verified; 2: another placement; 0: that launch did not run the
+    h->placement = v == 0 ? -1 : v;               // full-width rendezvous (multi-tile kernel): look again behind a later launch
+    h->place_pending = false;
+  }
+  const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8 && h->placement == 1 && !h->no_local;
   if (overlap_ok) HIPCHK(hipMemsetAsync(h->tile_ctr, 0, 4096 * sizeof(unsigned), s));
   // every exit path after a fork joins the side stream: an error return while the next chunk's pack is still writing X / RM
   // would leave the caller's stream unordered against it (the next forward on this handle could race with that pack)
@@ -794,6 +808,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     const int nct_l = std::max(1, std::min(nct, (((live_slots + h->G - 1) / h->G) + 15) / 16));
     if (h->x2 ? launch_gru_recurrence_x2(H, nct_l, ga, h->x2_scale + 5, s) : launch_gru_recurrence(h->bf16, H, nct_l, ga, s))
       return fail(PREGO_EINVAL, "recurrence: unsupported hid=%d nct=%d", H, nct_l);
+    if (h->placement < 0 && !h->place_pending && h->xcd_overlap && h->bf16 && h->G == 8 && !h->no_local && ga.Gd == 0) {
+      // the first full-width launch writes the verified-placement word: mirror it to the host behind that launch
+      HIPCHK(hipMemcpyAsync(h->pin_place, h->flags + 20, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipEventRecord(h->ev_place, s));
+      h->place_pending = true;
+    }
     ev_end(ev, s);
     if (prefetch_next) {
       // X is dead once the layer1 GEMM of this chunk has run: stream the next chunk's features into it while the recurrence

@@ -366,6 +366,12 @@ class AttentionLayer:
 
     def __call__(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.params)):
+            # the autograd path runs on bf16 operands (the training kernels take bf16 handles; an fp16 layer trains on bf16 like MROAD
+            # and ViTEnc do).  A layer that was ASKED for the fp32 parity mode must not silently answer with bf16-operand numbers
+            # because grad mode happens to be on: say so.  (Evaluate under torch.no_grad(), or detach the inputs.)
+            if self.compute_dtype == "fp32":
+                raise PregoError("AttentionLayer(compute_dtype='fp32') called with grad enabled on tensors that require grad: the autograd "
+                                 "path is bf16-operand only; wrap the call in torch.no_grad() for the fp32 parity mode")
             return _AttnLayerTrainFn.apply(self, x, *self.params)
         B, L, D = x.shape
         x = x.detach().float().contiguous()

@@ -142,6 +142,28 @@ def test_config1_overlap_worker_is_bit_identical_to_the_serial_pass():
         assert torch.equal(aa[i], bb[i])
 
 
+def test_overlap_stays_off_without_a_verified_placement():
+    """a handle whose recurrence never verifies the one-group-per-XCD placement (PREGO_GRU_NO_LOCAL=1: no rendezvous at all) must not
+    launch the layer1 worker beside a recurrence that then runs full width (round-3 advisor): the host mirrors the kernel's
+    verified-placement word and keeps the serial pass.  Three passes of a thinned-out workload: no timeout, results identical to
+    the default handle's."""
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    lens = [9000, 6000] + [700] * 100                # 102 clips: the tail of the pass has two live slots (compaction + worker territory)
+    rgb = [_feat((T, 2048), 300 + i) for i, T in enumerate(lens)]
+    m_def = _model(cfg, sd, "fp16")
+    e_def = m_def.engine()
+    m_nl = _model(cfg, sd, "fp16")
+    e_nl = _with_env("PREGO_GRU_NO_LOCAL", "1", m_nl.engine)
+    for _ in range(3):
+        a, _, _ = e_def.forward_ragged(rgb, None)
+        b, _, _ = e_nl.forward_ragged(rgb, None)
+    e_def.check()
+    e_nl.check()
+    for i in range(len(lens)):
+        assert torch.equal(a[i], b[i]), i
+
+
 def test_config4_multitile_kernel_is_bit_identical_to_the_classic_kernel():
     """512 clips x 512 frames = four clip tiles per group: the software-pipelined multi-tile recurrence (default) against the
     classic one-tile-at-a-time kernel (handle created under PREGO_GRU_NO_MT=1), bit for bit, in the shipped default dtype."""

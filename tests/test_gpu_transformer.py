@@ -295,6 +295,26 @@ def test_last_block_token0_path_equals_all_rows(layers):
     assert np.abs(full - g["logits"]).max() < 1e-2
 
 
+def test_attention_layer_fp32_mode_refuses_the_bf16_autograd_path():
+    """compute_dtype='fp32' is the parity mode: with nn.Parameter weights outside torch.no_grad() the layer would take the bf16-operand
+    training path - it raises instead of returning different numbers depending on grad mode (round-3 advisor); under no_grad it
+    matches the fixture at the fp32 tolerance."""
+    from prego_amd._lib import PregoError
+    from prego_amd.transformer import AttentionLayer
+    L = 128
+    g = np.load(os.path.join(G, f"g6_causal_attention_L{L}.npz"))
+    sd = W.attention_layer_state_dict(2048, 20)
+    names = ("query_projection", "key_projection", "value_projection", "out_projection")
+    params = [torch.nn.Parameter(torch.from_numpy(sd[n + s]).cuda()) for n in names for s in (".weight", ".bias")]
+    layer = AttentionLayer(*params, n_heads=8, mask_flag=True, compute_dtype="fp32")
+    x = torch.from_numpy(W.normal((1, L, 2048), 20, f"g6.x.{L}")).cuda()
+    with pytest.raises(PregoError):
+        layer(x)
+    with torch.no_grad():
+        out = layer(x)[0].cpu().numpy()
+    assert np.abs(out[g["rows"]] - g["out"]).max() < 2e-5 * max(1.0, np.abs(g["out"]).max())
+
+
 def test_attention_layer_stateless_op_equals_handle():
     """the stateless C-ABI op (weights converted per call) and the handle (converted once) run the same arithmetic"""
     import ctypes as C
