@@ -1,0 +1,203 @@
+// Training-step GEMMs whose operands are stored with the CONTRACTION index as the row index (trainer/train.py:23, loss.backward()):
+//   wgrad  dW[Nout, Kin] = dY^T . X     dY [rows, Nout], X [rows, Kin]: both "k-major"            (TA = true,  TB = true)
+//   dgrad  dX[rows, Kin] = dY . W       dY [rows, Nout] row-major, W [Nout, Kin] as [K][N]         (TA = false, TB = true)
+// Round 3 brought every such operand into nn.Linear's NT form first (10 transpose_convert launches per step) and summed the bias
+// gradients in separate two-stage column-sum launches.  Here a k-major operand is staged into LDS as it lies in memory ([64 k][128
+// columns], 256-byte rows, LDS-DMA with the 16-byte-chunk XOR swizzle of cdna_hip_programming.md T10 image (b) on the source
+// address) and its MFMA fragments are read TRANSPOSED by ds_read_b64_tr_b16: no transposed tensor exists anywhere.  The bias
+// gradient db[m] = sum_k dY[k][m] rides along as one more MFMA per k-step against a fragment of ones (COLSUM: column 0 of the
+// extra accumulator), written by the n-tile-0 workgroups.
+// 128 x 128 x 64 tiles, 4 waves of 64 x 64 (16x16x32 bf16 MFMA, fp32 accumulate), two LDS buffers, one barrier per K tile - the
+// structure of gemm.hip's 128-square kernel; these GEMMs are train.py-sized (rows = 16 x 128), 0.3 ms in all.
+// Measured and not kept: a four-stage 128 x 128 x 32 form of the wgrad (LDS-DMA two K tiles ahead behind a counted vmcnt, one raw
+// barrier per 16 MFMAs) - 1.329 against 1.286 ms per training step: the barrier per 32-wide K tile costs more than the exposed load
+// latency it removes (two workgroups per CU already cover for each other).
+#include "common.h"
+#include "kernels.h"
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+
+typedef short tn_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tn_v4s* tn_lds_v4s;
+
+__device__ __forceinline__ int tn_xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+// image (b): byte offset of 16-byte chunk ch (0..15) of row `row` of a [rows][128 x 16-bit] tile
+__device__ __forceinline__ int tn_key(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// C[M,N] fp32 = op(A) . op(B) (+ bias[n]);  TA: A stored [K][M] (lda = elements per k row) else [M][K];  TB: B stored [K][N] else [N][K].
+// Rows / columns past the logical extents read as zeros (buffer resources), M and N need not be tile multiples; K % 64 == 0.
+template <bool TA, bool TB, bool COLSUM>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                              const float* __restrict__ bias, float* __restrict__ C,
+                                                              float* __restrict__ colsum_out, int M, int N, int K, int k_valid,
+                                                              int lda, int ldb, int ldc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = (N + TBN - 1) / TBN, ntm = (M + TBM - 1) / TBM;
+  const int tile = tn_xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (tile / ntn) * TBM, n0 = (tile % ntn) * TBN;
+
+  // ---- LDS-DMA sources.  Row-major operand ([rows of the tile][64 k], 128-byte rows): 8 rows x 128 B per piece, chunk XOR (r >> 1) & 7.
+  // k-major operand ([64 k][128 columns], 256-byte rows): 4 rows x 256 B per piece, chunk XOR tn_key(row).  Out-of-range rows /
+  // columns fall outside the buffer resource and read as zeros.
+  __amdgpu_buffer_rsrc_t rs_a, rs_b;
+  int a_off[4], b_off[4];
+  if constexpr (TA) {
+    // rows = k (valid: k_valid), columns m0 .. m0 + 127 (valid: < M).  num_records bounds the ROWS; columns are clamped per lane.
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)k_valid * lda * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 4 + (lane >> 4);                // k row inside the K tile, 0..63
+      const int ch = (lane & 15) ^ tn_key(row);                        // source chunk that lands at LDS position lane & 15
+      // columns >= M only feed output rows that are never stored (an MFMA row depends on its own A row alone): no clamp needed,
+      // and reads past the end of the array fall outside num_records (zeros, no fault)
+      a_off[i] = (row * lda + m0 + ch * 8) * 2;
+    }
+  } else {
+    const int rows = M - m0 < TBM ? M - m0 : TBM;
+    rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (size_t)m0 * lda), 0, (unsigned)((size_t)rows * lda * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wave * 4 + i) * 8 + (lane >> 3);
+      a_off[i] = (r * lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+  }
+  if constexpr (TB) {
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (unsigned)((size_t)k_valid * ldb * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave * 4 + i) * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ tn_key(row);
+      b_off[i] = (row * ldb + n0 + ch * 8) * 2;
+    }
+  } else {
+    const int rows = N - n0 < TBN ? N - n0 : TBN;
+    rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(B + (size_t)n0 * ldb), 0, (unsigned)((size_t)rows * ldb * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (wave * 4 + i) * 8 + (lane >> 3);
+      b_off[i] = (r * ldb + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2;
+    }
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * 32768;
+    char* lb = la + 16384;
+    const int so_a = TA ? kt * TBK * lda * 2 : kt * TBK * 2;
+    const int so_b = TB ? kt * TBK * ldb * 2 : kt * TBK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(la + (wave * 4 + i) * 1024), 16, a_off[i], so_a, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(lb + (wave * 4 + i) * 1024), 16, b_off[i], so_b, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+  f32x4 cs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool do_cs = COLSUM && n0 == 0 && wn == 0;
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, (u32x4){0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+  // transposed fragment of the 16-column block cb at k-step ks of a k-major image: two 4-row x 16-column blocks (rows 8 g + 4 h + q)
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  auto tr_frag = [&](const char* img, int ks, int cb) -> bf16x8 {
+    const int r0 = ks * 32 + 8 * fq + tq;
+    const int ch = 2 * cb + (tp >> 1);
+    const int oa = 256 * r0 + 16 * (ch ^ tn_key(r0)) + 8 * (tp & 1);
+    const int r1 = r0 + 4;
+    const int ob = 256 * r1 + 16 * (ch ^ tn_key(r1)) + 8 * (tp & 1);
+    const tn_v4s ta = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_v4s)(img + oa));
+    const tn_v4s tb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_v4s)(img + ob));
+    const u32x2 ua = __builtin_bit_cast(u32x2, ta), ub = __builtin_bit_cast(u32x2, tb);
+    return __builtin_bit_cast(bf16x8, (u32x4){ua[0], ua[1], ub[0], ub[1]});
+  };
+  auto row_frag = [&](const char* img, int ks, int r) -> bf16x8 {
+    return *(const bf16x8*)(img + r * 128 + (((ks * 4 + fq) ^ ((r >> 1) & 7)) << 4));
+  };
+  auto compute = [&](int buf) {
+    const char* la = smem + buf * 32768;
+    const char* lb = la + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (TA) af[i] = tr_frag(la, ks, wm * 4 + i); else af[i] = row_frag(la, ks, wm * 64 + i * 16 + fr);
+        if constexpr (TB) bfr[i] = tr_frag(lb, ks, wn * 4 + i); else bfr[i] = row_frag(lb, ks, wn * 64 + i * 16 + fr);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = op16<bf16_t>::mfma(af[i], bfr[j], acc[i][j]);
+        if constexpr (COLSUM) { if (do_cs) cs[i] = op16<bf16_t>::mfma(af[i], ones, cs[i]); }
+      }
+    }
+  };
+
+  const int nk = K / TBK;
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk - 1; ++kt) {
+    stage(cur ^ 1, kt + 1);
+    compute(cur);
+    __syncthreads();
+    cur ^= 1;
+  }
+  compute(cur);
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + fr;
+      const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+        if (m < M && n < N) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+      }
+    }
+    if constexpr (COLSUM) {
+      if (do_cs && fr == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
+          if (m < M) colsum_out[m] = cs[i][e];
+        }
+      }
+    }
+  }
+}
+
+// C[M,N] fp32 = op(A) . op(B) + bias.  ta: A is stored [K][M] (else [M][K]); tb: B is stored [K][N] (else [N][K], nn.Linear's weight).
+// k_valid <= K: contraction rows that exist in memory (the rest reads as zeros; K itself a multiple of 64).  colsum_out (ta only,
+// nullable): [M] column sums of A over k = the bias gradient of a wgrad.  Returns -1 for an unsupported shape.
+int launch_gemm_bf16_tn(bool ta, bool tb, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
+                        int K, int k_valid, float* colsum_out, hipStream_t s) {
+  if (K % TBK || K <= 0 || M <= 0 || N <= 0 || !tb || (colsum_out && !ta) || (lda % 8) || (ldb % 8)) return -1;
+  const int ntm = (M + TBM - 1) / TBM, ntn = (N + TBN - 1) / TBN;
+  const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
+  const size_t lds = 65536;
+  static DeviceOnce once;
+  once.run([&] {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  if (ta && colsum_out) gemm_bf16_tn_kernel<true, true, true><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, colsum_out, M, N, K, k_valid, lda, ldb, ldc);
+  else if (ta) gemm_bf16_tn_kernel<true, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc);
+  else gemm_bf16_tn_kernel<false, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc);
+  return 0;
+}

@@ -172,7 +172,11 @@ void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_m
 // relu = 0: plain LayerNorm backward (Transformer path); accumulate = 1: dY += result (residual stream)
 int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
                        int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s,
-                       int relu = 1, int accumulate = 0);
+                       int relu = 1, int accumulate = 0, void* dYb = nullptr /* bf16 copy of dY (wgrad operand), nullable */);
+// training GEMMs on k-major operands (gemm_tn.hip): C[M,N] fp32 = op(A) . op(B) + bias; ta: A stored [K][M]; tb (required): B stored [K][N];
+// colsum_out (ta only): [M] column sums of A = the bias gradient of a wgrad; k_valid: contraction rows present in memory
+int launch_gemm_bf16_tn(bool ta, bool tb, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
+                        int K, int k_valid, float* colsum_out, hipStream_t s);
 
 // post-processing (postproc.hip)
 int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, hipStream_t s);

@@ -1061,7 +1061,7 @@ extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* con
 
 struct BwdLayout {
   size_t total;
-  size_t dLp, dLf, dLt, HRt, WcT, dWc, dHR, carry, dhpart, WhhT, dGI, dGH, dGIop, dGHop, part, T1, T2, WihT, dE, dY, Hprev, vec, bhx, bsync;
+  size_t dLp, dLf, dLt, HRt, WcT, dWc, dHR, carry, dhpart, WhhT, dGI, dGH, dGIop, dGHop, part, T1, T2, WihT, dE, dY, dYb, Hprev, vec, bhx, bsync;
 };
 static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   const size_t es = h->bf16 ? 2 : 4;
@@ -1082,6 +1082,7 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   L.T2 = put(std::max<size_t>(std::max<size_t>(E, H), Din) * Rp * es);   // transposed "B" operand (Et / Hprev_t / Xt)
   L.WihT = put(E * 3 * H * es);
   L.dE = put((size_t)R * E * 4); L.dY = put((size_t)R * E * 4);
+  L.dYb = put(Rp * E * 2);                                      // bf16 copy of dY: k-major A operand of layer1's wgrad
   L.Hprev = put((size_t)R * H * es);
   L.vec = put(4 * E * 4);
   L.bhx = put(gru_bptt_hx_bytes(h->bf16, h->hid, h->G)); L.bsync = put(1024 * 4);     // persistent BPTT: exchange buffers, step counters
@@ -1164,18 +1165,34 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   const float* const* d_dl = (const float* const*)h->d_ptrs;
 
   // ---- head: logits = relu(h) Wc^T + bc  (rnn.py:62-64)
+  // bf16 handles (round 4): every wgrad / dgrad below runs on the k-major GEMM (gemm_tn.hip: operands staged as they lie in memory,
+  // fragments read transposed from LDS, the bias gradient as one more MFMA per k-step) - no transposed copy of any activation or
+  // weight, no separate column-sum launches.  K of a wgrad = the packed rows, padded to 64 by reading zeros (k_valid = R).
+  // fp32 handles keep the transpose + NT-GEMM + two-stage column-sum path (exact-fp32 MFMA, fixed-order fp32 sums).
+  const bool tn = bf;
   launch_gather_dlogits(bf, d_dl, h->d_rowoff, h->d_sorted, h->t_max, R, C, Cp, bw + L.dLp, s);
-  launch_gather_dlogits(false, d_dl, h->d_rowoff, h->d_sorted, h->t_max, R, C, Cp, bw + L.dLf, s);
-  launch_colsum((const float*)(bw + L.dLf), R, Cp, part, (float*)(bw + L.vec), s);
-  HIPCHK(hipMemcpyAsync(g_fc_b, bw + L.vec, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
-  launch_transpose_convert(bf, bf, bw + L.dLp, R, Cp, Cp, bw + L.dLt, Rp, s);            // [Cp][Rp]
-  launch_transpose_convert(bf, bf, HR, R, H, H, bw + L.HRt, Rp, s);                       // [H][Rp]
-  gemm_nt(h, bw + L.dLt, Rp, bw + L.HRt, Rp, nullptr, (float*)(bw + L.dWc), H, Cp, H, Rp, s);   // dWc[Cp][H]
-  HIPCHK(hipMemcpyAsync(g_fc_w, bw + L.dWc, (size_t)C * H * 4, hipMemcpyDeviceToDevice, s));
+  if (tn) {
+    // dWc [C][H] = dL^T . relu(h), db_c = colsum(dL): straight into the caller's gradient tensors
+    if (launch_gemm_bf16_tn(true, true, bw + L.dLp, Cp, HR, H, nullptr, g_fc_w, H, C, H, Rp, R, g_fc_b, s)) return fail(PREGO_EINVAL, "backward: head wgrad shape");
+  } else {
+    launch_gather_dlogits(false, d_dl, h->d_rowoff, h->d_sorted, h->t_max, R, C, Cp, bw + L.dLf, s);
+    launch_colsum((const float*)(bw + L.dLf), R, Cp, part, (float*)(bw + L.vec), s);
+    HIPCHK(hipMemcpyAsync(g_fc_b, bw + L.vec, (size_t)C * 4, hipMemcpyDeviceToDevice, s));
+    launch_transpose_convert(bf, bf, bw + L.dLp, R, Cp, Cp, bw + L.dLt, Rp, s);            // [Cp][Rp]
+    launch_transpose_convert(bf, bf, HR, R, H, H, bw + L.HRt, Rp, s);                       // [H][Rp]
+    gemm_nt(h, bw + L.dLt, Rp, bw + L.HRt, Rp, nullptr, (float*)(bw + L.dWc), H, Cp, H, Rp, s);   // dWc[Cp][H]
+    HIPCHK(hipMemcpyAsync(g_fc_w, bw + L.dWc, (size_t)C * H * 4, hipMemcpyDeviceToDevice, s));
+  }
   if (h->bwd_ev[0]) HIPCHK(hipEventRecord(h->bwd_ev[0], s));            // f_classification gradients are final
   if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 0);
-  launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
-  gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
+  if (tn) {
+    // d relu(h) [R][H] = dL [R][Cp] . Wc [ncls_pad][H]: the weight as it is stored ([K][N]); rows >= ncls_pad read as zeros
+    if (launch_gemm_bf16_tn(false, true, bw + L.dLp, Cp, h->w_c, H, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, h->ncls_pad, nullptr, s))
+      return fail(PREGO_EINVAL, "backward: head dgrad shape");
+  } else {
+    launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
+    gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
+  }
   launch_relu_mask((const float*)(bw + L.dHR), HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);
 
   // ---- BPTT through the GRU (rnn.py:61), reverse time
@@ -1210,37 +1227,59 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
     if (t > 0)   // dh_{t-1} += dgh_t . W_hh
       gemm_nt(h, bw + L.dGHop + (size_t)row_t * 3 * H * es, 3 * H, bw + L.WhhT, 3 * H, nullptr, dhpart, H, na, H, 3 * H, s);
   }
-  // biases of the GRU
-  launch_colsum((const float*)(bw + L.dGI), R, 3 * H, part, g_b_ih, s);
-  launch_colsum((const float*)(bw + L.dGH), R, 3 * H, part, g_b_hh, s);
-  // dW_ih = dGI^T . e
-  launch_transpose_convert(bf, bf, bw + L.dGIop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
-  launch_transpose_convert(bf, bf, Eb, R, E, E, bw + L.T2, Rp, s);
-  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_ih, E, 3 * H, E, Rp, s);
-  // dW_hh = dGH^T . h_{t-1}
   launch_build_hprev(bf, HRAW, h->d_rowoff, h->t_max, R, H, bw + L.Hprev, s);
-  launch_transpose_convert(bf, bf, bw + L.dGHop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
-  launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
-  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
+  if (tn) {
+    // dW_ih = dGI^T . e (+ db_ih), dW_hh = dGH^T . h_{t-1} (+ db_hh): bias sums from the bf16 operand copies the BPTT kernel wrote
+    if (launch_gemm_bf16_tn(true, true, bw + L.dGIop, 3 * H, Eb, E, nullptr, g_w_ih, E, 3 * H, E, Rp, R, g_b_ih, s) ||
+        launch_gemm_bf16_tn(true, true, bw + L.dGHop, 3 * H, bw + L.Hprev, H, nullptr, g_w_hh, H, 3 * H, H, Rp, R, g_b_hh, s))
+      return fail(PREGO_EINVAL, "backward: GRU wgrad shape");
+  } else {
+    // biases of the GRU
+    launch_colsum((const float*)(bw + L.dGI), R, 3 * H, part, g_b_ih, s);
+    launch_colsum((const float*)(bw + L.dGH), R, 3 * H, part, g_b_hh, s);
+    // dW_ih = dGI^T . e
+    launch_transpose_convert(bf, bf, bw + L.dGIop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
+    launch_transpose_convert(bf, bf, Eb, R, E, E, bw + L.T2, Rp, s);
+    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_ih, E, 3 * H, E, Rp, s);
+    // dW_hh = dGH^T . h_{t-1}
+    launch_transpose_convert(bf, bf, bw + L.dGHop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
+    launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
+    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
+  }
   if (h->bwd_ev[1]) HIPCHK(hipEventRecord(h->bwd_ev[1], s));            // all four GRU gradients are final (layer1 / LayerNorm follow)
   if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 1);
   // d e = dGI . W_ih
-  launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
-  gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);
+  if (tn) {
+    if (launch_gemm_bf16_tn(false, true, bw + L.dGIop, 3 * H, h->w_ih, E, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, 3 * H, nullptr, s))
+      return fail(PREGO_EINVAL, "backward: W_ih dgrad shape");
+  } else {
+    launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
+    gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);
+  }
 
   // ---- Dropout / ReLU / LayerNorm backward (rnn.py:41-43)
   const int nb = launch_ln_relu_bwd((const float*)(bw + L.dE), Y, STATS, h->ln_g, h->ln_b, R, E, h->drop_p, h->drop_seed, 0,
-                                    (float*)(bw + L.dY), part, s);
-  launch_colsum_stage2(part, nb, 2 * E, (float*)(bw + L.vec), s);
-  HIPCHK(hipMemcpyAsync(g_ln_w, bw + L.vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemcpyAsync(g_ln_b, bw + L.vec + (size_t)E * 4, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+                                    (float*)(bw + L.dY), part, s, 1, 0, tn ? (void*)(bw + L.dYb) : nullptr);
+  // d gamma | d beta: the stage-2 sum goes straight into the caller's two tensors when they are adjacent (the flat gradient bucket
+  // of prego_amd/engine.py), through a scratch vector and two copies otherwise
+  if (g_ln_b == g_ln_w + E) launch_colsum_stage2(part, nb, 2 * E, g_ln_w, s);
+  else {
+    launch_colsum_stage2(part, nb, 2 * E, (float*)(bw + L.vec), s);
+    HIPCHK(hipMemcpyAsync(g_ln_w, bw + L.vec, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g_ln_b, bw + L.vec + (size_t)E * 4, (size_t)E * 4, hipMemcpyDeviceToDevice, s));
+  }
 
   // ---- layer1 Linear (rnn.py:40): db = colsum(dY), dW = dY^T . x
-  launch_colsum((const float*)(bw + L.dY), R, E, part, g_layer1_b, s);
-  launch_transpose_convert(false, bf, bw + L.dY, R, E, E, bw + L.T1, Rp, s);
-  launch_transpose_convert(bf, bf, X, R, kx, kx, bw + L.T2, Rp, s);
   if (kx < din) HIPCHK(hipMemsetAsync(g_layer1_w, 0, (size_t)E * din * 4, s));          // zero-flow columns: zero gradient
-  gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_layer1_w, din, E, kx, Rp, s);
+  if (tn) {
+    if (launch_gemm_bf16_tn(true, true, bw + L.dYb, E, X, kx, nullptr, g_layer1_w, din, E, kx, Rp, R, g_layer1_b, s))
+      return fail(PREGO_EINVAL, "backward: layer1 wgrad shape");
+  } else {
+    launch_colsum((const float*)(bw + L.dY), R, E, part, g_layer1_b, s);
+    launch_transpose_convert(false, bf, bw + L.dY, R, E, E, bw + L.T1, Rp, s);
+    launch_transpose_convert(bf, bf, X, R, kx, kx, bw + L.T2, Rp, s);
+    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_layer1_w, din, E, kx, Rp, s);
+  }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

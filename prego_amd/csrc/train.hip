@@ -223,7 +223,8 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
     const float* __restrict__ dE, const float* __restrict__ Y, const float* __restrict__ stats,
     const float* __restrict__ gamma, const float* __restrict__ beta, int nrows, int E, float drop_p,
-    unsigned long long seed, int row0_abs, float* __restrict__ dY, float* __restrict__ part, int relu, int accumulate) {
+    unsigned long long seed, int row0_abs, float* __restrict__ dY, float* __restrict__ part, int relu, int accumulate,
+    bf16_t* __restrict__ dYb /* nullable: the same rows in bf16 = the k-major A operand of layer1's wgrad (gemm_tn.hip) */) {
   __shared__ float sg[4][4096 / 1];   // per-wave dgamma contributions are reduced through LDS below (E <= 4096)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = E / 256;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
         o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
       }
       *(float4*)(dY + (size_t)r * E + c) = o;
+      if (dYb) *(uint2*)(dYb + (size_t)r * E + c) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
     }
   // block partials of dgamma (pass 0) and dbeta (pass 1): fixed order wave 0..3
   for (int pass = 0; pass < 2; ++pass) {
@@ -351,10 +353,10 @@ void launch_build_hprev(bool bf16, const float* Hraw, const int* rowoff, int t_m
 // part must hold ceil(nrows/4) * 2 * E floats; returns the number of row blocks
 int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, const float* gamma, const float* beta, int nrows,
                        int E, float drop_p, unsigned long long seed, int row0_abs, float* dY, float* part, hipStream_t s,
-                       int relu, int accumulate) {
+                       int relu, int accumulate, void* dYb) {
   const int nb = (nrows + 3) / 4;
   if (nb <= 0) return 0;
-  if (E <= 2048) ln_relu_bwd_rows_kernel<8><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate);
-  else ln_relu_bwd_rows_kernel<16><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate);
+  if (E <= 2048) ln_relu_bwd_rows_kernel<8><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate, (bf16_t*)dYb);
+  else ln_relu_bwd_rows_kernel<16><<<nb, 256, 0, s>>>(dE, Y, stats, gamma, beta, nrows, E, drop_p, seed, row0_abs, dY, part, relu, accumulate, (bf16_t*)dYb);
   return nb;
 }
