@@ -53,10 +53,14 @@ __device__ __forceinline__ int pp_key_b(int r) { return ((r >> 1) & 1) | (((r >>
 // OT = operand type tag (common.h: bf16_t or f16_t): selects the MFMA opcode and the 16-bit output conversion only.
 // WORKER (probe of DESIGN 5c, prego_debug_gemm_worker): a persistent workgroup that leaves at once on XCDs below epi.xcd_lo and
 // otherwise claims tiles from the atomic counter epi.counter until none is left (m-major order: consecutive tiles share A rows).
-// SPLIT (fp16x2 operands, common.h): A rows are [K hi | .. | K lo at column epi.split_a_lo], B rows likewise at epi.split_b_lo; the K
-// loop runs 3 K / 64 tiles - A_hi.B_lo, then A_lo.B_hi, then A_hi.B_hi (small terms first) - through the unchanged phase
-// structure: a K tile's column is a scalar function of its index, the LDS ring and every wait count stay as they are.  The
-// epilogue multiplies the weights' power-of-two scale out (epi.acc_scale: device pointer to 1 / scale) before the bias.
+// SPLIT (fp16x2 operands, common.h): A rows are [K hi | .. | K lo at column epi.split_a_lo], B rows likewise at epi.split_b_lo.  A K
+// tile then covers 32 values of k and its 128-byte LDS row holds [32 hi | 32 lo]: the 16-byte chunks 0-3 of a row come from the hi
+// half, chunks 4-7 from the lo half of the same k range (a per-lane constant in the DMA source offset, nothing else changes in the
+// staging, the LDS ring or the wait counts), so the k-step-0 fragments ARE the hi operands and the k-step-1 fragments the lo
+// operands, and a phase multiplies a_hi.b_lo, a_lo.b_hi, a_hi.b_hi (small terms first): 24 MFMAs behind the same 12 fragment
+// reads and 2 DMA pieces that serve 16 in the 16-bit kernel - a third less LDS traffic and DMA per product than walking three K
+// segments through the unchanged loop (the first fp16x2 form: 165 -> 136 ms per pass of the bench workload, 1.49 PFLOP/s of executed MFMA work).  The epilogue multiplies the
+// weights' power-of-two scale out (epi.acc_scale: device pointer to 1 / scale) before the bias.
 template <int EPI, typename OT = bf16_t, bool WORKER = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
@@ -70,17 +74,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   const int ntn = N / PBN;
   const int ntm = (M + PBM - 1) / PBM;
   const int ntiles = ntm * ntn;
-  const int nks = K / PBK;                                      // K tiles of one operand segment
-  const int nk = SPLIT ? 3 * nks : nks;
-  // element column of K tile kt in the A / B rows
-  auto acol = [&](int kt) -> int {
-    if constexpr (SPLIT) return kt < nks ? kt * PBK : (kt < 2 * nks ? (kt - nks) * PBK + epi.split_a_lo : (kt - 2 * nks) * PBK);
-    else return kt * PBK;
-  };
-  auto bcol = [&](int kt) -> int {
-    if constexpr (SPLIT) return kt < nks ? kt * PBK + epi.split_b_lo : (kt < 2 * nks ? (kt - nks) * PBK : (kt - 2 * nks) * PBK);
-    else return kt * PBK;
-  };
+  const int nk = SPLIT ? K / (PBK / 2) : K / PBK;               // SPLIT: a K tile = 32 values of k (hi and lo halves side by side)
   int idx = blockIdx.x;
   int tile = WORKER ? 0 : pp_xcd_remap(idx, ntiles);
   int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
@@ -99,8 +93,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
   for (int i = 0; i < 2; ++i) {
     const int r = (wave * 2 + i) * 8 + sr;                      // row inside the half-tile, 0..127
     const int c = scp ^ ((r >> 1) & 7);
-    a_off[i] = r * lda * 2 + c * 16;
-    b_off[i] = r * ldb * 2 + (scp ^ pp_key_b(r)) * 16;
+    const int cb = scp ^ pp_key_b(r);
+    if constexpr (SPLIT) {                                      // chunks 0-3: k .. k + 31 of the hi half; chunks 4-7: the same k of the lo half
+      a_off[i] = r * lda * 2 + (c < 4 ? c * 16 : epi.split_a_lo * 2 + (c - 4) * 16);
+      b_off[i] = r * ldb * 2 + (cb < 4 ? cb * 16 : epi.split_b_lo * 2 + (cb - 4) * 16);
+    } else {
+      a_off[i] = r * lda * 2 + c * 16;
+      b_off[i] = r * ldb * 2 + cb * 16;
+    }
   }
   __amdgpu_buffer_rsrc_t rs_a, rs_b;
   auto set_sources = [&](int tm0, int tn0) {
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     return;
 #endif
     char* dst = smem + (kt & 1) * PBUF + hf * PHALF + wave * 2048;
-    const int so = hf * 128 * lda * 2 + acol(kt) * 2;
+    const int so = hf * 128 * lda * 2 + kt * (SPLIT ? PBK : PBK * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, a_off[i], so, 0, 0);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
     return;
 #endif
     char* dst = smem + (kt & 1) * PBUF + (2 + hf) * PHALF + wave * 2048;
-    const int so = hf * 128 * ldb * 2 + bcol(kt) * 2;
+    const int so = hf * 128 * ldb * 2 + kt * (SPLIT ? PBK : PBK * 2);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, b_off[i], so, 0, 0);
@@ -174,12 +174,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_nt_pingpong_kernel(
 #define PP_PRIO 1
 #endif
     __builtin_amdgcn_s_setprio(PP_PRIO);
+    if constexpr (SPLIT) {               // k-step 0 = hi fragments, k-step 1 = lo fragments of the same 32 k: three products, small first
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          c[i][j] = op16<OT>::mfma(bf[1][j], af[0][i], c[i][j]);
+          c[i][j] = op16<OT>::mfma(bf[0][j], af[1][i], c[i][j]);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[i][j] = op16<OT>::mfma(bf[0][j], af[0][i], c[i][j]);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) c[i][j] = op16<OT>::mfma(bf[ks][j], af[ks][i], c[i][j]);   // D^T: see epilogue
+    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -431,7 +445,7 @@ int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb
 // A rows [.. lda fp16 ..] hold hi at column 0 and lo at column a_lo; B rows hi at 0 and lo at b_lo; any M (rows past M read as zeros).
 int launch_gemm_x2_pingpong(const void* A, int lda, int a_lo, const void* B, int ldb, int b_lo, const float* inv_scale, const float* bias,
                             float* C, int ldc, int M, int N, int K, hipStream_t s) {
-  if (N % PBN || K % PBK || K < 2 * PBK || !bias || M <= 0) return -1;
+  if (N % PBN || K % (PBK / 2) || K < PBK || !bias || M <= 0) return -1;
   const int ntm = (M + PBM - 1) / PBM, ntn = N / PBN, ntiles = ntm * ntn;
   static DeviceOnce once;
   once.run([&] {
