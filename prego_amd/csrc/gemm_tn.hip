@@ -35,7 +35,7 @@ template <bool TA, bool TB, bool COLSUM>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                               const float* __restrict__ bias, float* __restrict__ C,
                                                               float* __restrict__ colsum_out, int M, int N, int K, int k_valid,
-                                                              int lda, int ldb, int ldc) {
+                                                              int lda, int ldb, int ldc, bf16_t* __restrict__ C16 /* nullable: bf16 C instead */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KB | B 16 KB]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16_t* __re
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = m0 + wm * 64 + i * 16 + fq * 4 + e;
-        if (m < M && n < N) C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+        if (m < M && n < N) {
+          if (C16) C16[(size_t)m * ldc + n] = f2bf(acc[i][j][e] + bv);
+          else C[(size_t)m * ldc + n] = acc[i][j][e] + bv;
+        }
       }
     }
     if constexpr (COLSUM) {
@@ -183,9 +186,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const bf16_t* __re
 
 // C[M,N] fp32 = op(A) . op(B) + bias.  ta: A is stored [K][M] (else [M][K]); tb: B is stored [K][N] (else [N][K], nn.Linear's weight).
 // k_valid <= K: contraction rows that exist in memory (the rest reads as zeros; K itself a multiple of 64).  colsum_out (ta only,
-// nullable): [M] column sums of A over k = the bias gradient of a wgrad.  Returns -1 for an unsupported shape.
+// nullable): [M] column sums of A over k = the bias gradient of a wgrad.  C16 (nullable): store C as bf16 there instead of fp32 into C.
+// Returns -1 for an unsupported shape.
 int launch_gemm_bf16_tn(bool ta, bool tb, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
-                        int K, int k_valid, float* colsum_out, hipStream_t s) {
+                        int K, int k_valid, float* colsum_out, hipStream_t s, void* C16) {
   if (K % TBK || K <= 0 || M <= 0 || N <= 0 || !tb || (colsum_out && !ta) || (lda % 8) || (ldb % 8)) return -1;
   const int ntm = (M + TBM - 1) / TBM, ntn = (N + TBN - 1) / TBN;
   const bf16_t* a = (const bf16_t*)A; const bf16_t* b = (const bf16_t*)B;
@@ -196,8 +200,8 @@ int launch_gemm_bf16_tn(bool ta, bool tb, const void* A, int lda, const void* B,
     (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
-  if (ta && colsum_out) gemm_bf16_tn_kernel<true, true, true><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, colsum_out, M, N, K, k_valid, lda, ldb, ldc);
-  else if (ta) gemm_bf16_tn_kernel<true, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc);
-  else gemm_bf16_tn_kernel<false, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc);
+  if (ta && colsum_out) gemm_bf16_tn_kernel<true, true, true><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, colsum_out, M, N, K, k_valid, lda, ldb, ldc, (bf16_t*)C16);
+  else if (ta) gemm_bf16_tn_kernel<true, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc, (bf16_t*)C16);
+  else gemm_bf16_tn_kernel<false, true, false><<<ntm * ntn, 256, lds, s>>>(a, b, bias, C, nullptr, M, N, K, k_valid, lda, ldb, ldc, (bf16_t*)C16);
   return 0;
 }

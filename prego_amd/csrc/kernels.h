@@ -176,7 +176,7 @@ int launch_ln_relu_bwd(const float* dE, const float* Y, const float* stats, cons
 // training GEMMs on k-major operands (gemm_tn.hip): C[M,N] fp32 = op(A) . op(B) + bias; ta: A stored [K][M]; tb (required): B stored [K][N];
 // colsum_out (ta only): [M] column sums of A = the bias gradient of a wgrad; k_valid: contraction rows present in memory
 int launch_gemm_bf16_tn(bool ta, bool tb, const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
-                        int K, int k_valid, float* colsum_out, hipStream_t s);
+                        int K, int k_valid, float* colsum_out, hipStream_t s, void* C16 = nullptr /* bf16 C instead of fp32 */);
 
 // post-processing (postproc.hip)
 int launch_window_vote(const int* pred, long long n_frames, int window, int n_classes, int* votes, hipStream_t s);

@@ -503,13 +503,15 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
   return PREGO_OK;
 }
 
-// C[Mo, No] = A^T . B over the rows: A_rows [R, Mo], B_rows [R, No] (fp32 or bf16) -> transposes + NT GEMM (the reduction
-// dimension of every weight gradient is the row index)
-static void wgrad(const void* a_rows, bool a_bf16, int Mo, const void* b_rows, bool b_bf16, int No, int R, int Rp, char* T1, char* T2,
-                  float* out, hipStream_t s) {
-  launch_transpose_convert(a_bf16, true, a_rows, R, Mo, Mo, T1, Rp, s);
-  launch_transpose_convert(b_bf16, true, b_rows, R, No, No, T2, Rp, s);
-  launch_gemm_bf16_nt(T1, Rp, T2, Rp, nullptr, out, No, Mo, No, Rp, s);
+// Weight gradient C[Mo, No] = A^T . B over the rows (the reduction dimension of every weight gradient is the row index) and, when
+// bias_out is given, the bias gradient colsum(A): the k-major GEMM of csrc/gemm_tn.hip reads A_rows [R, Mo] and B_rows [R, No] (bf16) as
+// they lie in memory - round 3 transposed both first and summed the bias in two more launches.  Rp = R padded to 64 (zeros are read).
+static int wgrad(const void* a_rows, int Mo, const void* b_rows, int No, int R, int Rp, float* out, float* bias_out, hipStream_t s) {
+  return launch_gemm_bf16_tn(true, true, a_rows, Mo, b_rows, No, nullptr, out, No, Mo, No, Rp, R, bias_out, s);
+}
+// Input gradient C[R, No] = A [R, Ko] . W [Ko, No]: the weight as nn.Linear stores it IS the [K][N] operand (no transposed copy)
+static int dgrad(const void* a_rows, int Ko, const void* w, int No, int R, float* out, hipStream_t s, void* out16 = nullptr) {
+  return launch_gemm_bf16_tn(false, true, a_rows, Ko, w, No, nullptr, out, No, R, No, Ko, Ko, nullptr, s, out16);
 }
 
 extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits, float* const* grads, int n_tensors, int flags,
@@ -551,15 +553,12 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
     const float* dbr = dx;
     if (dthr) { launch_mask_convert(dx, (size_t)M * E, (float*)(ws + w.dxm), ws + w.dxb, dthr, dsc, site_seed(h, li, 3), s); dbr = (const float*)(ws + w.dxm); }
     else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
-    launch_colsum(dbr, M, E, part, g[10], s);                                                // d b2
-    wgrad(dbr, false, E, ws + k.f, true, mlp, M, Mp, T1, T2, g[9], s);                       // d W2 [E, mlp]
-    launch_transpose_convert(true, true, l.ff2_w, E, mlp, mlp, WT, E, s);                    // W2^T [mlp][E]
-    launch_gemm_bf16_nt(ws + w.dxb, E, WT, E, nullptr, tmp, mlp, M, mlp, E, s);              // d f = dx . W2
+    (void)dbr;                                                                              // the bf16 copy w.dxb carries the same values
+    if (wgrad(ws + w.dxb, E, ws + k.f, mlp, M, Mp, g[9], g[10], s) ||                        // d W2 [E, mlp], d b2
+        dgrad(ws + w.dxb, E, l.ff2_w, mlp, M, tmp, s)) return prego_fail_(PREGO_EINVAL, "backward: FFN-2 GEMM shape");   // d f = dx . W2
     launch_gelu_bwd(tmp, (const float*)(ws + k.u), (size_t)M * mlp, (float*)(ws + w.du), ws + w.dub, s, dthr, dsc, site_seed(h, li, 2));
-    launch_colsum((const float*)(ws + w.du), M, mlp, part, g[8], s);                         // d b1
-    wgrad(ws + w.du, false, mlp, ws + k.xn2, true, E, M, Mp, T1, T2, g[7], s);               // d W1 [mlp, E]
-    launch_transpose_convert(true, true, l.ff1_w, mlp, E, E, WT, mlp, s);                    // W1^T [E][mlp]
-    launch_gemm_bf16_nt(ws + w.dub, mlp, WT, mlp, nullptr, tmp, E, M, E, mlp, s);            // d LN2 out = du . W1
+    if (wgrad(ws + w.dub, mlp, ws + k.xn2, E, M, Mp, g[7], g[8], s) ||                       // d W1 [mlp, E], d b1
+        dgrad(ws + w.dub, mlp, l.ff1_w, E, M, tmp, s)) return prego_fail_(PREGO_EINVAL, "backward: FFN-1 GEMM shape");   // d LN2 out = du . W1
     int nb = launch_ln_relu_bwd(tmp, (const float*)(ws + k.x_mid), (const float*)(ws + k.st2), l.ln2_w, l.ln2_b, M, E, 0.f, 0, 0, dx,
                                 part, s, 0, 1);                                              // dx += LN2 backward
     launch_colsum_stage2(part, nb, 2 * E, vec, s);
@@ -572,19 +571,15 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
                           site_seed(h, li, 5));
       dbr = (const float*)(ws + w.dxm);
     } else launch_f32_to_bf16(dx, ws + w.dxb, (size_t)M * E, s);
-    launch_colsum(dbr, M, E, part, g[4], s);                                                 // d proj bias
-    wgrad(dbr, false, E, ws + k.ao, true, E, M, Mp, T1, T2, g[3], s);                        // d Wproj [E, E]
-    launch_transpose_convert(true, true, l.proj_w, E, E, E, WT, E, s);                       // Wp^T
-    {
-      GemmEpi eb{}; eb.mode = EPI_STORE_BF16; eb.out_b = ws + w.dO;
-      launch_gemm_bf16_nt_epi(ws + w.dxb, E, WT, E, nullptr, nullptr, E, M, E, E, eb, s);    // d o = dx . Wp (bf16, [B,N,h*dh])
-    }
+    (void)dbr;
+    if (wgrad(ws + w.dxb, E, ws + k.ao, E, M, Mp, g[3], g[4], s) ||                          // d Wproj [E, E], d proj bias
+        dgrad(ws + w.dxb, E, l.proj_w, E, M, nullptr, s, ws + w.dO))                         // d o = dx . Wp (bf16, [B,N,h*dh])
+      return prego_fail_(PREGO_EINVAL, "backward: projection GEMM shape");
     if (launch_attention_bwd(ws + k.q, ws + k.k, ws + k.vn, ws + k.ao, ws + w.dO, (const float*)(ws + k.lse), (float*)(ws + w.delta),
                              ws + w.dqkv, B, N, h->heads, dh, causal, 1.0f / sqrtf((float)dh), s, athr_of(h), asc_of(h), site_seed(h, li, 4)))
       return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
-    wgrad(ws + w.dqkv, true, 3 * E, ws + k.xn1, true, E, M, Mp, T1, T2, g[2], s);            // d Wqkv [3E, E]
-    launch_transpose_convert(true, true, l.qkv_w, 3 * E, E, E, WT, 3 * E, s);                // Wqkv^T [E][3E]
-    launch_gemm_bf16_nt(ws + w.dqkv, 3 * E, WT, 3 * E, nullptr, tmp, E, M, E, 3 * E, s);     // d LN1 out
+    if (wgrad(ws + w.dqkv, 3 * E, ws + k.xn1, E, M, Mp, g[2], nullptr, s) ||                 // d Wqkv [3E, E] (no bias, Attention.py:16)
+        dgrad(ws + w.dqkv, 3 * E, l.qkv_w, E, M, tmp, s)) return prego_fail_(PREGO_EINVAL, "backward: qkv GEMM shape");   // d LN1 out
     nb = launch_ln_relu_bwd(tmp, (const float*)(ws + k.x_in), (const float*)(ws + k.st1), l.ln1_w, l.ln1_b, M, E, 0.f, 0, 0, dx, part,
                             s, 0, 1);                                                        // dx += LN1 backward
     launch_colsum_stage2(part, nb, 2 * E, vec, s);
@@ -594,8 +589,8 @@ extern "C" int prego_vit_backward(prego_vit* h, int batch, const float* dlogits,
   // ---- tokens: positional table, cls token, encoding Linear (ViT.py:125-129)
   float* denc = (float*)(ws + w.denc);
   launch_vit_tokens_bwd(dx, B, T, E, denc, g_pe, g_cls, s, dthr, dsc, site_seed(h, 0, 0));
-  launch_colsum(denc, B * T, E, part, g_enc_b, s);
-  wgrad(denc, false, E, ws + w.xb, true, din, B * T, w.MTp, T1, T2, g_enc_w, s);             // d W_enc [E, din]
+  launch_f32_to_bf16(denc, T1, (size_t)B * T * E, s);                                        // the wgrad's A operand in bf16 (rows = frames)
+  if (wgrad(T1, E, ws + w.xb, din, B * T, w.MTp, g_enc_w, g_enc_b, s)) return prego_fail_(PREGO_EINVAL, "backward: encoding GEMM shape");   // d W_enc [E, din], d b_enc
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
@@ -809,27 +804,20 @@ extern "C" int prego_attention_layer_backward(prego_attn_layer* h, int batch, in
   char* T1 = ws + w.T1; char* T2 = ws + w.T2; char* WT = ws + w.WT;
   // ---- out_projection (attn.py:170): d bo, d Wo, d (attention output)
   launch_f32_to_bf16(dout, ws + w.dyb, (size_t)M * D, s);
-  launch_colsum(dout, M, D, part, grads[7], s);
-  wgrad(dout, false, D, ao, true, D, M, Mp, T1, T2, grads[6], s);
-  launch_transpose_convert(true, true, h->wo, D, D, D, WT, D, s);
-  {
-    GemmEpi eb{}; eb.mode = EPI_STORE_BF16; eb.out_b = ws + w.dO;
-    launch_gemm_bf16_nt_epi(ws + w.dyb, D, WT, D, nullptr, nullptr, D, M, D, D, eb, s);
-  }
+  if (wgrad(ws + w.dyb, D, ao, D, M, Mp, grads[6], grads[7], s) ||                           // d Wo, d bo
+      dgrad(ws + w.dyb, D, h->wo, D, M, nullptr, s, ws + w.dO)) return prego_fail_(PREGO_EINVAL, "backward: out_projection GEMM shape");
   // ---- softmax(scale * Q K^T + mask) V (attn.py:41-52)
   if (launch_attention_bwd(q, k, vn, ao, ws + w.dO, (const float*)(ws + w.lse), (float*)(ws + w.delta), ws + w.dqkv, batch, len,
                            h->heads, dh, causal ? 1 : 0, 1.0f / sqrtf((float)dh), s))
     return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
   // ---- query / key / value projections (attn.py:160-162): rows of dqkv are [dq | dk | dv]
-  launch_colsum_bf16(ws + w.dqkv, M, 3 * D, part, vec, s);
-  wgrad(ws + w.dqkv, true, 3 * D, xb, true, D, M, Mp, T1, T2, dW, s);
+  if (wgrad(ws + w.dqkv, 3 * D, xb, D, M, Mp, dW, vec, s)) return prego_fail_(PREGO_EINVAL, "backward: qkv GEMM shape");
   for (int j = 0; j < 3; ++j) {
     HIPCHK(hipMemcpyAsync(grads[2 * j], dW + j * DD, DD * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(grads[2 * j + 1], vec + (size_t)j * D, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
   }
   if (dx) {     // self-attention: queries = keys = values = x, the three input gradients add up = dqkv . Wqkv
-    launch_transpose_convert(true, true, h->wqkv, 3 * D, D, D, WT, 3 * D, s);
-    launch_gemm_bf16_nt(ws + w.dqkv, 3 * D, WT, 3 * D, nullptr, dx, D, M, D, 3 * D, s);
+    if (dgrad(ws + w.dqkv, 3 * D, h->wqkv, D, M, dx, s)) return prego_fail_(PREGO_EINVAL, "backward: qkv dgrad shape");
   }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
