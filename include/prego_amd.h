@@ -324,7 +324,7 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
  * production, every one selects between two code paths that both stay tested - DESIGN.md section 6 says what each measured):
  *   PREGO_NO_XCD_OVERLAP, PREGO_OVERLAP_NARROW, PREGO_OVERLAP_MAX_GD, PREGO_GRU_COMPACT   layer1 worker on the XCDs the recurrence left
  *   PREGO_GRU_NO_MT, PREGO_GRU_MT_SPEC, PREGO_GRU_NO_LOCAL, PREGO_GRU_STAMPS, PREGO_NO_ARM_FUSE   recurrence kernel choice / hand-off
- *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY                     where the next chunk's pack runs
+ *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY, PREGO_SIDE_PRIO    where / on what stream the next chunk's pack runs
  *   PREGO_PLAN_SLOTS, PREGO_FP32_INTERMEDIATES                                             planner calibration, fp32 Y / GI in 16-bit modes
  *   PREGO_GEMM_NO_PINGPONG, PREGO_GEMM_NO_BIG, PREGO_HEAD_V1, PREGO_BPTT_STEPWISE, PREGO_STEP_NO_LN_FUSE, PREGO_VIT_TOKENS_KERNEL,
  *   PREGO_ATTN_NW                                                                          older kernels kept as A/B references

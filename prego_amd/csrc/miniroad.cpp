@@ -209,7 +209,18 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   // costs the pass 0.9 ms less than unthrottled (sweep: scripts/probes/env_sweep.sh, 128: +10 ms, 256: +1, 512: -0.9, 1024: 0)
   h->prefetch_grid = 512;
   if (const char* pg = getenv("PREGO_PACK_PREFETCH_GRID")) h->prefetch_grid = atoi(pg);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  // The side stream must run BESIDE the caller's stream.  HIP maps streams onto a handful of hardware queues in creation order and
+  // two streams on one queue execute in submission order (round 4: an eval loop whose copy stream shared the compute stream's queue
+  // lost all of its overlap), and a queue has one priority: a LOW-priority side stream never shares the queue of a normal-priority
+  // caller, and its pack / layer1 worker yield to the recurrence where they compete.  PREGO_SIDE_PRIO=0: the plain stream (A/B).
+  if (e == hipSuccess) {
+    int lo = 0, hi = 0;
+    static const bool plain = getenv("PREGO_SIDE_PRIO") != nullptr && atoi(getenv("PREGO_SIDE_PRIO")) == 0;
+    if (!plain && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+      e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo);       // lo = numerically greatest = least priority
+    else
+      e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
   A((void**)&h->stamps, 8 * sizeof(unsigned long long));

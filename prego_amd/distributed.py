@@ -106,7 +106,9 @@ def allreduce_bucket_(flat: torch.Tensor, lo: int, hi: int, world: int, event=No
     dev = flat.device
     comm = _COMM_STREAMS.get(dev)
     if comm is None:
-        comm = _COMM_STREAMS[dev] = torch.cuda.Stream(dev)
+        # high priority: a hardware queue of its own (streams of equal priority may share one and then run in submission order),
+        # and the collective wins arbitration against the backward it runs under
+        comm = _COMM_STREAMS[dev] = torch.cuda.Stream(dev, priority=-1)
     flat.record_stream(comm)
     if event is not None:
         comm.wait_event(event)           # recorded inside prego_miniroad_backward when this sub-bucket became final

@@ -41,6 +41,15 @@ class Evaluate(nn.Module):
         self.last_fps = None
         self._copy_stream = None             # side stream for the H2D feature copies (double buffering against the compute stream)
 
+    @staticmethod
+    def _new_copy_stream(dev):
+        """The H2D copies must run BESIDE the forward's kernels.  HIP maps streams onto a handful of hardware queues round-robin in
+        creation order, and two streams that share a queue execute in submission order: in a process that had created a few streams
+        before (bench.py after its main pass) the copy stream landed on the compute stream's queue and the whole transfer ran in FRONT
+        of the forward (149 instead of 89 ms for the 60-video set).  A queue has one priority, so a high-priority stream never shares
+        the queue of the normal-priority compute stream."""
+        return torch.cuda.Stream(dev, priority=-1)
+
     def _zero_flow(self, model, dataloader=None) -> bool:
         """the flow half of EVERY video is identically zero - never shipped, its half of layer1's K never multiplied (exact).  Known
         from what the data IS, not from a config string: the model was told so (cfg['assume_zero_flow']), or the loader's dataset
@@ -93,7 +102,7 @@ class Evaluate(nn.Module):
             # H2D on a side stream: these copies run while whatever was enqueued before is still computing (the loader's
             # pin_memory=True makes them true async DMA); the compute stream waits on one event per sub-batch
             if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(dev)
+                self._copy_stream = self._new_copy_stream(dev)
             cur = torch.cuda.current_stream(dev)
             with torch.cuda.stream(self._copy_stream):
                 rgb = [b[0].to(dev, non_blocking=True) for b in sub]
@@ -125,7 +134,7 @@ class Evaluate(nn.Module):
         dev = torch.device(device)
         eng = model.engine()
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(dev)
+            self._copy_stream = self._new_copy_stream(dev)
         cur = torch.cuda.current_stream(dev)
         lens = [int(b[0].shape[0]) for b in batch]
         any_flow = any(b[1] is not None for b in batch)
