@@ -63,7 +63,7 @@ class Evaluate(nn.Module):
         zeroes the flow stream hands out before collation)"""
         if not (bool(getattr(model, "use_rgb", True)) and bool(self.cfg.get("eval_skip_zero_flow", True))):
             return False
-        return flow.dim() == 2 and flow.shape[0] > 0 and flow.stride(0) == 0 and not bool(flow[0].any())
+        return flow.dim() == 2 and flow.shape[0] > 0 and (flow.stride(0) == 0 or flow.shape[0] == 1) and not bool(flow[0].any())
 
     @staticmethod
     def _features(model, x):

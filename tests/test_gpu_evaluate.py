@@ -69,6 +69,44 @@ def test_evaluate_matches_reference_fixture(tmp_path, dtype, assume_zero):
     print(f"evaluate {dtype}: mAP {mAP:.5f} (ref {g['mAP']:.5f}), argmax mismatches {total_mism} of {sum(g['lens'])}")
 
 
+@pytest.mark.parametrize("dtype,with_flow", [("fp16", False), ("fp16", True), ("fp16x2", False)])
+def test_link_fed_eval_equals_the_copy_then_forward_eval(tmp_path, dtype, with_flow):
+    """Pinned host features (a DataLoader with pin_memory=True) take the link-fed path: the features are copied in pieces in the order the
+    packed pipeline needs them, under ONE forward whose packing stream waits on feed events (prego_miniroad_plan_starts /
+    set_feed_events; a slot schedule costed for a link-bound feed).  A clip's result does not depend on the packing, so the output file and
+    the mAP must equal, entry for entry and bit for bit, those of the copy-everything-then-forward path (cfg eval_link_fed = False)."""
+    from prego_amd.registry import build_model, build_eval
+    import prego_amd.model, prego_amd.evaluate  # noqa: F401
+    vl = os.path.join(tmp_path, "video_list.json")
+    json.dump({"EPIC-TENT-O": {"class_index": [f"c{i}" for i in range(12)]}}, open(vl, "w"))
+    lens = [5000, 1, 2500, 777, 3100, 64, 1025, 4000, 19, 2048, 300, 1500]           # ragged, incl. one-frame and piece-edge lengths
+    items = []
+    for i, T in enumerate(lens):
+        rgb = torch.from_numpy(W.tsn_features((T, 2048), 21, f"lf.rgb.{i}"))[None].pin_memory()
+        flow = torch.from_numpy(W.tsn_features((T, 2048), 21, f"lf.flow.{i}"))[None].pin_memory() if with_flow else \
+            torch.zeros(1, 1, 2048).expand(1, T, 2048)
+        tgt = torch.zeros(1, T, 12)
+        tgt[0, torch.arange(T), (torch.arange(T) // 41 + i) % 12] = 1
+        items.append((rgb, flow, tgt.pin_memory(), (f"v{i}",), torch.tensor([0]), torch.tensor([T])))
+    res = {}
+    for fed in (True, False):
+        out_dir = tmp_path / f"out_{int(fed)}"
+        cfg = epic_tent_cfg(eval="dummy.pth", video_list_path=vl, compute_dtype=dtype, eval_output_dir=str(out_dir), eval_link_fed=fed)
+        model = build_model(cfg, "cuda:0")
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in W.miniroad_state_dict(cfg, 20, head_gain=8.0).items()})
+        ev = build_eval(cfg)
+        taken = []
+        orig = ev._enqueue_link_fed
+        ev._enqueue_link_fed = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]
+        mAP = ev(model, items, logging.getLogger("t"), "cuda:0")
+        model.check()
+        assert bool(taken) == fed                                     # the path under test really ran (and only when asked for)
+        res[fed] = (mAP, json.load(open(out_dir / "output_miniROAD.json")))
+    assert res[True][1] == res[False][1]
+    assert res[True][0] == res[False][0]
+    assert all(len(res[True][1][f"v{i}"]["pred"]) == T for i, T in enumerate(lens))
+
+
 @pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86)])
 def test_device_average_precision_kernel_vs_sklearn(n, C):
     """prego_perframe_ap (csrc/metrics.hip: segmented radix sort + scan per class) against sklearn's average_precision_score and the
