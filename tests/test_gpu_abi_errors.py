@@ -110,3 +110,53 @@ def test_loss_and_optimizer_entry_points_validate_arguments():
     assert lib.prego_oad_loss(1, lens, p_lg, p_tg, 86, loss.data_ptr(), None, C.c_float(1.0), None) == 0
     torch.cuda.synchronize()
     assert np.isfinite(float(loss))
+
+
+def test_split_operand_handle_and_feed_event_misuse():
+    """PREGO_F16X2 (ABI 4) is an inference mode: KEEP (training forward), backward, the fused AdamW step and the streaming fast path refuse
+    such a handle with a message; feed events (link-fed inference) refuse h0 / h_last calls and events that do not cover the call; and a
+    plain forward on the same handle still works afterwards, raw through the C ABI."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    din, emb, hid, ncls = 4096, 2048, 1024, 86
+    assert lib.prego_miniroad_create(C.byref(h), 2048, 2048, emb, hid, ncls, _lib.PREGO_F16X2) == 0
+    try:
+        w = _weights(din, emb, hid, ncls)
+        assert lib.prego_miniroad_set_weights(h, *[t.data_ptr() for t in w], None) == 0
+        T = 33
+        rgb = torch.rand((T, 2048), device="cuda")
+        out = torch.full((T, ncls), float("nan"), device="cuda")
+        arg = torch.full((T,), -1, dtype=torch.int32, device="cuda")
+        hs = torch.zeros((1, hid), device="cuda")
+        lens = (C.c_int32 * 1)(T)
+        p_rgb, p_out, p_arg = (C.c_void_p * 1)(rgb.data_ptr()), (C.c_void_p * 1)(out.data_ptr()), (C.c_void_p * 1)(arg.data_ptr())
+        need = lib.prego_miniroad_workspace_bytes(h, 1, lens, 128, 0)
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+
+        def fwd(flags=1, h_last=None):
+            return lib.prego_miniroad_forward(h, 1, lens, p_rgb, None, p_out, p_arg, None, h_last, flags, ws.data_ptr(), need, None)
+        assert fwd(flags=1 | _lib.FWD_KEEP) == EINVAL and "fp16x2" in _err(lib, h)
+        assert fwd(flags=1 | _lib.FWD_IN16) == EINVAL
+        assert lib.prego_miniroad_step(h, 1, rgb.data_ptr(), None, hs.data_ptr(), out.data_ptr(), arg.data_ptr(), 1, None) == EINVAL
+        # link-fed calls: the schedule query validates its arguments, events must be non-NULL / ascending, and a call with h_last refuses them
+        st = (C.c_int32 * 1)()
+        ns = C.c_int32(0)
+        assert lib.prego_miniroad_plan_starts(h, 0, lens, 4096, st, C.byref(ns)) == EINVAL
+        assert lib.prego_miniroad_plan_starts(h, 1, lens, 4096, st, C.byref(ns)) == 0 and st[0] == 0 and ns.value == T
+        ev = torch.cuda.Event()
+        ev.record()
+        up = (C.c_int32 * 1)(2 ** 31 - 1)
+        assert lib.prego_miniroad_set_feed_events(h, 1, up, (C.c_void_p * 1)(None), 4096) == EINVAL
+        assert lib.prego_miniroad_set_feed_events(h, 1, up, (C.c_void_p * 1)(ev.cuda_event), 0) == EINVAL
+        assert lib.prego_miniroad_set_feed_events(h, 1, up, (C.c_void_p * 1)(ev.cuda_event), 4096) == 0
+        assert fwd(h_last=hs.data_ptr()) == EINVAL and "feed" in _err(lib, h)
+        # events that stop short of the call's last step: the call says so (and the events are dropped: the next call is a plain one)
+        short = (C.c_int32 * 1)(5)
+        assert lib.prego_miniroad_set_feed_events(h, 1, short, (C.c_void_p * 1)(ev.cuda_event), 4096) == 0
+        assert fwd() == EINVAL and "feed events cover" in _err(lib, h)
+        assert fwd() == 0 and lib.prego_miniroad_check(h, None) == 0
+        o = out.cpu().numpy()
+        assert np.isfinite(o).all() and np.allclose(o.sum(1), 1.0, atol=1e-4)
+        assert np.array_equal(arg.cpu().numpy(), o.argmax(1))
+    finally:
+        lib.prego_miniroad_destroy(h)
