@@ -63,7 +63,10 @@ class MiniRoadEngine:
         self.h = h
         self.max_clips = self.lib.prego_miniroad_max_clips(self.h)
         self._ws: Optional[torch.Tensor] = None
-        self.rows_per_chunk = 49152      # packed rows per chunk: 192 M tiles = whole rounds of 256x256 tiles on 256 CUs for N = 2048 (6) and 3072 (9);
+        # fp16x2 rows are 34 KB (fp32 intermediates, split operands): 32 768 rows measured best there (262.6 against 269.4 ms per pass
+        # at 49 152; scripts/probes/chunk_sweep3.sh); the 16-bit modes are flat between 32 768 and 49 152 (120.2 / 120.4 ms)
+        self.rows_per_chunk = 32768 if compute_dtype == "fp16x2" else 49152
+        #                                  packed rows per chunk: 192 M tiles = whole rounds of 256x256 tiles on 256 CUs for N = 2048 (6) and 3072 (9);
                                          # X + GI of a chunk (1 GB) stay close to the 256 MB Infinity Cache (sweep 32 k..256 k rows: 137..142 ms)
         self._weights_version = None
 
