@@ -31,7 +31,7 @@ extern "C" {
  * 3: round 3 (fp16 operand mode, device AP, window_vote marks windows with an id outside [0, n_classes) as -1).
  * 4: round 4 (PREGO_F16X2 split-operand mode; the prego_debug_* / _debug_stamps entry points left this header and the product library:
  *    prego_amd_debug.h / libprego_amd_debug.so). */
-#define PREGO_ABI_VERSION 4
+#define PREGO_ABI_VERSION 5
 
 enum {
   PREGO_OK = 0,
@@ -146,6 +146,11 @@ int prego_miniroad_timing_enable(prego_miniroad* h, int enable);
 int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flop,
                                double* gru_ms, int64_t* gru_launches, double* pack_ms, int64_t* pack_launches,
                                double* pack_bytes);
+/* What the last prego_miniroad_forward() of this handle ran (any pointer may be NULL): *mode = 0: the chunked pass (a chain of launches
+ * per chunk); R > 0: the split pass - the recurrence of the whole call as ONE launch on R XCDs (16 R slots) beside ONE feed-forward
+ * launch on the other XCDs (plain inference calls of 16-bit handles with >= 16 R clips and >= 262 144 frames, once an earlier
+ * call has verified the workgroup placement; PREGO_SPLIT_PASS=R selects it).  *n_steps sequential recurrence steps, *n_slots slots. */
+int prego_miniroad_pass_info(const prego_miniroad* h, int32_t* mode, int32_t* n_steps, int32_t* n_slots);
 
 /* ---- training: trainer/train.py:6-29 (fwd, loss, backward); criterions/loss.py:15-34 -------------------------- */
 
@@ -326,6 +331,7 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
  *   PREGO_GRU_NO_MT, PREGO_GRU_MT_SPEC, PREGO_GRU_NO_LOCAL, PREGO_GRU_STAMPS, PREGO_NO_ARM_FUSE   recurrence kernel choice / hand-off
  *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY, PREGO_SIDE_PRIO    where / on what stream the next chunk's pack runs
  *   PREGO_PLAN_SLOTS, PREGO_FP32_INTERMEDIATES                                             planner calibration, fp32 Y / GI in 16-bit modes
+ *   PREGO_SPLIT_PASS, PREGO_SPLIT_LAG1/2/3                                                 split pass: recurrence XCDs (0 = chunked pass), job lags
  *   PREGO_GEMM_NO_PINGPONG, PREGO_GEMM_NO_BIG, PREGO_HEAD_V1, PREGO_BPTT_STEPWISE, PREGO_STEP_NO_LN_FUSE, PREGO_VIT_TOKENS_KERNEL,
  *   PREGO_ATTN_NW                                                                          older kernels kept as A/B references
  * The probe / unit-test entry points (prego_debug_*, prego_miniroad_debug_stamps) are NOT part of this library: they are declared in

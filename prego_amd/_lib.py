@@ -34,7 +34,7 @@ SYMBOLS = [
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward",
     "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events", "prego_miniroad_backward_callback",
-    "prego_miniroad_plan_starts", "prego_miniroad_set_feed_events",
+    "prego_miniroad_plan_starts", "prego_miniroad_set_feed_events", "prego_miniroad_pass_info",
     "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
 ]
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
@@ -88,6 +88,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_miniroad_backward_callback.argtypes = [vp, vp, vp]
     lib.prego_miniroad_plan_starts.argtypes = [vp, i32, C.POINTER(C.c_int32), i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.prego_miniroad_set_feed_events.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp), i32]
+    lib.prego_miniroad_pass_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.prego_window_vote.argtypes = [vp, i64, i32, i32, vp, vp]
     lib.prego_perframe_ap_workspace_bytes.argtypes = [i64, i32]
     lib.prego_perframe_ap_workspace_bytes.restype = sz

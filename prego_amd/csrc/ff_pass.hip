@@ -1,0 +1,369 @@
+// The feed-forward half of a SPLIT PASS: pack -> layer1 GEMM -> LayerNorm + ReLU -> W_ih GEMM
+// (model/rnn/rnn.py:38-43,53-61) as ONE persistent kernel that lives on the XCDs the recurrence does not hold, for the whole pass.
+//
+// Why one kernel.  A kernel's workgroups are dealt to all eight XCDs and the launch completes only when every one of them has run;
+// the recurrence holds every CU of its XCDs with 312 registers per lane, and the 256 x 256 ping-pong GEMM (2 x 224 registers per
+// SIMD) cannot even be dispatched beside it.  So feed-forward work can only run BESIDE a resident recurrence (instead of between
+// its launches) if it never needs a workgroup on the recurrence's XCDs: a persistent launch whose workgroups read HW_REG_XCC_ID,
+// leave at once below `xcd_lo`, and otherwise pull jobs from their XCD's queue until the pass is over.  The recurrence is the other
+// persistent launch (gru_recurrence.hip, PASS instantiation) on XCDs 0 .. xcd_lo - 1; the two meet in memory:
+//     gi_cnt[c]   += 1 per completed 256-row UNIT of chunk c        (this kernel -> recurrence: "the input projection of chunk c is there")
+//     rec_cnt[c]  += 1 per recurrence wave that has consumed chunk c (recurrence -> this kernel: "the GI ring slot of chunk c is free")
+//
+// Units and rings.  The packed rows of a pass are cut into units of 256 rows (one GEMM tile row); unit u belongs to feed-forward
+// XCD u mod nf for ALL of its jobs, so X, Y and E of a unit are produced and consumed through ONE XCD's L2 (which is coherent for
+// its own CUs: plain stores, then `s_waitcnt vmcnt(0)` + a counter; the consumer invalidates its CU's vector L1 with `buffer_inv
+// sc0` behind the counter and loads normally).  Only GI crosses to other XCDs: its stores are write-through (sc1), the recurrence
+// reads it with sc1 loads.  X / Y / E live in rings of `ring_units` units (a multiple of nf: a slot is only ever touched by one XCD,
+// so no XCD can write back a stale dirty line over another's data), GI in a ring of `gi_ring_units` (a power of two).
+//
+// Jobs of a unit: PACK (1), L1 tile (nt1 = E / 256), LN (1), WIH tile (nt2 = 3H / 256).  An XCD's queue is a ticket counter; ticket k is
+// job k mod (2 + nt1 + nt2) of ROUND k div (..): round i holds PACK of the XCD's unit i, the L1 tiles of unit i - lag1, LN of unit
+// i - lag2 and the WIH tiles of unit i - lag3, so that by the time a job is claimed its producers (claimed `lag` rounds = tens of
+// microseconds earlier) have normally finished: the dependency waits below are a safety net, not a pipeline stage.  Tickets are
+// claimed in order by resident workgroups that run every job to completion, so a wait can only be for a job that is already running.
+// Every wait is bounded (2 s of s_memrealtime): a timeout raises the abort word that ends both kernels (no hung GPU).
+//
+// Arithmetic: the tile loop is the ping-pong K loop of gemm_pp.hip (same fragment order, same MFMA order), the row jobs are the
+// bodies of pack_rows_kernel / ln_relu_rows_kernel (rowwise.hip) on a wave per row: every GI element is bit-identical to the
+// chunked pass.
+#include "common.h"
+#include "kernels.h"
+
+#define FBK 64
+#define FHALF 16384
+#define FBUF 65536
+#define FF_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define FF_TIMEOUT_TICKS 200000000ull          // s_memrealtime runs at 100 MHz: 2 s
+
+__device__ __forceinline__ int ffp_key_b(int r) { return ((r >> 1) & 1) | (((r >> 3) & 3) << 1); }
+
+// tid 0 only: wait until *p >= need.  false = aborted (by this wait's timeout or by someone else)
+__device__ __forceinline__ bool ffp_wait_ge(const unsigned* p, unsigned need, unsigned* abort_word, unsigned code) {
+  if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned spins = 0;
+  for (;;) {
+    __builtin_amdgcn_s_sleep(8);
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return true;
+    if ((++spins & 31u) == 0u) {
+      if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      if (__builtin_amdgcn_s_memrealtime() - t0 > FF_TIMEOUT_TICKS) {
+        __hip_atomic_store(abort_word, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+// One 256 x 256 output tile: C[rows <= 256, 256] (16-bit) = A[rows, K] . B[256, K]^T + bias, the 8-phase ping-pong loop of gemm_pp.hip
+// (see there for the schedule).  A, B, bias, C point at the tile's first row / column.  SC1OUT: the stores are write-through (the tile
+// is read on another XCD).
+template <typename OT, bool SC1OUT>
+__device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ A, int lda, int rows, const bf16_t* __restrict__ B, int ldb,
+                                         const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc, int K) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int nk = K / FBK;
+  const int sr = lane >> 3, scp = lane & 7;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wave * 2 + i) * 8 + sr;
+    a_off[i] = r * lda * 2 + ((scp ^ ((r >> 1) & 7)) << 4);
+    b_off[i] = r * ldb * 2 + ((scp ^ ffp_key_b(r)) << 4);
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, rows * lda * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 256 * ldb * 2, 0x00020000);
+  auto stage_a = [&](int hf, int kt) {
+    char* dst = smem + (kt & 1) * FBUF + hf * FHALF + wave * 2048;
+    const int so = hf * 128 * lda * 2 + kt * (FBK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, a_off[i], so, 0, 0);
+  };
+  auto stage_b = [&](int hf, int kt) {
+    char* dst = smem + (kt & 1) * FBUF + (2 + hf) * FHALF + wave * 2048;
+    const int so = hf * 128 * ldb * 2 + kt * (FBK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, b_off[i], so, 0, 0);
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  bf16x8 a0[2][4], a1[2][4], b0[2][2], b1[2][2];
+  auto read_a = [&](bf16x8 (&af)[2][4], int slot, int kt) {
+    const char* base = smem + (kt & 1) * FBUF + slot * FHALF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = grp * 64 + i * 16 + fr;
+        af[ks][i] = *(const bf16x8*)(base + r * 128 + (((ks * 4 + fq) ^ ((r >> 1) & 7)) << 4));
+      }
+  };
+  auto read_b = [&](bf16x8 (&bf)[2][2], int slot, int kt) {
+    const char* base = smem + (kt & 1) * FBUF + slot * FHALF;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = wc * 32 + (fr >> 2) * 8 + j * 4 + (fr & 3);
+        bf[ks][j] = *(const bf16x8*)(base + r * 128 + (((ks * 4 + fq) ^ ffp_key_b(r)) << 4));
+      }
+  };
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[x][y][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](f32x4 (&c)[4][2], const bf16x8 (&af)[2][4], const bf16x8 (&bf)[2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[i][j] = op16<OT>::mfma(bf[ks][j], af[ks][i], c[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  stage_a(0, 0); stage_b(0, 0); stage_b(1, 0); stage_a(1, 0);
+  stage_a(0, 1); stage_b(0, 1); stage_b(1, 1);
+  FF_WAIT(10);
+  bar();
+  read_a(a0, 0, 0);
+  if (grp == 1) bar();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool full = kt + 2 < nk;
+    read_b(b0, 2, kt);
+    if (kt + 1 < nk) stage_a(1, kt + 1);
+    if (full) FF_WAIT(10); else FF_WAIT(0);
+    bar();
+    mma(acc[0][0], a0, b0);
+    bar();
+    read_b(b1, 3, kt);
+    if (full) { stage_a(0, kt + 2); FF_WAIT(10); } else FF_WAIT(0);
+    bar();
+    mma(acc[0][1], a0, b1);
+    bar();
+    read_a(a1, 1, kt);
+    if (full) { stage_b(0, kt + 2); FF_WAIT(10); } else FF_WAIT(0);
+    bar();
+    mma(acc[1][1], a1, b1);
+    bar();
+    if (kt + 1 < nk) read_a(a0, 0, kt + 1);
+    if (full) { stage_b(1, kt + 2); FF_WAIT(10); } else FF_WAIT(0);
+    bar();
+    mma(acc[1][0], a1, b0);
+    bar();
+  }
+  if (grp == 0) bar();
+  float4 bv[2][2];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bv[y][j] = *(const float4*)(bias + y * 128 + wc * 32 + fq * 8 + j * 4);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)C, 0, rows * ldc * 2, 0x00020000);
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int n = y * 128 + wc * 32 + fq * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = x * 128 + grp * 64 + i * 16 + fr;
+        const f32x4 v0 = acc[x][y][i][0], v1 = acc[x][y][i][1];
+        u32x4 pk;
+        pk[0] = op16<OT>::pack2_sat(v0[0] + bv[y][0].x, v0[1] + bv[y][0].y); pk[1] = op16<OT>::pack2_sat(v0[2] + bv[y][0].z, v0[3] + bv[y][0].w);
+        pk[2] = op16<OT>::pack2_sat(v1[0] + bv[y][1].x, v1[1] + bv[y][1].y); pk[3] = op16<OT>::pack2_sat(v1[2] + bv[y][1].z, v1[3] + bv[y][1].w);
+        // rows past `rows` fall outside the resource's num_records: the store is dropped
+        if constexpr (SC1OUT) __builtin_amdgcn_raw_buffer_store_b128(pk, rs_c, (m * ldc + n) * 2, 0, AUX_SC1);
+        else __builtin_amdgcn_raw_buffer_store_b128(pk, rs_c, (m * ldc + n) * 2, 0, 0);
+      }
+    }
+}
+
+// rows [row0, row0 + nrows) of the packed feature matrix, a wave per row (pack_rows_kernel's element arithmetic)
+template <typename OT>
+__device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int din = a.kx;
+  for (int r = wave; r < nrows; r += 8) {
+    const int row = row0 + r;
+    int clip, t;
+    plan_clip_of_row(a.plan, row, clip, t);
+    if (a.rowmap != nullptr && lane == 0) ((int2*)a.rowmap)[row] = make_int2(clip, t);
+    const float* rgb = a.rgb_ptrs ? a.rgb_ptrs[clip] : nullptr;
+    const float* flow = a.flow_ptrs ? a.flow_ptrs[clip] : nullptr;
+    bf16_t* dst = Xs + (size_t)r * din;
+    if (a.in16) {
+      const bf16_t* rgb16 = (const bf16_t*)rgb;
+      const bf16_t* flow16 = (const bf16_t*)flow;
+      for (int c = lane * 8; c < din; c += 512) {
+        const bf16_t* src = (c < a.d_rgb) ? (rgb16 ? rgb16 + (size_t)t * a.d_rgb + c : nullptr)
+                                          : (flow16 ? flow16 + (size_t)t * a.d_flow + (c - a.d_rgb) : nullptr);
+        const u32x4 v = src ? __builtin_nontemporal_load((const u32x4*)src) : (u32x4){0u, 0u, 0u, 0u};
+        *(u32x4*)(dst + c) = v;
+      }
+    } else {
+      for (int c = lane * 8; c < din; c += 512) {
+        const float* src = (c < a.d_rgb) ? (rgb ? rgb + (size_t)t * a.d_rgb + c : nullptr)
+                                         : (flow ? flow + (size_t)t * a.d_flow + (c - a.d_rgb) : nullptr);
+        float4 x = make_float4(0, 0, 0, 0), y = x;
+        if (src) { x = nt_load4(src); y = nt_load4(src + 4); }
+        uint4 o;
+        o.x = op16<OT>::pack2_sat(x.x, x.y); o.y = op16<OT>::pack2_sat(x.z, x.w);
+        o.z = op16<OT>::pack2_sat(y.x, y.y); o.w = op16<OT>::pack2_sat(y.z, y.w);
+        *(uint4*)(dst + c) = o;
+      }
+    }
+  }
+}
+
+// LayerNorm + ReLU of nrows 16-bit rows, a wave per row (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order)
+template <typename OT>
+__device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
+  constexpr int MAXV = 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int E = a.E, nv = E / 512;
+  for (int r = wave; r < nrows; r += 8) {
+    const bf16_t* y = Ys + (size_t)r * E;
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const u32x4 w = *(const u32x4*)(y + (i * 64 + lane) * 8);
+        const float4 p = make_float4(op16<OT>::lo(w[0]), op16<OT>::hi(w[0]), op16<OT>::lo(w[1]), op16<OT>::hi(w[1]));
+        const float4 q = make_float4(op16<OT>::lo(w[2]), op16<OT>::hi(w[2]), op16<OT>::lo(w[3]), op16<OT>::hi(w[3]));
+        v[i][0] = p.x; v[i][1] = p.y; v[i][2] = p.z; v[i][3] = p.w; v[i][4] = q.x; v[i][5] = q.y; v[i][6] = q.z; v[i][7] = q.w;
+        s += ((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w));
+      }
+    const float mu = wave_sum(s) / (float)E;
+    float qq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; qq += d * d; }
+      }
+    const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)E + a.ln_eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * 8;
+        const float4 g0 = *(const float4*)(a.ln_g + c), g1 = *(const float4*)(a.ln_g + c + 4);
+        const float4 b0 = *(const float4*)(a.ln_b + c), b1 = *(const float4*)(a.ln_b + c + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf((v[i][k] - mu) * rstd * gg[k] + bb[k], 0.f);
+        uint4 w;
+        w.x = op16<OT>::pack2_sat(o[0], o[1]); w.y = op16<OT>::pack2_sat(o[2], o[3]); w.z = op16<OT>::pack2_sat(o[4], o[5]); w.w = op16<OT>::pack2_sat(o[6], o[7]);
+        *(uint4*)(Es + (size_t)r * E + c) = w;
+      }
+  }
+}
+
+template <typename OT>
+__global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_job[2];
+  const int tid = threadIdx.x;
+  const int xcc = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);           // HW_REG_XCC_ID
+  if (xcc < a.xcd_lo) return;                                                // the recurrence's XCDs
+  const int q = xcc - a.xcd_lo, nf = 8 - a.xcd_lo;
+  const int n_q = a.n_units > q ? (a.n_units - q + nf - 1) / nf : 0;         // units of this XCD: q, q + nf, ...
+  const int jpr = 2 + a.nt1 + a.nt2;
+  const int n_rounds = n_q + a.lag3;
+  for (;;) {
+    __syncthreads();                                                         // s_job of the previous iteration has been read
+    if (tid == 0) s_job[0] = (int)__hip_atomic_fetch_add(a.tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int k = __builtin_amdgcn_readfirstlane(s_job[0]);                  // wave-uniform: everything derived from it stays in SGPRs
+    const int round = k / jpr, j = k - round * jpr;
+    if (round >= n_rounds) break;
+    int type, i, nb = 0;
+    if (j == 0) { type = 0; i = round; }
+    else if (j <= a.nt1) { type = 1; i = round - a.lag1; nb = j - 1; }
+    else if (j == a.nt1 + 1) { type = 2; i = round - a.lag2; }
+    else { type = 3; i = round - a.lag3; nb = j - a.nt1 - 2; }
+    if (i < 0 || i >= n_q) continue;
+    const int u = q + i * nf;
+    if (tid == 0) {
+      bool ok = true;
+      const int up = u - a.ring_units;                                       // the unit that held this unit's ring slot before
+      if (type == 0) {
+        if (up >= 0) ok = ffp_wait_ge(a.l1_cnt + up, (unsigned)a.nt1, a.abort_word, 0x100u);
+      } else if (type == 1) {
+        ok = ffp_wait_ge(a.pack_done + u, 1u, a.abort_word, 0x101u);
+        if (ok && up >= 0) ok = ffp_wait_ge(a.ln_done + up, 1u, a.abort_word, 0x102u);
+      } else if (type == 2) {
+        ok = ffp_wait_ge(a.l1_cnt + u, (unsigned)a.nt1, a.abort_word, 0x103u);
+        if (ok && up >= 0) ok = ffp_wait_ge(a.wih_cnt + up, (unsigned)a.nt2, a.abort_word, 0x104u);
+      } else {
+        ok = ffp_wait_ge(a.ln_done + u, 1u, a.abort_word, 0x105u);
+        const int ug = u - a.gi_ring_units;                                  // the recurrence must have consumed that unit's chunk
+        if (ok && ug >= 0) ok = ffp_wait_ge(a.rec_cnt + (ug >> a.chunk_unit_shift), (unsigned)a.rec_expect, a.abort_word, 0x106u);
+      }
+      s_job[1] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!__builtin_amdgcn_readfirstlane(s_job[1])) break;
+    asm volatile("buffer_inv sc0" ::: "memory");                            // this CU's vector L1 may hold the slot's previous contents
+    const int row0 = u * 256;
+    const int nrows = a.total_rows - row0 < 256 ? a.total_rows - row0 : 256;
+    const size_t slot = (size_t)(u % a.ring_units) * 256;
+    if (type == 0) {
+      ffp_pack<OT>(a, row0, nrows, a.X + slot * a.kx);
+    } else if (type == 1) {
+      ffp_tile<OT, false>(smem, a.X + slot * a.kx, a.kx, nrows, a.w1 + (size_t)nb * 256 * a.ld_w1, a.ld_w1, a.b1 + nb * 256,
+                          a.Y + slot * a.E + nb * 256, a.E, a.kx);
+    } else if (type == 2) {
+      ffp_ln<OT>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
+    } else {
+      const size_t gslot = (size_t)(u & (a.gi_ring_units - 1)) * 256;
+      ffp_tile<OT, true>(smem, a.Eb + slot * a.E, a.E, nrows, a.w_ih + (size_t)nb * 256 * a.E, a.E, a.bias2 + nb * 256,
+                         a.GI + gslot * a.n3 + nb * 256, a.n3, a.E);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // my stores have reached the L2 (sc1: memory)
+    __syncthreads();
+    if (tid == 0) {
+      if (type == 0) __hip_atomic_store(a.pack_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (type == 1) __hip_atomic_fetch_add(a.l1_cnt + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (type == 2) __hip_atomic_store(a.ln_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else {
+        const unsigned old = __hip_atomic_fetch_add(a.wih_cnt + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)a.nt2)                                     // the unit's input projection is complete
+          __hip_atomic_fetch_add(a.gi_cnt + (u >> a.chunk_unit_shift), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// 0 on success, -1 = shape not supported.  One launch per pass; `grid` workgroups (256: one per CU, an eighth lands on every XCD).
+int launch_ff_pass(const FfPassArgs& a, hipStream_t s) {
+  if (a.E % 512 || a.E > 4096 || a.kx % FBK || a.kx < 2 * FBK || a.n3 % 256 || a.xcd_lo < 1 || a.xcd_lo > 7) return -1;
+  if (a.ring_units % (8 - a.xcd_lo) || (a.gi_ring_units & (a.gi_ring_units - 1)) || a.nt1 != a.E / 256 || a.nt2 != a.n3 / 256) return -1;
+  static DeviceOnce once;
+  once.run([&] {
+    (void)hipFuncSetAttribute((const void*)ff_pass_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FBUF);
+    (void)hipFuncSetAttribute((const void*)ff_pass_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FBUF);
+  });
+  if (a.f16) ff_pass_kernel<f16_t><<<256, 512, 2 * FBUF, s>>>(a);
+  else ff_pass_kernel<bf16_t><<<256, 512, 2 * FBUF, s>>>(a);
+  return 0;
+}

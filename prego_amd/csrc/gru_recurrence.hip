@@ -56,8 +56,12 @@ template <> struct gru_ot<f16_t> { typedef f16_t type; };
 // TRAIN: also store the gate activations / raw state BPTT needs (a.keep_*, a.h_raw_out); the inference instantiation
 // carries none of that code or its registers.
 // GI16: the input projection rows (a.gi) are bf16 (inference path with bf16 intermediates)
-template <typename WT, int HID, int UT, int NCT, bool TRAIN, bool GI16 = false>
+// PASS: the recurrence of a WHOLE pass in one launch on XCDs 0 .. a.Gd - 1 (split pass, ff_pass.hip): gi is a ring indexed by absolute
+// packed row that the feed-forward kernel fills WHILE this launch runs (sc1 loads: the producer is on another XCD), a.gi_cnt[c] says
+// when chunk c is complete, a.rec_cnt[c] tells the producer when its ring slot is free again.  Same step arithmetic.
+template <typename WT, int HID, int UT, int NCT, bool TRAIN, bool GI16 = false, bool PASS = false>
 __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
+  static_assert(!PASS || (GI16 && !TRAIN && NCT == 1 && sizeof(WT) == 2), "pass mode: 16-bit operands and GI, one clip tile, inference");
   constexpr bool BF = (sizeof(WT) == 2);          // 16-bit operands: bf16_t or f16_t (same layout, same tag bit 14: |h| < 2 in both)
   typedef typename gru_ot<WT>::type OT;
   constexpr int UNITS = 16 * UT;              // hidden units owned by this workgroup
@@ -94,6 +98,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const bool compact_ok = a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P && a.Gd > 0 && a.Gd < a.G &&
                             __hip_atomic_load(a.sync + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
     s_place[3] = compact_ok ? 1 : 0;
+    if (PASS && !compact_ok) {                 // a pass launch shares the device with the feed-forward kernel: never full width
+      __hip_atomic_store(a.abort_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      loc = -1;
+    } else
     if (compact_ok) {
       // compacted launch (a.Gd groups; probe of DESIGN 5c): the rendezvous is per XCD - a workgroup on an XCD without a group leaves
       // at once and is not waited for (another kernel may hold those CUs for the whole launch); the others wait for the 32 of
@@ -147,12 +155,42 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   // (XCDs 0 .. Gd - 1 under the verified placement): the other XCDs' workgroups leave at once (overlap probe)
   const int gd = compacted ? a.Gd : a.G;
   if (g >= gd) return;
-  if (g >= a.n_clips) return;                 // group without slots (its most loaded slot is slot g)
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // pass mode: chunks this wave knows complete (`have`) / has reported consumed (`sig`); both wave-uniform
+  int have = 0, sig = 0;
+  auto pass_signal_upto = [&](int c_end) {     // caller: every vector-memory op that touched chunks < c_end has retired
+    if constexpr (PASS) {
+      while (sig < c_end) {
+        if (lane == 0) __hip_atomic_fetch_add(a.rec_cnt + sig, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++sig;
+      }
+    }
+  };
+  if (g >= a.n_clips) { pass_signal_upto(a.n_chunks); return; }                 // group without slots (its most loaded slot is slot g)
   {                                           // group whose slots have all ended before this launch (nact never grows)
     typedef const __attribute__((address_space(4))) int* cint_p0;
-    if (g >= ((cint_p0)a.nact)[a.t0]) return;
+    if (g >= ((cint_p0)a.nact)[a.t0]) { pass_signal_upto(a.n_chunks); return; }
   }
-  const int l15 = lane & 15, l4 = lane >> 4;
+  // every chunk up to the one that holds packed row `last_row` is complete (false: aborted)
+  auto pass_wait_row = [&](int last_row) -> bool {
+    if constexpr (PASS) {
+      const int c_need = last_row >> a.chunk_shift;
+      while (have <= c_need) {
+        const unsigned need = (unsigned)(have == a.n_chunks - 1 ? a.units_last : a.units_per_chunk);
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.gi_cnt + have, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          if (++spins > (1u << 21)) {
+            if (lane == 0) __hip_atomic_store(a.abort_word, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+          }
+          if ((spins & 63u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        ++have;
+      }
+    }
+    return true;
+  };
 
   // ---- resident weights -------------------------------------------------------------------
   bf16x8 wb[BF ? 3 : 1][BF ? UT : 1][BF ? NKS : 1];
@@ -243,10 +281,16 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   };
   // gi loads are UNCONDITIONAL (inactive lanes read row 0 of the step, which always exists, and ignore it): a
   // "load or zero" select makes hipcc branch around every load and wait vmcnt(0) right behind it.
+  __amdgpu_buffer_rsrc_t rs_gi = rs;
+  if constexpr (PASS) rs_gi = __builtin_amdgcn_make_buffer_rsrc((void*)a.gi, 0, (a.gi_row_mask + 1u) * (unsigned)(3 * HID * 2), 0x00020000);
   auto load_gi = [&](float (&dst)[3][OWN_R], int ct, int na, int rbase) {
     const int r = rbase + (sidx[ct] < na ? sidx[ct] : 0);
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
+      if constexpr (PASS) {                    // ring slot of the absolute row; the row was written on another XCD: sc1
+        const unsigned off = ((unsigned)r & a.gi_row_mask) * (unsigned)(3 * HID * 2) + (unsigned)((gate * HID + ucol) * 2);
+        dst[gate][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, (int)off, 0, AUX_SC1));
+      } else
       if constexpr (GI16) {
         const bf16_t* p = (const bf16_t*)a.gi + (size_t)r * (3 * HID) + gate * HID + ucol;
         // RAW bits only: unpacking here would make hipcc wait for the prefetch right behind its issue; the gate phase unpacks
@@ -281,6 +325,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   int na_n = nsteps > 1 ? nact_c[a.t0 + 1] : 0, rb_n = nsteps > 1 ? rowoff_c[a.t0 + 1] : 0;   // step tl+1
   // prologue: h_{t0-1} -> buffer 1 with the tag of step "-1" (= 1); gi of the first step
   float giA[NCT][3][OWN_R], giB[NCT][3][OWN_R];                         // ping-pong: no register copies
+  if constexpr (PASS) { if (!pass_wait_row(rowoff_c[a.t0 + 1] - 1)) return; }      // the first step's rows
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
     if (tfirst[ct] < na_c) { publish(ct, 1, 1u, false); load_gi(giA[ct], ct, na_c, rb_c - a.row_base); }
@@ -294,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const bool more = tl + 1 < nsteps;
     const int t2 = (tl + 2 < nsteps) ? t + 2 : t;                       // look-ahead index (clamped)
     const int na_2 = nact_c[t2], rb_2 = rowoff_c[t2];
+    const int re_n = PASS ? rowoff_c[more ? t + 2 : t + 1] : 0;         // pass mode: end of step t + 1's rows
     const int rbuf = (tl + 1) & 1;
     const unsigned etag = (unsigned)(((tl - 1) >> 1) & 1);              // tag of the step that produced h_{t-1}
     const unsigned eword = etag ? TAGM : 0u;
@@ -398,6 +444,13 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
           for (int e = 0; e < OWN_R; ++e) asm volatile("" : "+v"(gir[ct][gate][e]));
+        if constexpr (PASS) {
+          // rows below rowoff[t] belong to finished steps and nothing of them is in flight (the vmcnt(0) above): report their chunks;
+          // then make sure the chunk(s) of step t + 1's rows are complete before the prefetch below reads them
+          const int c_done = rb_c >> a.chunk_shift;
+          if (sig < c_done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pass_signal_upto(c_done); }
+          if (more) { if (!pass_wait_row(re_n - 1)) return false; }
+        }
         if (more && tfirst[ct] < na_n) load_gi(gin[ct], ct, na_n, rb_n - a.row_base);
 
         // ---- (2) cross-wave (K-quarter) reduction through LDS, double buffered: one barrier per tile
@@ -537,6 +590,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     a.stamps[6] += (unsigned long long)nsteps;
   }
 #undef STAMP
+  if constexpr (PASS) {                       // this group is done with every remaining chunk
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pass_signal_upto(a.n_chunks);
+  }
 
   // final state back to h_state (streaming / next chunk)
 #pragma unroll
@@ -965,6 +1022,23 @@ __global__ void gru_arm_kernel(unsigned* __restrict__ hx, size_t words_per_buf, 
 
 GruArm gru_arm_desc(bool bf16, int hid, int G, void* hx, unsigned* sync) {
   return GruArm{(unsigned*)hx, (unsigned long long)(gru_hx_bytes(bf16, hid, G) / 2 / 4), bf16 ? 0x40004000u : 0x40000000u, sync};
+}
+
+// The recurrence of a whole split pass: XCDs 0 .. a.Gd - 1 (needs the verified placement of an earlier full-width launch: rendezvous
+// word 20), one clip tile per group, GI ring + chunk counters of GruArgs' pass fields.  -1: unsupported.
+// The exchange buffers / rendezvous words must have been armed by launch_gru_arm EARLIER in the stream, before the feed-forward launch of
+// the pass is released: an ordinary kernel queued between the two persistent launches would need workgroups on CUs the feed-forward
+// kernel fills completely (2 x 256 registers per SIMD) and would hold the recurrence up until the feed-forward has finished - which
+// waits for the recurrence.
+void launch_gru_arm(bool bf16, int hid, int G, void* hx, unsigned* sync, hipStream_t s) {
+  gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)hx, gru_hx_bytes(bf16, hid, G) / 2 / 4, bf16 ? 0x40004000u : 0x40000000u, sync);
+}
+int launch_gru_recurrence_pass(int hid, GruArgs a, hipStream_t s) {
+  if (hid != 1024 || a.G != 8 || a.Gd < 1 || a.Gd >= 8 || !a.gi_bf16 || !a.gi_cnt || !a.rec_cnt || a.sync == nullptr) return -1;
+  const size_t lds = (size_t)2 * 4 * 3 * 2 * 64 * 16;
+  if (a.f16) gru_recurrence_kernel<f16_t, 1024, 2, 1, false, true, true><<<256, 256, lds, s>>>(a);
+  else gru_recurrence_kernel<bf16_t, 1024, 2, 1, false, true, true><<<256, 256, lds, s>>>(a);
+  return 0;
 }
 
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s) {

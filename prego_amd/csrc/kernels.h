@@ -56,7 +56,48 @@ struct GruArgs {
   int rows;                    // packed rows this launch covers (rowoff[t1] - row_base); 0 = unknown
   int armed;                   // 1: hx / sync were re-armed by an earlier kernel of this stream (launch_ln_relu with a GruArm): no arm launch
   int no_mt;                   // 1: never the software-pipelined multi-tile kernel (handle created under PREGO_GRU_NO_MT=1: A/B and the bit-identity test)
+  // split pass (PASS instantiation, launch_gru_recurrence_pass): gi is a ring of (gi_row_mask + 1) rows indexed by absolute packed row,
+  // filled by ff_pass.hip while this launch runs; h_relu_out is indexed by absolute packed row
+  const unsigned* gi_cnt;      // [n_chunks] completed 256-row units of chunk c (chunk = rows >> chunk_shift)
+  unsigned* rec_cnt;           // [n_chunks] += 1 per wave that has consumed the chunk
+  int chunk_shift, n_chunks;
+  int units_per_chunk, units_last;   // what gi_cnt[c] must reach (last chunk: units_last)
+  unsigned gi_row_mask;
 };
+// ---- split pass (ff_pass.hip + the PASS instantiation of gru_recurrence.hip): the feed-forward of a whole pass as one persistent
+// kernel on XCDs xcd_lo .. 7 beside one persistent recurrence launch on XCDs 0 .. xcd_lo - 1
+struct FfPassArgs {
+  const float* const* rgb_ptrs; const float* const* flow_ptrs;   // per-clip feature arrays (device pointer tables), flow nullable
+  SlotPlan plan;
+  void* rowmap;                 // int2 [total_rows]: (clip, frame) of every packed row (written by the PACK jobs, read by the head); nullable
+  int d_rgb, d_flow;            // d_flow = 0: no flow half
+  int in16;                     // feature arrays hold the 16-bit operand type already
+  int kx;                       // K of layer1 = d_rgb + d_flow
+  const unsigned short* w1; int ld_w1; const float* b1;          // [E][ld_w1]
+  const float* ln_g; const float* ln_b; float ln_eps;
+  const unsigned short* w_ih; const float* bias2;                // [3H][E]
+  int E, n3;                    // embedding width, 3 H
+  unsigned short* X; unsigned short* Y; unsigned short* Eb;      // rings of ring_units x 256 rows
+  unsigned short* GI;           // ring of gi_ring_units x 256 rows x n3
+  int ring_units, gi_ring_units;
+  int total_rows, n_units;      // n_units = ceil(total_rows / 256)
+  int xcd_lo;                   // XCDs below belong to the recurrence
+  int chunk_unit_shift;         // log2(units per chunk): chunk of unit u = u >> shift
+  int rec_expect;               // recurrence waves that signal a chunk (groups x P x 4)
+  int nt1, nt2;                 // tiles per unit of the two GEMMs (E / 256, 3H / 256)
+  int lag1, lag2, lag3;         // rounds between PACK and L1 / LN / WIH of a unit in an XCD's ticket order
+  int f16;
+  unsigned* tick;               // [8] per-XCD job tickets
+  unsigned* pack_done; unsigned* l1_cnt; unsigned* ln_done; unsigned* wih_cnt;   // [n_units]
+  unsigned* gi_cnt;             // [n_chunks] completed units per chunk (read by the recurrence)
+  const unsigned* rec_cnt;      // [n_chunks] recurrence waves done with the chunk
+  unsigned* abort_word;
+};
+int launch_ff_pass(const FfPassArgs& a, hipStream_t s);
+// the recurrence of a whole pass as one launch on XCDs 0 .. a.Gd - 1 (GruArgs pass fields); 16-bit operands, 16-bit GI ring, one tile
+int launch_gru_recurrence_pass(int hid, GruArgs a, hipStream_t s);
+void launch_gru_arm(bool bf16, int hid, int G, void* hx, unsigned* sync, hipStream_t s);   // must precede it in the stream (see there)
+
 // what a recurrence launch needs re-armed before it starts (gru_recurrence.hip: buffer 0 := tag 1 everywhere, buffer 1 := 0,
 // sync[0..15] := 0).  A LayerNorm launch that runs between two recurrence launches of a stream can do it on the side (one launch
 // and one launch gap fewer per chunk)

@@ -128,6 +128,12 @@ struct prego_miniroad {
   // worker competed for the same CUs).  -1 = not read yet: copied out behind the first full-width launch, read when that copy is done
   int placement = -1; unsigned* pin_place = nullptr; hipEvent_t ev_place = nullptr; bool place_pending = false;
   int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
+  // split pass: recurrence on XCDs 0 .. split_r - 1 and the feed-forward of the whole pass on the others, two persistent
+  // launches.  split_buf: handle-owned [relu(h) rows of the pass | row map | counters], grown outside the steady state
+  int split_r = 0; int plan_force_slots = 0;
+  char* split_buf = nullptr; size_t split_bytes = 0;
+  hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
+  double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
   // timing
   bool timing = false;
@@ -253,6 +259,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_place) (void)hipEventDestroy(h->ev_place);
   if (h->pin_place) (void)hipHostFree(h->pin_place);
+  if (h->split_buf) (void)hipFree(h->split_buf);
   delete h;
 }
 
@@ -310,9 +317,9 @@ static const double kStepCostF32[5] = {0.0, 6.89, 9.25, 11.6, 14.0};
 // a step can then be bound by the link - live slots x row bytes at ~50 GB/s - instead of by the recurrence, and the slot count that
 // minimises the pass is the one that keeps the link evenly busy for the whole run (about frames / longest clip slots: every slot
 // alive to the end), not the one that minimises the number of steps.
-static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single, int host_row_bytes = 0) {
+static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_single, int host_row_bytes = 0, int slots_arg = 0) {
   if ((int)h->plan_lens.size() == n && std::equal(lens, lens + n, h->plan_lens.begin()) && h->plan_want_single == want_single &&
-      h->plan_host_row_bytes == host_row_bytes)
+      h->plan_host_row_bytes == host_row_bytes && h->plan_force_slots == slots_arg)
     return PREGO_OK;
   long long total = 0;
   int lmax = 0;
@@ -373,7 +380,8 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   };
   Cand best;
   static const int force_slots = getenv("PREGO_PLAN_SLOTS") ? atoi(getenv("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
-  if (want_single || (n <= per_layer && host_row_bytes <= 0)) best = pack(n);
+  if (slots_arg > 0) best = pack(std::min(n, slots_arg));                 // split pass: one tile on each of its groups
+  else if (want_single || (n <= per_layer && host_row_bytes <= 0)) best = pack(n);
   else if (force_slots > 0) best = pack(std::min(n, std::min(force_slots, max_slots)));
   else {
     best = pack(std::min(n, per_layer));
@@ -426,6 +434,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   h->plan_single = single;
   h->plan_want_single = want_single;
   h->plan_host_row_bytes = host_row_bytes;
+  h->plan_force_slots = slots_arg;
   h->plan_lens.assign(lens, lens + n);
   return PREGO_OK;
 }
@@ -583,6 +592,130 @@ static EventPair* ev_begin(prego_miniroad* h, int kind, hipStream_t s) {
 }
 static void ev_end(EventPair* p, hipStream_t s) { if (p) (void)hipEventRecord(p->b, s); }
 
+// the side stream was created with the LEAST priority so that it never shares a hardware queue with a normal-priority caller (create);
+// a caller's stream of that same priority might: two persistent launches that wait for each other must not be queued one behind the other
+static bool side_queue_differs(const prego_miniroad* h, hipStream_t s) {
+  int ps = 0, pside = 0;
+  if (hipStreamGetPriority(s, &ps) != hipSuccess || hipStreamGetPriority(h->side, &pside) != hipSuccess) return false;
+  return ps != pside;
+}
+static void refresh_placement(prego_miniroad* h) {
+  if (h->placement < 0 && h->place_pending && hipEventQuery(h->ev_place) == hipSuccess) {
+    const int v = (int)*h->pin_place;             // 1: group := XCD verified; 2: another placement; 0: that launch did not run the
+    h->placement = v == 0 ? -1 : v;               // full-width rendezvous (multi-tile kernel): look again behind a later launch
+    h->place_pending = false;
+  }
+}
+
+// ---- split pass ----------------------------------------------------------------------------------------------------------------
+// Geometry: units of 256 packed rows; chunks of 64 units (16 384 rows) are what the two kernels tell each other about; X / Y / E rings
+// of 8 units per feed-forward XCD, a GI ring of 4 chunks.  The rings come out of the caller's workspace (they fit the default one),
+// relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer (the head runs behind the pass).
+static const int kSplitChunkUnitShift = 6, kSplitGiRingUnits = 256, kSplitRingPerXcd = 8;
+struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
+static SplitRings split_rings(const prego_miniroad* h, int R) {
+  SplitRings g;
+  g.ring_units = kSplitRingPerXcd * (8 - R);
+  g.x = align_up((size_t)g.ring_units * 256 * (size_t)(h->d_rgb + h->d_flow) * 2, 256);
+  g.y = align_up((size_t)g.ring_units * 256 * (size_t)h->emb * 2, 256);
+  g.e = g.y;
+  g.gi = align_up((size_t)kSplitGiRingUnits * 256 * (size_t)3 * h->hid * 2, 256);
+  g.total = g.x + g.y + g.e + g.gi;
+  return g;
+}
+static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_bytes) { return workspace_bytes >= split_rings(h, R).total; }
+
+static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bool in16, int kx, const SlotPlan& plan,
+                         const float* const* d_rgb_ptrs, const float* const* d_flow_ptrs, float* const* d_out_ptrs, int* const* d_arg_ptrs,
+                         void* workspace, size_t workspace_bytes, hipStream_t s) {
+  const int H = h->hid, E = h->emb, din = h->d_rgb + h->d_flow;
+  const int total = h->h_rowoff[h->t_max];
+  const int n_units = (total + 255) / 256;
+  const int upc = 1 << kSplitChunkUnitShift;
+  const int n_chunks = (n_units + upc - 1) >> kSplitChunkUnitShift;
+  const SplitRings rg = split_rings(h, R);
+  if (workspace_bytes < rg.total) return fail(PREGO_EWORKSPACE, "split pass: workspace %zu B < %zu B of rings", workspace_bytes, rg.total);
+  char* wp = (char*)workspace;
+  unsigned short* X = (unsigned short*)wp; wp += rg.x;
+  unsigned short* Y = (unsigned short*)wp; wp += rg.y;
+  unsigned short* Eb = (unsigned short*)wp; wp += rg.e;
+  unsigned short* GI = (unsigned short*)wp;
+  // handle-owned: relu(h) of every packed row, the row map, the counters
+  const size_t hr_bytes = align_up((size_t)total * H * 2, 256), rm_bytes = align_up((size_t)total * 8, 256);
+  const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 16;
+  const size_t need = hr_bytes + rm_bytes + align_up(n_ctr * 4, 256);
+  if (need > h->split_bytes) {                      // outside the steady state: a bigger pass than any before
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->split_buf) (void)hipFree(h->split_buf);
+    h->split_buf = nullptr; h->split_bytes = 0;
+    HIPCHK(hipMalloc((void**)&h->split_buf, need + need / 8));
+    h->split_bytes = need + need / 8;
+  }
+  char* HR = h->split_buf;
+  char* RM = HR + hr_bytes;
+  unsigned* ctr = (unsigned*)(RM + rm_bytes);
+  unsigned* tick = ctr; unsigned* pack_done = ctr + 16; unsigned* l1_cnt = pack_done + n_units; unsigned* ln_done = l1_cnt + n_units;
+  unsigned* wih_cnt = ln_done + n_units; unsigned* gi_cnt = wih_cnt + n_units; unsigned* rec_cnt = gi_cnt + n_chunks;
+  HIPCHK(hipMemsetAsync(ctr, 0, n_ctr * 4, s));
+  HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)h->n_slots * H * 4, s));
+
+  FfPassArgs fa{};
+  fa.rgb_ptrs = d_rgb_ptrs; fa.flow_ptrs = with_flow ? d_flow_ptrs : nullptr; fa.plan = plan; fa.rowmap = RM;
+  fa.d_rgb = h->d_rgb; fa.d_flow = with_flow ? h->d_flow : 0; fa.in16 = in16 ? 1 : 0; fa.kx = kx;
+  fa.w1 = (const unsigned short*)h->w1; fa.ld_w1 = din; fa.b1 = h->b1; fa.ln_g = h->ln_g; fa.ln_b = h->ln_b; fa.ln_eps = 1e-5f;
+  fa.w_ih = (const unsigned short*)h->w_ih; fa.bias2 = h->bias2; fa.E = E; fa.n3 = 3 * H;
+  fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = kSplitGiRingUnits;
+  fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = kSplitChunkUnitShift;
+  fa.rec_expect = R * h->P * 4; fa.nt1 = E / 256; fa.nt2 = 3 * H / 256;
+  static const int lag1 = getenv("PREGO_SPLIT_LAG1") ? atoi(getenv("PREGO_SPLIT_LAG1")) : 3;
+  static const int lag2 = getenv("PREGO_SPLIT_LAG2") ? atoi(getenv("PREGO_SPLIT_LAG2")) : 6;
+  static const int lag3 = getenv("PREGO_SPLIT_LAG3") ? atoi(getenv("PREGO_SPLIT_LAG3")) : 8;
+  fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
+  fa.tick = tick; fa.pack_done = pack_done; fa.l1_cnt = l1_cnt; fa.ln_done = ln_done; fa.wih_cnt = wih_cnt; fa.gi_cnt = gi_cnt;
+  fa.rec_cnt = rec_cnt; fa.abort_word = h->abort_word;
+  // a job may only ever wait for jobs with earlier tickets: the previous holder of a ring slot (kSplitRingPerXcd rounds back) must have been
+  // issued before the job that overwrites the slot
+  if (lag1 < 1 || lag2 <= lag1 || lag3 <= lag2 || lag1 >= kSplitRingPerXcd || lag2 - kSplitRingPerXcd >= lag1 || lag3 - kSplitRingPerXcd >= lag2)
+    return fail(PREGO_EINVAL, "split pass: lags %d %d %d", lag1, lag2, lag3);
+
+  GruArgs ga{};
+  ga.whh = h->w_hh; ga.b_hn = h->b_hn; ga.gi = GI; ga.gi_bf16 = 1; ga.f16 = h->f16 ? 1 : 0; ga.h_relu_out = HR; ga.h_raw_out = nullptr;
+  ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
+  ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = 0; ga.t1 = h->t_max; ga.row_base = 0; ga.rows = 0;
+  ga.n_clips = h->n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
+  ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = nullptr; ga.sync = h->flags; ga.armed = 0; ga.Gd = R;
+  ga.gi_cnt = gi_cnt; ga.rec_cnt = rec_cnt; ga.chunk_shift = kSplitChunkUnitShift + 8; ga.n_chunks = n_chunks;
+  ga.units_per_chunk = upc; ga.units_last = n_units - upc * (n_chunks - 1); ga.gi_row_mask = (unsigned)kSplitGiRingUnits * 256u - 1u;
+
+  // the feed-forward launch goes to the side stream (another hardware queue: it must be resident TOGETHER with the recurrence), forked
+  // from and joined to the caller's stream by events
+  struct SideJoin {
+    prego_miniroad* h; bool pending = false;
+    ~SideJoin() { if (pending) (void)hipStreamSynchronize(h->side); }
+  } side_join{h};
+  // everything the recurrence launch needs done first goes IN FRONT of the fork: once the feed-forward kernel is resident it fills its CUs
+  // completely, and an ordinary kernel of the caller's stream (the arm kernel, a memset) would wait for it - with the recurrence queued behind
+  launch_gru_arm(true, H, h->G, h->hx, h->flags, s);
+  HIPCHK(hipEventRecord(h->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+  EventPair* evf = ev_begin(h, 4, h->side);
+  if (launch_ff_pass(fa, h->side)) return fail(PREGO_EINVAL, "split pass: feed-forward shape E=%d kx=%d", E, kx);
+  ev_end(evf, h->side);
+  side_join.pending = true;
+  HIPCHK(hipEventRecord(h->ev_join, h->side));
+  EventPair* evr = ev_begin(h, 1, s);
+  if (launch_gru_recurrence_pass(H, ga, s)) return fail(PREGO_EINVAL, "split pass: recurrence launch");
+  ev_end(evr, s);
+  HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+  side_join.pending = false;
+  if (h->timing) { h->gemm_flop += 2.0 * total * ((double)E * kx + 3.0 * H * E); h->split_passes++; h->split_steps += h->t_max; }
+  if (launch_head_softmax(true, HR, h->w_c, h->b_c, plan, 0, total, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s,
+                          RM, h->f16))
+    return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
 extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* rgb,
                                       const float* const* flow, float* const* out, int32_t* const* argmax,
                                       const float* h0, float* h_last, int flags, void* workspace,
@@ -608,7 +741,23 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (hostfeat && want_single) { h->feed_ev.clear(); return fail(PREGO_EINVAL, "feed events with h0 / h_last / PREGO_FWD_KEEP: link-fed calls are plain inference"); }
   const int host_row_bytes = hostfeat ? h->feed_row_bytes : 0;
   struct FeedClear { prego_miniroad* h; ~FeedClear() { h->feed_ev.clear(); h->feed_upto.clear(); h->feed_pos = 0; } } feed_clear{h};   // one call only
-  int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes);
+  refresh_placement(h);
+  // split pass: the recurrence of the whole call on XCDs 0 .. R - 1 (16 R slots, continuous batching) and its feed-forward on
+  // the other XCDs, two persistent launches instead of a chain of launches per chunk.  Plain inference calls of 16-bit handles with
+  // enough clips to fill the slots and enough frames to amortise the pipeline fill; needs the verified placement (group := XCD) that an
+  // earlier full-width launch of this handle established, so a handle's first call is always the chunked pass.
+  int split_r = 0;
+  {
+    static const int split_env = getenv("PREGO_SPLIT_PASS") ? atoi(getenv("PREGO_SPLIT_PASS")) : 0;
+    long long frames = 0;
+    for (int i = 0; i < n_clips; ++i) frames += lens[i] > 0 ? lens[i] : 0;
+    if (split_env >= 1 && split_env <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local && h->placement == 1 &&
+        h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * split_env && frames >= 262144 && frames < (1ll << 31) - 65536 && (out || argmax) &&
+        split_workspace_ok(h, split_env, workspace_bytes))
+      split_r = split_env;
+  }
+  h->split_r = split_r;
+  int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes, split_r > 0 ? 16 * split_r : 0);
   if (rc) return rc;
   const SlotPlan plan = device_plan(h);
   const int n_slots = h->n_slots;
@@ -636,6 +785,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const bool with_flow = any_flow;
   const int kx = h->d_rgb + (with_flow ? h->d_flow : 0);      // K of the layer1 GEMM actually multiplied
   if (kx == 0) return fail(PREGO_EINVAL, "a model without rgb features (--no_rgb) needs the flow tensors");
+  if (split_r > 0)
+    return forward_split(h, split_r, flags, with_flow, in16, kx, plan, d_rgb_ptrs, d_flow_ptrs, d_out_ptrs, d_arg_ptrs, workspace, workspace_bytes, s);
   const int din = h->d_rgb + h->d_flow;
   const RowBytes rb = row_bytes(h, with_flow, flags);
   const int total_rows = h->h_rowoff[h->t_max];
@@ -717,11 +868,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const bool prefetch = h->pack_prefetch && !keep && h->side != nullptr;
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
   bool l1_done = false;           // Y already holds layer1 of this chunk (XCD overlap: the worker GEMM ran under the previous recurrence)
-  if (h->placement < 0 && h->place_pending && hipEventQuery(h->ev_place) == hipSuccess) {
-    const int v = (int)*h->pin_place;             // 1: group := XCD verified; 2: another placement; 0: that launch did not run the
-    h->placement = v == 0 ? -1 : v;               // full-width rendezvous (multi-tile kernel): look again behind a later launch
-    h->place_pending = false;
-  }
+  refresh_placement(h);
   const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8 && h->placement == 1 && !h->no_local;
   if (overlap_ok) HIPCHK(hipMemsetAsync(h->tile_ctr, 0, 4096 * sizeof(unsigned), s));
   // every exit path after a fork joins the side stream: an error return while the next chunk's pack is still writing X / RM
@@ -903,7 +1050,10 @@ extern "C" int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream) {
   HIPCHK(hipMemcpy(&ab, h->abort_word, sizeof ab, hipMemcpyDeviceToHost));
   if (ab) {
     (void)hipMemset(h->abort_word, 0, sizeof ab);
-    return fail(PREGO_ETIMEOUT, "GRU recurrence kernel timed out waiting for a producer workgroup (not all %d workgroups resident?)", h->G * h->P);
+    // codes: 1 = the recurrence's gather / rendezvous; 2 = a pass launch without the verified placement; 3 = the recurrence of a split pass
+    // waiting for its input projection; 0x100 + k = wait k of the feed-forward launch of a split pass (ff_pass.hip)
+    return fail(PREGO_ETIMEOUT, "GRU recurrence kernel timed out waiting for a producer workgroup (not all %d workgroups resident?) [code 0x%x]",
+                h->G * h->P, ab);
   }
   return PREGO_OK;
 }
@@ -922,8 +1072,8 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
                                           int64_t* pack_launches, double* pack_bytes) {
   HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
-  double ms[4] = {0, 0, 0, 0};
-  int64_t n[4] = {0, 0, 0, 0};
+  double ms[5] = {0, 0, 0, 0, 0};      // kinds: 0 gemm, 1 recurrence, 2 pack, 3 overlapped layer1 worker, 4 feed-forward launch of a split pass
+  int64_t n[5] = {0, 0, 0, 0, 0};
   for (size_t i = 0; i < h->ev_used; ++i) {
     HIPCHK(hipEventSynchronize(h->ev_pool[i].b));
     float t = 0;
@@ -942,6 +1092,14 @@ extern "C" int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, in
   h->ev_used = 0;
   h->gemm_flop = 0;
   h->pack_bytes = 0;
+  return PREGO_OK;
+}
+
+extern "C" int prego_miniroad_pass_info(const prego_miniroad* h, int32_t* mode, int32_t* n_steps, int32_t* n_slots) {
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (mode) *mode = h->split_r;
+  if (n_steps) *n_steps = h->t_max;
+  if (n_slots) *n_slots = h->n_slots;
   return PREGO_OK;
 }
 

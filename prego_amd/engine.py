@@ -345,6 +345,12 @@ class MiniRoadEngine:
         with torch.cuda.device(self.device):
             check(self.lib.prego_miniroad_check(self.h, C.c_void_p(_stream_ptr(self.device))))
 
+    def pass_info(self) -> dict:
+        """what the last forward() ran: mode 0 = chunked pass, R > 0 = split pass with the recurrence on R XCDs; steps, slots"""
+        m, st, sl = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.lib.prego_miniroad_pass_info(self.h, C.byref(m), C.byref(st), C.byref(sl)))
+        return dict(mode=m.value, steps=st.value, slots=sl.value)
+
     # -- kernel timing (bench.py roofline leg) -----------------------------------------------
     def timing_enable(self, on: bool = True):
         check(self.lib.prego_miniroad_timing_enable(self.h, 1 if on else 0))

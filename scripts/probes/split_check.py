@@ -1,0 +1,54 @@
+"""Split pass (PREGO_SPLIT_PASS=R) against the chunked pass of the SAME handle: bit-identical probabilities / argmax, and time per pass.
+The first forward of a handle is always the chunked pass (it establishes the verified placement); later ones split when eligible.
+usage: PREGO_SPLIT_PASS=3 python scripts/probes/split_check.py [n_clips] [min_T] [max_T] [flow 0/1] [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from prego_amd import weights as W
+from prego_amd.config import assembly101_cfg
+from prego_amd.registry import build_model
+import prego_amd.model  # noqa: F401
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else 9000
+use_flow = (int(sys.argv[4]) if len(sys.argv) > 4 else 0) != 0
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+dt = os.environ.get("SPLIT_DTYPE", "fp16")
+cfg = assembly101_cfg(compute_dtype=dt)
+sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+model = build_model(cfg, "cuda:0"); model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); model.eval()
+eng = model.engine()
+g = torch.Generator().manual_seed(7)
+lens = [int(x) for x in torch.randint(lo, hi + 1, (n,), generator=g)]
+dev = torch.device("cuda:0")
+rgb = [torch.randn((T, 2048), generator=g).clamp_(min=0).to(dev) for T in lens]
+flow = [torch.randn((T, 2048), generator=g).clamp_(min=0).to(dev) for T in lens] if use_flow else None
+frames = sum(lens)
+print(f"{n} clips, {frames} frames, flow={use_flow}, dtype {dt}, PREGO_SPLIT_PASS={os.environ.get('PREGO_SPLIT_PASS')}", flush=True)
+
+
+def run():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    o, a, _ = eng.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)
+    eng.check()
+    torch.cuda.synchronize()
+    return o, a, time.perf_counter() - t0
+
+
+o0, a0, t = run()
+info = eng.pass_info()
+print(f"call 0: mode {info['mode']} steps {info['steps']} slots {info['slots']}  {t*1e3:.2f} ms", flush=True)
+ref_o, ref_a = torch.cat(o0), torch.cat(a0)
+for k in range(1, reps + 1):
+    o, a, t = run()
+    info = eng.pass_info()
+    oo, aa = torch.cat(o), torch.cat(a)
+    same = bool(torch.equal(oo, ref_o)) and bool(torch.equal(aa, ref_a))
+    dmax = float((oo - ref_o).abs().max())
+    nbad = int((oo != ref_o).any(1).sum())
+    print(f"call {k}: mode {info['mode']} steps {info['steps']} slots {info['slots']}  {t*1e3:.2f} ms = {frames/t/1e6:.2f} M frames/s   "
+          f"bit-identical to call 0: {same} (max |d| {dmax:.3e}, rows differing {nbad}, argmax mismatches {int((aa != ref_a).sum())})", flush=True)
+    if nbad:
+        bad = (oo != ref_o).any(1).nonzero().flatten()
+        print("   first differing frames:", bad[:8].tolist(), " last:", bad[-4:].tolist(), flush=True)
