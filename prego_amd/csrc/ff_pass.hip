@@ -17,11 +17,15 @@
 // reads it with sc1 loads.  X / Y / E live in rings of `ring_units` units (a multiple of nf: a slot is only ever touched by one XCD,
 // so no XCD can write back a stale dirty line over another's data), GI in a ring of `gi_ring_units` (a power of two).
 //
-// Jobs of a unit: PACK (1), L1 tile (nt1 = E / 256), LN (1), WIH tile (nt2 = 3H / 256).  An XCD's queue is a ticket counter; ticket k is
-// job k mod (2 + nt1 + nt2) of ROUND k div (..): round i holds PACK of the XCD's unit i, the L1 tiles of unit i - lag1, LN of unit
-// i - lag2 and the WIH tiles of unit i - lag3, so that by the time a job is claimed its producers (claimed `lag` rounds = tens of
-// microseconds earlier) have normally finished: the dependency waits below are a safety net, not a pipeline stage.  Tickets are
-// claimed in order by resident workgroups that run every job to completion, so a wait can only be for a job that is already running.
+// Jobs of a unit: PACK (1), L1 tile (nt1 = E / 256), LN (1), WIH tile (nt2 = 3H / 256).  An XCD's queue is a ticket counter.  Its units
+// are taken `sg` at a time: ticket k is job k mod T of SUPER-ROUND k div T (T = sg (2 + nt1 + nt2)), and super-round r holds PACK of its
+// own sg units, the L1 tiles of the units of super-round r - lag1, LN of r - lag2 and the WIH tiles of r - lag3, so that by the time a job
+// is claimed its producers (claimed a super-round = ~0.2 ms earlier) have normally finished: the dependency waits below are a safety
+// net, not a pipeline stage.  Inside a GEMM section the tiles are ordered weight-slab-major over the sg units: the 32 workgroups of an
+// XCD then work on sg row blocks x 8 slabs at a time, every slab feeding sg of them from the XCD's L2 (unit-major order made every
+// running tile stream its own 2 MB slab over the fabric: 0.7 TB/s per XCD, and the pass ran at half the chunked GEMM rate).
+// Tickets are claimed in order by resident workgroups that run every job to completion, so a wait can only be for a job that is
+// already running.
 // Every wait is bounded (2 s of s_memrealtime): a timeout raises the abort word that ends both kernels (no hung GPU).
 //
 // Arithmetic: the tile loop is the ping-pong K loop of gemm_pp.hip (same fragment order, same MFMA order), the row jobs are the
@@ -195,71 +199,120 @@ __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ 
     }
 }
 
-// rows [row0, row0 + nrows) of the packed feature matrix, a wave per row (pack_rows_kernel's element arithmetic)
+// rows [row0, row0 + nrows) of the packed feature matrix (pack_rows_kernel's element arithmetic).  A wave owns 32 consecutive rows: lanes
+// 0 .. 31 look their (clip, frame) up side by side (one chain of table reads per wave instead of one per row: a persistent workgroup has
+// no other workgroups to hide that latency behind), then the wave copies two rows at a time with every load of both in flight before
+// the first conversion.
 template <typename OT>
 __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int din = a.kx;
-  for (int r = wave; r < nrows; r += 8) {
-    const int row = row0 + r;
-    int clip, t;
-    plan_clip_of_row(a.plan, row, clip, t);
-    if (a.rowmap != nullptr && lane == 0) ((int2*)a.rowmap)[row] = make_int2(clip, t);
+  const int rl = wave * 32 + (lane & 31);                       // my row of the unit (lanes 32 .. 63 mirror 0 .. 31)
+  int clip = 0, t = 0;
+  if (rl < nrows) {
+    const int row = row0 + rl;
+    int lo = a.plan.blk_step[row >> 5];                         // step of packed row 32 (row / 32): zero or a few hops from there
+    while (lo + 1 < a.plan.s_max && a.plan.rowoff[lo + 1] <= row) ++lo;
+    const int slot = row - a.plan.rowoff[lo];
+    int k = a.plan.seg_off[slot];
+    const int kend = a.plan.seg_off[slot + 1];
+    while (k + 1 < kend && a.plan.seg_start[k + 1] <= lo) ++k;
+    clip = a.plan.seg_clip[k];
+    t = lo - a.plan.seg_start[k];
+    if (a.rowmap != nullptr && lane < 32) ((int2*)a.rowmap)[row] = make_int2(clip, t);
+  }
+  const char* srgb = nullptr; const char* sflow = nullptr;       // my row's source rows (byte pointers; nullptr = zeros)
+  const int es = a.in16 ? 2 : 4;
+  if (rl < nrows) {
     const float* rgb = a.rgb_ptrs ? a.rgb_ptrs[clip] : nullptr;
     const float* flow = a.flow_ptrs ? a.flow_ptrs[clip] : nullptr;
-    bf16_t* dst = Xs + (size_t)r * din;
-    if (a.in16) {
-      const bf16_t* rgb16 = (const bf16_t*)rgb;
-      const bf16_t* flow16 = (const bf16_t*)flow;
-      for (int c = lane * 8; c < din; c += 512) {
-        const bf16_t* src = (c < a.d_rgb) ? (rgb16 ? rgb16 + (size_t)t * a.d_rgb + c : nullptr)
-                                          : (flow16 ? flow16 + (size_t)t * a.d_flow + (c - a.d_rgb) : nullptr);
-        const u32x4 v = src ? __builtin_nontemporal_load((const u32x4*)src) : (u32x4){0u, 0u, 0u, 0u};
-        *(u32x4*)(dst + c) = v;
-      }
-    } else {
-      for (int c = lane * 8; c < din; c += 512) {
-        const float* src = (c < a.d_rgb) ? (rgb ? rgb + (size_t)t * a.d_rgb + c : nullptr)
-                                         : (flow ? flow + (size_t)t * a.d_flow + (c - a.d_rgb) : nullptr);
-        float4 x = make_float4(0, 0, 0, 0), y = x;
-        if (src) { x = nt_load4(src); y = nt_load4(src + 4); }
-        uint4 o;
-        o.x = op16<OT>::pack2_sat(x.x, x.y); o.y = op16<OT>::pack2_sat(x.z, x.w);
-        o.z = op16<OT>::pack2_sat(y.x, y.y); o.w = op16<OT>::pack2_sat(y.z, y.w);
-        *(uint4*)(dst + c) = o;
-      }
+    if (rgb) srgb = (const char*)rgb + (size_t)t * a.d_rgb * es;
+    if (flow) sflow = (const char*)flow + (size_t)t * a.d_flow * es;
+  }
+  for (int rr = 0; rr < 32; rr += 2) {
+    const int r0 = wave * 32 + rr;
+    if (r0 >= nrows) break;
+    const char* pr[2]; const char* pf[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      pr[e] = (const char*)__shfl((unsigned long long)srgb, rr + e, 64) ;
+      pf[e] = (const char*)__shfl((unsigned long long)sflow, rr + e, 64);
+    }
+    const bool two = r0 + 1 < nrows;
+    for (int c0 = lane * 8; c0 < din; c0 += 2048) {              // four 512-column chunks of both rows per round
+      u32x4 v[2][4][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int c = c0 + b * 512;
+          const char* src = nullptr;
+          if (c < din && (e == 0 || two)) src = c < a.d_rgb ? (pr[e] ? pr[e] + (size_t)c * es : nullptr) : (pf[e] ? pf[e] + (size_t)(c - a.d_rgb) * es : nullptr);
+          v[e][b][0] = (u32x4){0u, 0u, 0u, 0u}; v[e][b][1] = v[e][b][0];
+          if (src) {
+            v[e][b][0] = __builtin_nontemporal_load((const u32x4*)src);
+            if (!a.in16) v[e][b][1] = __builtin_nontemporal_load((const u32x4*)src + 1);
+          }
+        }
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int c = c0 + b * 512;
+          if (c < din && (e == 0 || two)) {
+            u32x4 o = v[e][b][0];
+            if (!a.in16) {
+              const u32x4 x = v[e][b][0], y = v[e][b][1];
+              o[0] = op16<OT>::pack2_sat(__uint_as_float(x[0]), __uint_as_float(x[1])); o[1] = op16<OT>::pack2_sat(__uint_as_float(x[2]), __uint_as_float(x[3]));
+              o[2] = op16<OT>::pack2_sat(__uint_as_float(y[0]), __uint_as_float(y[1])); o[3] = op16<OT>::pack2_sat(__uint_as_float(y[2]), __uint_as_float(y[3]));
+            }
+            *(u32x4*)(Xs + (size_t)(r0 + e) * din + c) = o;
+          }
+        }
     }
   }
 }
 
-// LayerNorm + ReLU of nrows 16-bit rows, a wave per row (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order)
-template <typename OT>
+// LayerNorm + ReLU of nrows 16-bit rows (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order), a wave per row and NR
+// rows of a wave in flight together (a lone row is three dependent round trips: load, two wave reductions)
+template <typename OT, int MAXV, int NR>
 __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
-  constexpr int MAXV = 8;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int E = a.E, nv = E / 512;
-  for (int r = wave; r < nrows; r += 8) {
-    const bf16_t* y = Ys + (size_t)r * E;
-    float v[MAXV][8];
-    float s = 0.f;
+  for (int rb = wave; rb < nrows; rb += 8 * NR) {
+    float v[NR][MAXV][8];
+    float s[NR];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if (i < nv) {
-        const u32x4 w = *(const u32x4*)(y + (i * 64 + lane) * 8);
-        const float4 p = make_float4(op16<OT>::lo(w[0]), op16<OT>::hi(w[0]), op16<OT>::lo(w[1]), op16<OT>::hi(w[1]));
-        const float4 q = make_float4(op16<OT>::lo(w[2]), op16<OT>::hi(w[2]), op16<OT>::lo(w[3]), op16<OT>::hi(w[3]));
-        v[i][0] = p.x; v[i][1] = p.y; v[i][2] = p.z; v[i][3] = p.w; v[i][4] = q.x; v[i][5] = q.y; v[i][6] = q.z; v[i][7] = q.w;
-        s += ((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w));
-      }
-    const float mu = wave_sum(s) / (float)E;
-    float qq = 0.f;
+    for (int e = 0; e < NR; ++e) {
+      const int r = rb + 8 * e < nrows ? rb + 8 * e : rb;         // a missing row repeats the first (its result is not stored)
+      const bf16_t* y = Ys + (size_t)r * E;
+      s[e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i)
-      if (i < nv) {
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+          const u32x4 w = *(const u32x4*)(y + (i * 64 + lane) * 8);
+          const float4 p = make_float4(op16<OT>::lo(w[0]), op16<OT>::hi(w[0]), op16<OT>::lo(w[1]), op16<OT>::hi(w[1]));
+          const float4 q = make_float4(op16<OT>::lo(w[2]), op16<OT>::hi(w[2]), op16<OT>::lo(w[3]), op16<OT>::hi(w[3]));
+          v[e][i][0] = p.x; v[e][i][1] = p.y; v[e][i][2] = p.z; v[e][i][3] = p.w; v[e][i][4] = q.x; v[e][i][5] = q.y; v[e][i][6] = q.z; v[e][i][7] = q.w;
+          s[e] += ((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w));
+        }
+    }
+    float mu[NR], rstd[NR];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; qq += d * d; }
-      }
-    const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)E + a.ln_eps);
+    for (int e = 0; e < NR; ++e) mu[e] = wave_sum(s[e]) / (float)E;
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      float qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { const float d = v[e][i][k] - mu[e]; qq += d * d; }
+        }
+      rstd[e] = qq;
+    }
+#pragma unroll
+    for (int e = 0; e < NR; ++e) rstd[e] = 1.0f / sqrtf(wave_sum(rstd[e]) / (float)E + a.ln_eps);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
@@ -268,12 +321,15 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
         const float4 b0 = *(const float4*)(a.ln_b + c), b1 = *(const float4*)(a.ln_b + c + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        float o[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = fmaxf((v[i][k] - mu) * rstd * gg[k] + bb[k], 0.f);
-        uint4 w;
-        w.x = op16<OT>::pack2_sat(o[0], o[1]); w.y = op16<OT>::pack2_sat(o[2], o[3]); w.z = op16<OT>::pack2_sat(o[4], o[5]); w.w = op16<OT>::pack2_sat(o[6], o[7]);
-        *(uint4*)(Es + (size_t)r * E + c) = w;
+        for (int e = 0; e < NR; ++e) {
+          float o[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = fmaxf((v[e][i][k] - mu[e]) * rstd[e] * gg[k] + bb[k], 0.f);
+          uint4 w;
+          w.x = op16<OT>::pack2_sat(o[0], o[1]); w.y = op16<OT>::pack2_sat(o[2], o[3]); w.z = op16<OT>::pack2_sat(o[4], o[5]); w.w = op16<OT>::pack2_sat(o[6], o[7]);
+          if (rb + 8 * e < nrows) *(uint4*)(Es + (size_t)(rb + 8 * e) * E + c) = w;
+        }
       }
   }
 }
@@ -287,20 +343,28 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   if (xcc < a.xcd_lo) return;                                                // the recurrence's XCDs
   const int q = xcc - a.xcd_lo, nf = 8 - a.xcd_lo;
   const int n_q = a.n_units > q ? (a.n_units - q + nf - 1) / nf : 0;         // units of this XCD: q, q + nf, ...
-  const int jpr = 2 + a.nt1 + a.nt2;
-  const int n_rounds = n_q + a.lag3;
+  // ticket k = job (k mod T) of super-round (k div T), T = sg (2 + nt1 + nt2): the sg units of a super-round go through each job kind
+  // TOGETHER, and the tiles of a GEMM section are ordered weight-slab-major: [slab 0 of units 0 .. sg - 1], [slab 1 of ...], so the
+  // workgroups that run side by side share a weight slab (read once from the fabric, sg - 1 times from this XCD's L2) and each unit's A rows
+  const int sg = a.sg, tpr = sg * (2 + a.nt1 + a.nt2);
+  const int n_rounds = (n_q + sg - 1) / sg + a.lag3;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
+  const bool stats = a.stats != nullptr && tid == 0;
+  if (stats) { st_t0 = __builtin_amdgcn_s_memrealtime(); st_t = st_t0; }
+#define FSTAT(i) do { if (stats) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += n_ - st_t; st_t = n_; } } while (0)
   for (;;) {
     __syncthreads();                                                         // s_job of the previous iteration has been read
     if (tid == 0) s_job[0] = (int)__hip_atomic_fetch_add(a.tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const int k = __builtin_amdgcn_readfirstlane(s_job[0]);                  // wave-uniform: everything derived from it stays in SGPRs
-    const int round = k / jpr, j = k - round * jpr;
+    const int round = k / tpr, j = k - round * tpr;
+    FSTAT(5);
     if (round >= n_rounds) break;
     int type, i, nb = 0;
-    if (j == 0) { type = 0; i = round; }
-    else if (j <= a.nt1) { type = 1; i = round - a.lag1; nb = j - 1; }
-    else if (j == a.nt1 + 1) { type = 2; i = round - a.lag2; }
-    else { type = 3; i = round - a.lag3; nb = j - a.nt1 - 2; }
+    if (j < sg) { type = 0; i = round * sg + j; }
+    else if (j < sg + sg * a.nt1) { const int jj = j - sg; type = 1; nb = jj / sg; i = (round - a.lag1) * sg + (jj - nb * sg); }
+    else if (j < 2 * sg + sg * a.nt1) { type = 2; i = (round - a.lag2) * sg + (j - sg - sg * a.nt1); }
+    else { const int jj = j - 2 * sg - sg * a.nt1; type = 3; nb = jj / sg; i = (round - a.lag3) * sg + (jj - nb * sg); }
     if (i < 0 || i >= n_q) continue;
     const int u = q + i * nf;
     if (tid == 0) {
@@ -323,17 +387,20 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
     }
     __syncthreads();
     if (!__builtin_amdgcn_readfirstlane(s_job[1])) break;
+    FSTAT(4);
     asm volatile("buffer_inv sc0" ::: "memory");                            // this CU's vector L1 may hold the slot's previous contents
     const int row0 = u * 256;
     const int nrows = a.total_rows - row0 < 256 ? a.total_rows - row0 : 256;
     const size_t slot = (size_t)(u % a.ring_units) * 256;
     if (type == 0) {
-      ffp_pack<OT>(a, row0, nrows, a.X + slot * a.kx);
+      if (!(a.dbg & 1)) ffp_pack<OT>(a, row0, nrows, a.X + slot * a.kx);
     } else if (type == 1) {
       ffp_tile<OT, false>(smem, a.X + slot * a.kx, a.kx, nrows, a.w1 + (size_t)nb * 256 * a.ld_w1, a.ld_w1, a.b1 + nb * 256,
                           a.Y + slot * a.E + nb * 256, a.E, a.kx);
     } else if (type == 2) {
-      ffp_ln<OT>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
+      if (a.dbg & 2) { }
+      else if (a.E <= 2048) ffp_ln<OT, 4, 4>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
+      else ffp_ln<OT, 8, 2>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
     } else {
       const size_t gslot = (size_t)(u & (a.gi_ring_units - 1)) * 256;
       ffp_tile<OT, true>(smem, a.Eb + slot * a.E, a.E, nrows, a.w_ih + (size_t)nb * 256 * a.E, a.E, a.bias2 + nb * 256,
@@ -341,6 +408,8 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // my stores have reached the L2 (sc1: memory)
     __syncthreads();
+    FSTAT(type);
+    if (stats) st_acc[6] += 1;
     if (tid == 0) {
       if (type == 0) __hip_atomic_store(a.pack_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if (type == 1) __hip_atomic_fetch_add(a.l1_cnt + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -352,12 +421,17 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
       }
     }
   }
+  if (stats) {                               // debug (PREGO_SPLIT_STATS=1): 10 ns ticks summed over the feed-forward workgroups
+    st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_t0;
+    for (int e = 0; e < 8; ++e) atomicAdd(a.stats + e, st_acc[e]);
+  }
+#undef FSTAT
 }
 
 // 0 on success, -1 = shape not supported.  One launch per pass; `grid` workgroups (256: one per CU, an eighth lands on every XCD).
 int launch_ff_pass(const FfPassArgs& a, hipStream_t s) {
   if (a.E % 512 || a.E > 4096 || a.kx % FBK || a.kx < 2 * FBK || a.n3 % 256 || a.xcd_lo < 1 || a.xcd_lo > 7) return -1;
-  if (a.ring_units % (8 - a.xcd_lo) || (a.gi_ring_units & (a.gi_ring_units - 1)) || a.nt1 != a.E / 256 || a.nt2 != a.n3 / 256) return -1;
+  if (a.sg < 1 || a.ring_units % (8 - a.xcd_lo) || (a.gi_ring_units & (a.gi_ring_units - 1)) || a.nt1 != a.E / 256 || a.nt2 != a.n3 / 256) return -1;
   static DeviceOnce once;
   once.run([&] {
     (void)hipFuncSetAttribute((const void*)ff_pass_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * FBUF);

@@ -85,7 +85,10 @@ struct FfPassArgs {
   int chunk_unit_shift;         // log2(units per chunk): chunk of unit u = u >> shift
   int rec_expect;               // recurrence waves that signal a chunk (groups x P x 4)
   int nt1, nt2;                 // tiles per unit of the two GEMMs (E / 256, 3H / 256)
-  int lag1, lag2, lag3;         // rounds between PACK and L1 / LN / WIH of a unit in an XCD's ticket order
+  int sg;                       // units per super-round of an XCD's ticket order
+  int lag1, lag2, lag3;         // super-rounds between PACK and L1 / LN / WIH of a unit
+  int dbg;                      // timing experiments only (PREGO_SPLIT_DBG; wrong results): 1 skip the pack copies, 2 skip the LayerNorm rows
+  unsigned long long* stats;    // debug, nullable: [8] tick sums (pack, l1, ln, wih, waits, ticket, jobs, lifetime)
   int f16;
   unsigned* tick;               // [8] per-XCD job tickets
   unsigned* pack_done; unsigned* l1_cnt; unsigned* ln_done; unsigned* wih_cnt;   // [n_units]

@@ -611,7 +611,7 @@ static void refresh_placement(prego_miniroad* h) {
 // Geometry: units of 256 packed rows; chunks of 64 units (16 384 rows) are what the two kernels tell each other about; X / Y / E rings
 // of 8 units per feed-forward XCD, a GI ring of 4 chunks.  The rings come out of the caller's workspace (they fit the default one),
 // relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer (the head runs behind the pass).
-static const int kSplitChunkUnitShift = 6, kSplitGiRingUnits = 256, kSplitRingPerXcd = 8;
+static const int kSplitChunkUnitShift = 6, kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
   SplitRings g;
@@ -667,15 +667,20 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = kSplitGiRingUnits;
   fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = kSplitChunkUnitShift;
   fa.rec_expect = R * h->P * 4; fa.nt1 = E / 256; fa.nt2 = 3 * H / 256;
-  static const int lag1 = getenv("PREGO_SPLIT_LAG1") ? atoi(getenv("PREGO_SPLIT_LAG1")) : 3;
-  static const int lag2 = getenv("PREGO_SPLIT_LAG2") ? atoi(getenv("PREGO_SPLIT_LAG2")) : 6;
-  static const int lag3 = getenv("PREGO_SPLIT_LAG3") ? atoi(getenv("PREGO_SPLIT_LAG3")) : 8;
-  fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
+  static const int lag1 = getenv("PREGO_SPLIT_LAG1") ? atoi(getenv("PREGO_SPLIT_LAG1")) : 2;
+  static const int lag2 = getenv("PREGO_SPLIT_LAG2") ? atoi(getenv("PREGO_SPLIT_LAG2")) : 3;
+  static const int lag3 = getenv("PREGO_SPLIT_LAG3") ? atoi(getenv("PREGO_SPLIT_LAG3")) : 4;
+  static const bool want_stats = getenv("PREGO_SPLIT_STATS") != nullptr;
+  fa.sg = kSplitSg; fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
+  fa.stats = want_stats ? h->stamps : nullptr;
+  static const int dbg = getenv("PREGO_SPLIT_DBG") ? atoi(getenv("PREGO_SPLIT_DBG")) : 0;
+  fa.dbg = dbg;
   fa.tick = tick; fa.pack_done = pack_done; fa.l1_cnt = l1_cnt; fa.ln_done = ln_done; fa.wih_cnt = wih_cnt; fa.gi_cnt = gi_cnt;
   fa.rec_cnt = rec_cnt; fa.abort_word = h->abort_word;
-  // a job may only ever wait for jobs with earlier tickets: the previous holder of a ring slot (kSplitRingPerXcd rounds back) must have been
+  // a job may only ever wait for jobs with earlier tickets: the previous holder of a ring slot (ring / sg super-rounds back) must have been
   // issued before the job that overwrites the slot
-  if (lag1 < 1 || lag2 <= lag1 || lag3 <= lag2 || lag1 >= kSplitRingPerXcd || lag2 - kSplitRingPerXcd >= lag1 || lag3 - kSplitRingPerXcd >= lag2)
+  const int ring_sr = kSplitRingPerXcd / kSplitSg;
+  if (lag1 < 1 || lag2 <= lag1 || lag3 <= lag2 || lag1 >= ring_sr || lag2 - ring_sr >= lag1 || lag3 - ring_sr >= lag2)
     return fail(PREGO_EINVAL, "split pass: lags %d %d %d", lag1, lag2, lag3);
 
   GruArgs ga{};
@@ -698,7 +703,7 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   launch_gru_arm(true, H, h->G, h->hx, h->flags, s);
   HIPCHK(hipEventRecord(h->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  EventPair* evf = ev_begin(h, 4, h->side);
+  EventPair* evf = ev_begin(h, 2, h->side);       // timing_read: the feed-forward launch of a split pass is reported in the pack slot
   if (launch_ff_pass(fa, h->side)) return fail(PREGO_EINVAL, "split pass: feed-forward shape E=%d kx=%d", E, kx);
   ev_end(evf, h->side);
   side_join.pending = true;

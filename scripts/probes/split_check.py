@@ -40,6 +40,8 @@ o0, a0, t = run()
 info = eng.pass_info()
 print(f"call 0: mode {info['mode']} steps {info['steps']} slots {info['slots']}  {t*1e3:.2f} ms", flush=True)
 ref_o, ref_a = torch.cat(o0), torch.cat(a0)
+eng.timing_enable(True)
+import ctypes as C
 for k in range(1, reps + 1):
     o, a, t = run()
     info = eng.pass_info()
@@ -52,3 +54,12 @@ for k in range(1, reps + 1):
     if nbad:
         bad = (oo != ref_o).any(1).nonzero().flatten()
         print("   first differing frames:", bad[:8].tolist(), " last:", bad[-4:].tolist(), flush=True)
+tm = eng.timing_read()
+if reps:
+    print(f"per pass: recurrence launch(es) {tm['gru_ms']/reps:.2f} ms ({tm['gru_launches']//reps} launches), feed-forward launch / packs {tm['pack_ms']/reps:.2f} ms, "
+          f"static GEMM launches {tm['gemm_ms']/reps:.2f} ms", flush=True)
+if os.environ.get("PREGO_SPLIT_STATS") and hasattr(eng.lib, "prego_miniroad_debug_stamps"):
+    out = (C.c_uint64 * 8)(); eng.lib.prego_miniroad_debug_stamps(eng.h, out)
+    v = [x / 1e5 / max(1, reps) for x in out]          # 10 ns ticks -> ms, per pass (summed over the feed-forward workgroups)
+    print(f"feed-forward workgroup-ms per pass: pack {v[0]:.1f}  layer1 {v[1]:.1f}  ln {v[2]:.1f}  w_ih {v[3]:.1f}  waits {v[4]:.1f}  tickets {v[5]:.1f}  "
+          f"lifetime {v[7]:.1f}  jobs {out[6] // max(1, reps)}", flush=True)
