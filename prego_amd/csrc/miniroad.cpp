@@ -131,6 +131,9 @@ struct prego_miniroad {
   // split pass: recurrence on XCDs 0 .. split_r - 1 and the feed-forward of the whole pass on the others, two persistent
   // launches.  split_buf: handle-owned [relu(h) rows of the pass | row map | counters], grown outside the steady state
   int split_r = 0; int plan_force_slots = 0;
+  int split_env = -1;           // PREGO_SPLIT_PASS at create: -1 unset = decide per call (cost model), 0 = never, R = whenever a call is eligible
+  double plan_cost_us = 0;      // recurrence cost estimate of the cached plan (kStepCost tables)
+  std::vector<int32_t> split_seen_lens; int split_seen_key = -1, split_seen_r = 0;   // the last decision (same clips, same call shape: same answer)
   char* split_buf = nullptr; size_t split_bytes = 0;
   hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
   double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
@@ -234,6 +237,7 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin_place, 64, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_place, hipEventDisableTiming);
   h->xcd_overlap = getenv("PREGO_NO_XCD_OVERLAP") == nullptr;       // A/B knob: PREGO_NO_XCD_OVERLAP=1 = the serial pass of round 2
+  if (const char* sp = getenv("PREGO_SPLIT_PASS")) h->split_env = atoi(sp);
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
   h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
@@ -435,6 +439,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   h->plan_want_single = want_single;
   h->plan_host_row_bytes = host_row_bytes;
   h->plan_force_slots = slots_arg;
+  h->plan_cost_us = best.cost;
   h->plan_lens.assign(lens, lens + n);
   return PREGO_OK;
 }
@@ -753,13 +758,39 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   // earlier full-width launch of this handle established, so a handle's first call is always the chunked pass.
   int split_r = 0;
   {
-    static const int split_env = getenv("PREGO_SPLIT_PASS") ? atoi(getenv("PREGO_SPLIT_PASS")) : 0;
     long long frames = 0;
     for (int i = 0; i < n_clips; ++i) frames += lens[i] > 0 ? lens[i] : 0;
-    if (split_env >= 1 && split_env <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local && h->placement == 1 &&
-        h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * split_env && frames >= 262144 && frames < (1ll << 31) - 65536 && (out || argmax) &&
-        split_workspace_ok(h, split_env, workspace_bytes))
-      split_r = split_env;
+    const int r_try = h->split_env > 0 ? h->split_env : 3;
+    const bool with_flow_ = flow != nullptr && h->d_flow > 0 && flow[0] != nullptr;
+    const bool eligible = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
+                          h->placement == 1 && h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * r_try && frames >= 262144 &&
+                          frames < (1ll << 31) - 65536 && (out || argmax) && split_workspace_ok(h, r_try, workspace_bytes) &&
+                          (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
+    if (eligible && h->split_env > 0) split_r = r_try;
+    else if (eligible) {
+      // cost model (ms), calibrated on the bench workloads.  Chunked pass: the plan's recurrence estimate + the feed-forward of
+      // every row on the whole chip (projections at 1.4 PFLOP/s, 3 ns of LayerNorm + head; the pack hides under the recurrence) + 30 us
+      // per chunk.  Split pass: the slower of the 16 R-slot recurrence at 2.0 us per step and the feed-forward on 8 - R of 8 XCDs (pack
+      // included, at 5.3 TB/s), + 1.5 ms of pipeline fill and the head behind the pass.
+      const int key = (with_flow_ ? 1 : 0) | (in16 ? 2 : 0) | (int)((workspace_bytes >> 20) << 2);
+      if (key == h->split_seen_key && (int)h->split_seen_lens.size() == n_clips && std::equal(lens, lens + n_clips, h->split_seen_lens.begin()))
+        split_r = h->split_seen_r;
+      else {
+        const double kx_ = h->d_rgb + (with_flow_ ? h->d_flow : 0), E_ = h->emb, H3 = 3.0 * h->hid;
+        const double gemm_ns = (2.0 * kx_ * E_ + 2.0 * E_ * H3) / 1.4e15 * 1e9;
+        const double pack_ns = kx_ * ((in16 ? 2.0 : 4.0) + 2.0) / 5.3e12 * 1e9;
+        int rc0 = build_plan(h, n_clips, lens, false, 0, 0);
+        if (rc0) return rc0;
+        const RowBytes rb0 = row_bytes(h, with_flow_, flags);
+        const double chunk_rows = std::max(1.0, (double)((workspace_bytes - 12 * 256) / rb0.total));
+        const double est_chunked = h->plan_cost_us * 1e-3 + frames * (gemm_ns + 3.0) * 1e-6 + 0.03 * std::ceil(frames / chunk_rows);
+        rc0 = build_plan(h, n_clips, lens, false, 0, 16 * r_try);
+        if (rc0) return rc0;
+        const double est_split = std::max(h->t_max * 2.0e-3, frames * (gemm_ns + pack_ns + 1.5) * 1e-6 * 8.0 / (8 - r_try)) + 1.5;
+        split_r = est_split < 0.93 * est_chunked ? r_try : 0;
+        h->split_seen_lens.assign(lens, lens + n_clips); h->split_seen_key = key; h->split_seen_r = split_r;
+      }
+    }
   }
   h->split_r = split_r;
   int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes, split_r > 0 ? 16 * split_r : 0);

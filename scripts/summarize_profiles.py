@@ -37,7 +37,10 @@ if rows:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
     g = [r for r in rows if "gemm_bf16_nt" in r["kernel"]]
     p = [r for r in rows if "pack_rows" in r["kernel"]]
-    u = [r for r in rows if "gru_recurrence_kernel" in r["kernel"]]
+    is_pass = lambda k: "gru_recurrence_kernel" in k and ("ELb1ELb1EEv" in k or "true, true>" in k)     # the PASS instantiation (split pass)
+    u = [r for r in rows if "gru_recurrence_kernel" in r["kernel"] and not is_pass(r["kernel"])]
+    up = [r for r in rows if is_pass(r["kernel"])]
+    ff = [r for r in rows if "ff_pass_kernel" in r["kernel"]]
     tot = lambda rs: sum((r["read_bytes_per_launch_corrected_x2"] + r["write_bytes_per_launch"]) * r["launches"] for r in rs) / max(1, sum(r["launches"] for r in rs))
     import subprocess
     try:
@@ -47,7 +50,8 @@ if rows:
     json.dump({"source": f"profiles/{tag}_pmc_traffic.csv", "git": git, "dtype": os.environ.get("PREGO_PROFILE_DTYPE", "fp16"),
                "workload": "bench.py --clips 64 --len-scale 0.25 (64 clips at a quarter of the bench lengths: the same 49 152-row chunks per launch), "
                            "two separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE)",
-               "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p), "gru_bytes_per_launch": tot(u)},
+               "gemm_bytes_per_launch": tot(g), "pack_bytes_per_launch": tot(p), "gru_bytes_per_launch": tot(u),
+               "ff_pass_bytes_per_launch": tot(ff) if ff else None, "gru_pass_bytes_per_launch": tot(up) if up else None},
               open(os.path.join(dst, "traffic_latest.json"), "w"))
     for r in rows[:12]:
         print(r)

@@ -129,9 +129,9 @@ def test_config1_overlap_worker_is_bit_identical_to_the_serial_pass():
     rgb = [_feat((T, 2048), 50 + i) for i, T in enumerate(lens)]
     flow = [_feat((T, 2048), 5000 + i) for i, T in enumerate(lens)]
     m_on = _model(cfg, sd, "fp16")
-    e_on = m_on.engine()
+    e_on = _with_env("PREGO_SPLIT_PASS", "0", m_on.engine)        # the chunked pass is what this test is about (tests/test_gpu_split.py: the split pass)
     m_off = _model(cfg, sd, "fp16")
-    e_off = _with_env("PREGO_NO_XCD_OVERLAP", "1", m_off.engine)
+    e_off = _with_env("PREGO_NO_XCD_OVERLAP", "1", lambda: _with_env("PREGO_SPLIT_PASS", "0", m_off.engine))
     a, aa, _ = e_on.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)     # first pass verifies the placement
     a, aa, _ = e_on.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)     # second pass runs compacted + worker
     e_on.check()

@@ -1,0 +1,148 @@
+"""The split pass (csrc/ff_pass.hip + the PASS instantiation of csrc/gru_recurrence.hip): the recurrence of a whole call as one
+launch on R XCDs beside ONE persistent feed-forward launch on the others, instead of a chain of launches per chunk.
+
+Same tiles, same K order, same step arithmetic: every output must equal, BIT FOR BIT, the chunked pass of a handle created under
+PREGO_SPLIT_PASS=0 - for ragged clips (partial last 256-row unit), with and without the flow half, fp32 and 16-bit features, fp16 and bf16
+operands, probabilities / raw logits / argmax only, and on repeated calls (the counters, rings and rendezvous words are re-armed per
+pass).  Sampled clips are also held to the numpy oracle (model/rnn/rnn.py:51-71).  A handle's first call is always chunked (it
+establishes the verified workgroup placement), so every test runs its split handle at least twice and asks prego_miniroad_pass_info
+what actually ran."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import oracle_np as O            # noqa: E402  (checker only)
+from prego_amd import weights as W           # noqa: E402
+from prego_amd.config import assembly101_cfg  # noqa: E402
+from prego_amd._lib import PregoError         # noqa: E402
+
+
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
+
+
+def _engine(sd, cfg, dtype, split):
+    """split: '0' = never, 'R' = whenever eligible, None = the library decides per call (cost model)"""
+    from prego_amd.registry import build_model
+    import prego_amd.model  # noqa: F401
+    m = build_model(dict(cfg, compute_dtype=dtype), "cuda:0")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    return m, _with_env("PREGO_SPLIT_PASS", split, m.engine)
+
+
+def _feat(shape, seed, dtype=torch.float32):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randn(shape, device="cuda", generator=g).clamp_(min=0).to(dtype)
+
+
+def _lens(n, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [int(x) for x in torch.randint(lo, hi + 1, (n,), generator=g)]
+
+
+@pytest.fixture(scope="module")
+def weights():
+    cfg = assembly101_cfg()
+    return cfg, W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+
+
+def _run(eng, rgb, flow, **kw):
+    o, a, _ = eng.forward_ragged(rgb, flow, **kw)
+    eng.check()
+    return o, a, eng.pass_info()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_split_pass_equals_chunked_pass_bit_for_bit(weights, dtype):
+    cfg, sd = weights
+    lens = _lens(64, 3000, 6200, 11)               # 64 ragged clips, ~295 k frames: the last unit of the pass is partial
+    assert sum(lens) >= 262144 and sum(lens) % 256 != 0
+    rgb = [_feat((T, 2048), 100 + i) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, dtype, "0")
+    _, e3 = _engine(sd, cfg, dtype, "3")
+    ref_o, ref_a, info = _run(e0, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    assert info["mode"] == 0
+    o, a, info = _run(e3, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    assert info["mode"] == 0, "the first call of a handle establishes the placement: chunked"
+    for k in range(3):                                                    # repeated split passes: everything is re-armed per pass
+        o, a, info = _run(e3, rgb, None, softmax=True, want_out=True, want_argmax=True)
+        assert info["mode"] == 3 and info["slots"] == 48, info
+        assert info["steps"] >= max(lens)
+        for i in range(len(lens)):
+            assert torch.equal(o[i], ref_o[i]), f"pass {k}, clip {i}: the split pass changed the probabilities"
+            assert torch.equal(a[i], ref_a[i])
+    # two clips against the oracle (every other clip is pinned to them through bit-identity with the chunked pass and its own gates)
+    tol = {"fp16": 3e-3, "bf16": 1e-2}[dtype]
+    for i in (int(np.argmin(lens)), 17):
+        ref = O.miniroad_forward(sd, rgb[i].cpu().numpy()[None], None)["logits"][0]
+        assert np.abs(o[i].cpu().numpy() - ref).max() < tol
+
+
+def test_split_pass_with_flow_16bit_features_logits_and_argmax_only(weights):
+    cfg, sd = weights
+    lens = _lens(50, 4200, 6400, 12)                # 50 clips >= 48 slots: two slots run two clips back to back
+    rgb = [_feat((T, 2048), 300 + i, torch.float16) for i, T in enumerate(lens)]
+    flow = [_feat((T, 2048), 900 + i, torch.float16) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    _, e3 = _engine(sd, cfg, "fp16", "3")
+    ref_o, _, _ = _run(e0, rgb, flow, softmax=False, want_out=True, want_argmax=False)         # raw logits (training branch of MROAD.forward)
+    _, ref_a, _ = _run(e0, rgb, flow, softmax=True, want_out=False, want_argmax=True)
+    _run(e3, rgb, flow, softmax=False, want_out=True, want_argmax=False)
+    o, _, info = _run(e3, rgb, flow, softmax=False, want_out=True, want_argmax=False)
+    assert info["mode"] == 3
+    _, a, info = _run(e3, rgb, flow, softmax=True, want_out=False, want_argmax=True)
+    assert info["mode"] == 3
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]), i
+        assert torch.equal(a[i], ref_a[i]), i
+
+
+def test_split_pass_is_chosen_per_call_and_falls_back(weights):
+    """default handle (no PREGO_SPLIT_PASS): long ragged clips go through the split pass once the placement is known; a call that needs
+    h_last, one with too few clips and one with too few frames stay on the chunked pass - and all agree with the never-split handle"""
+    cfg, sd = weights
+    lens = _lens(60, 3000, 5000, 13) + [12000] * 4     # four long videos: the chunked pass is bound by their 12 000 sequential steps
+    rgb = [_feat((T, 2048), 500 + i) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    _, ea = _engine(sd, cfg, "fp16", None)
+    ref_o, ref_a, _ = _run(e0, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    assert info["mode"] == 3, f"cost model kept the chunked pass: {info}"
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i])
+    o, _, hl = ea.forward_ragged(rgb, None, want_h_last=True)            # one clip per slot, state handed back: chunked
+    ea.check()
+    assert ea.pass_info()["mode"] == 0 and hl.shape == (64, 1024)
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i])
+    o, _, _ = ea.forward_ragged(rgb[:40], None)                           # fewer clips than slots
+    ea.check()
+    assert ea.pass_info()["mode"] == 0
+    for i in range(40):
+        assert torch.equal(o[i], ref_o[i])
+    short = [r[:512] for r in rgb]                                         # 64 x 512 frames: too little work to fill the pipeline
+    o, _, _ = ea.forward_ragged(short, None)
+    ea.check()
+    assert ea.pass_info()["mode"] == 0
+    o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)      # and back
+    assert info["mode"] == 3
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i])
