@@ -340,7 +340,9 @@ def main():
                        "achieved": ff_tflops, "peak": peak, "unit": "TFLOP/s", "frac": ff_tflops / peak, "xcds": 8 - R,
                        "frac_of_its_xcds": ff_tflops / (peak * share), "traffic": traffic.get("ff_pass_bytes_per_launch"),
                        "avg_launch_ms": ff_ms / max(1, kt["pack_launches"]), "launches": kt["pack_launches"], "ms_per_step": ff_ms / args.steps,
-                       "note": "achieved = the two projections' algorithmic flops / the launch's duration; the launch also streams the features (pack) and normalises the rows"}
+                       "note": "achieved = the two projections' algorithmic flops / the launch's duration; the launch also streams the features (pack) and normalises the rows",
+                       "traffic_note": "null: rocprofv3 counter collection serialises kernel dispatches and the two launches of a split pass only make progress side by side "
+                                       "(a serialised pass ends in the bounded timeout, PREGO_ETIMEOUT); the chunked pass's per-kernel PMC traffic is in profiles/*_pmc_traffic.csv"}
             rl_gru.update({"kernel": f"gru_recurrence_kernel<PASS> (one launch per pass on {R} of 8 XCDs, {pinfo['slots']} slots)", "xcds": R,
                            "us_per_timestep": kt["gru_ms"] / args.steps * 1e3 / max(1, pinfo["steps"]), "sequential_timesteps": pinfo["steps"],
                            "traffic": traffic.get("gru_pass_bytes_per_launch")})

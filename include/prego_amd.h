@@ -143,6 +143,8 @@ int prego_miniroad_set_feed_events(prego_miniroad* h, int n_events, const int32_
  * its recurrence launches with HIP events on the caller's stream; read() synchronises and returns the summed
  * milliseconds and launch counts since enable. */
 int prego_miniroad_timing_enable(prego_miniroad* h, int enable);
+/* (a split pass reports its recurrence launch in the gru slot and its feed-forward launch - pack, both projections, LayerNorm - in the
+ * pack slot; gemm_flop still counts the projections' flops, gemm_ms / gemm_launches stay 0) */
 int prego_miniroad_timing_read(prego_miniroad* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flop,
                                double* gru_ms, int64_t* gru_launches, double* pack_ms, int64_t* pack_launches,
                                double* pack_bytes);
@@ -331,7 +333,8 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
  *   PREGO_GRU_NO_MT, PREGO_GRU_MT_SPEC, PREGO_GRU_NO_LOCAL, PREGO_GRU_STAMPS, PREGO_NO_ARM_FUSE   recurrence kernel choice / hand-off
  *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY, PREGO_SIDE_PRIO    where / on what stream the next chunk's pack runs
  *   PREGO_PLAN_SLOTS, PREGO_FP32_INTERMEDIATES                                             planner calibration, fp32 Y / GI in 16-bit modes
- *   PREGO_SPLIT_PASS, PREGO_SPLIT_LAG1/2/3                                                 split pass: recurrence XCDs (0 = chunked pass), job lags
+ *   PREGO_SPLIT_PASS (0 = never, R = on R XCDs whenever a call is eligible; unset = per-call cost model), PREGO_SPLIT_LAG1/2/3,
+ *   PREGO_SPLIT_CHUNK_SHIFT, PREGO_SPLIT_STATS                                             split pass: forcing, job lags, chunk size, job-time sums
  *   PREGO_GEMM_NO_PINGPONG, PREGO_GEMM_NO_BIG, PREGO_HEAD_V1, PREGO_BPTT_STEPWISE, PREGO_STEP_NO_LN_FUSE, PREGO_VIT_TOKENS_KERNEL,
  *   PREGO_ATTN_NW                                                                          older kernels kept as A/B references
  * The probe / unit-test entry points (prego_debug_*, prego_miniroad_debug_stamps) are NOT part of this library: they are declared in

@@ -1,4 +1,4 @@
-// The feed-forward half of a SPLIT PASS (DESIGN.md section 5d): pack -> layer1 GEMM -> LayerNorm + ReLU -> W_ih GEMM
+// The feed-forward half of a SPLIT PASS (DESIGN.md section 5b): pack -> layer1 GEMM -> LayerNorm + ReLU -> W_ih GEMM
 // (model/rnn/rnn.py:38-43,53-61) as ONE persistent kernel that lives on the XCDs the recurrence does not hold, for the whole pass.
 //
 // Why one kernel.  A kernel's workgroups are dealt to all eight XCDs and the launch completes only when every one of them has run;

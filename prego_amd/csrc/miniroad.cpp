@@ -128,7 +128,7 @@ struct prego_miniroad {
   // worker competed for the same CUs).  -1 = not read yet: copied out behind the first full-width launch, read when that copy is done
   int placement = -1; unsigned* pin_place = nullptr; hipEvent_t ev_place = nullptr; bool place_pending = false;
   int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
-  // split pass (DESIGN 5d): recurrence on XCDs 0 .. split_r - 1 and the feed-forward of the whole pass on the others, two persistent
+  // split pass (DESIGN 5b): recurrence on XCDs 0 .. split_r - 1 and the feed-forward of the whole pass on the others, two persistent
   // launches.  split_buf: handle-owned [relu(h) rows of the pass | row map | counters], grown outside the steady state
   int split_r = 0; int plan_force_slots = 0;
   int split_env = -1;           // PREGO_SPLIT_PASS at create: -1 unset = decide per call (cost model), 0 = never, R = whenever a call is eligible
@@ -384,7 +384,48 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
   };
   Cand best;
   static const int force_slots = getenv("PREGO_PLAN_SLOTS") ? atoi(getenv("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
-  if (slots_arg > 0) best = pack(std::min(n, slots_arg));                 // split pass: one tile on each of its groups
+  if (slots_arg > 0) {                                                    // split pass: one tile on each of its groups
+    best = pack(std::min(n, slots_arg));
+    // every slot is alive to the end of a split pass, so the pass takes as long as the most loaded slot: LPT leaves it a few percent above
+    // frames / slots (bench workload: 50 126 vs 48 045 steps).  Local search on the LPT result: move or swap clips between the most loaded
+    // slot and any other while that lowers the larger of the two loads
+    const int S2 = best.S;
+    for (int iter = 0; iter < 4096; ++iter) {
+      int A = 0;
+      for (int i = 1; i < S2; ++i) if (best.load[i] > best.load[A]) A = i;
+      long long best_gain = 0; int bB = -1, ba = -1, bb = -1;
+      for (int B = 0; B < S2; ++B) {
+        if (B == A) continue;
+        const long long la = best.load[A], lb = best.load[B];
+        for (size_t ia = 0; ia < best.bins[A].size(); ++ia) {
+          const long long a = lens[best.bins[A][ia]];
+          if (best.bins[A].size() > 1) {                                  // move a: A -> B
+            const long long gain = la - std::max(la - a, lb + a);
+            if (gain > best_gain) { best_gain = gain; bB = B; ba = (int)ia; bb = -1; }
+          }
+          for (size_t ib = 0; ib < best.bins[B].size(); ++ib) {           // swap a <-> b
+            const long long b = lens[best.bins[B][ib]];
+            if (b >= a) continue;
+            const long long gain = la - std::max(la - a + b, lb - b + a);
+            if (gain > best_gain) { best_gain = gain; bB = B; ba = (int)ia; bb = (int)ib; }
+          }
+        }
+      }
+      if (bB < 0) break;
+      const int ca = best.bins[A][ba];
+      if (bb < 0) {
+        best.bins[A].erase(best.bins[A].begin() + ba); best.bins[bB].push_back(ca);
+        best.load[A] -= lens[ca]; best.load[bB] += lens[ca];
+      } else {
+        const int cb = best.bins[bB][bb];
+        best.bins[A][ba] = cb; best.bins[bB][bb] = ca;
+        best.load[A] += lens[cb] - lens[ca]; best.load[bB] += lens[ca] - lens[cb];
+      }
+    }
+    long long mx = 0;
+    for (int i = 0; i < S2; ++i) mx = std::max(mx, best.load[i]);
+    best.cost = (double)mx * (h->x2 ? kStepCostX2 : h->bf16 ? kStepCost : kStepCostF32)[1];
+  }
   else if (want_single || (n <= per_layer && host_row_bytes <= 0)) best = pack(n);
   else if (force_slots > 0) best = pack(std::min(n, std::min(force_slots, max_slots)));
   else {
@@ -616,7 +657,8 @@ static void refresh_placement(prego_miniroad* h) {
 // Geometry: units of 256 packed rows; chunks of 64 units (16 384 rows) are what the two kernels tell each other about; X / Y / E rings
 // of 8 units per feed-forward XCD, a GI ring of 4 chunks.  The rings come out of the caller's workspace (they fit the default one),
 // relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer (the head runs behind the pass).
-static const int kSplitChunkUnitShift = 6, kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
+static const int kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
+static const int kSplitChunkUnitShift = getenv("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(getenv("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
   SplitRings g;
@@ -678,8 +720,10 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   static const bool want_stats = getenv("PREGO_SPLIT_STATS") != nullptr;
   fa.sg = kSplitSg; fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
   fa.stats = want_stats ? h->stamps : nullptr;
-  static const int dbg = getenv("PREGO_SPLIT_DBG") ? atoi(getenv("PREGO_SPLIT_DBG")) : 0;
+#ifdef PREGO_DEBUG_ABI
+  static const int dbg = getenv("PREGO_SPLIT_DBG") ? atoi(getenv("PREGO_SPLIT_DBG")) : 0;     // timing experiments (wrong results): debug library only
   fa.dbg = dbg;
+#endif
   fa.tick = tick; fa.pack_done = pack_done; fa.l1_cnt = l1_cnt; fa.ln_done = ln_done; fa.wih_cnt = wih_cnt; fa.gi_cnt = gi_cnt;
   fa.rec_cnt = rec_cnt; fa.abort_word = h->abort_word;
   // a job may only ever wait for jobs with earlier tickets: the previous holder of a ring slot (ring / sg super-rounds back) must have been
@@ -693,7 +737,8 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   ga.h_state = h->h_state; ga.hx = h->hx; ga.flags = h->flags; ga.abort_word = h->abort_word;
   ga.rowoff = h->d_rowoff; ga.nact = h->d_nact; ga.t0 = 0; ga.t1 = h->t_max; ga.row_base = 0; ga.rows = 0;
   ga.n_clips = h->n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
-  ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = nullptr; ga.sync = h->flags; ga.armed = 0; ga.Gd = R;
+  ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = (h->use_stamps && !want_stats) ? h->stamps : nullptr;
+  ga.sync = h->flags; ga.armed = 0; ga.Gd = R;
   ga.gi_cnt = gi_cnt; ga.rec_cnt = rec_cnt; ga.chunk_shift = kSplitChunkUnitShift + 8; ga.n_chunks = n_chunks;
   ga.units_per_chunk = upc; ga.units_last = n_units - upc * (n_chunks - 1); ga.gi_row_mask = (unsigned)kSplitGiRingUnits * 256u - 1u;
 
@@ -752,7 +797,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const int host_row_bytes = hostfeat ? h->feed_row_bytes : 0;
   struct FeedClear { prego_miniroad* h; ~FeedClear() { h->feed_ev.clear(); h->feed_upto.clear(); h->feed_pos = 0; } } feed_clear{h};   // one call only
   refresh_placement(h);
-  // split pass (DESIGN 5d): the recurrence of the whole call on XCDs 0 .. R - 1 (16 R slots, continuous batching) and its feed-forward on
+  // split pass (DESIGN 5b): the recurrence of the whole call on XCDs 0 .. R - 1 (16 R slots, continuous batching) and its feed-forward on
   // the other XCDs, two persistent launches instead of a chain of launches per chunk.  Plain inference calls of 16-bit handles with
   // enough clips to fill the slots and enough frames to amortise the pipeline fill; needs the verified placement (group := XCD) that an
   // earlier full-width launch of this handle established, so a handle's first call is always the chunked pass.
@@ -768,7 +813,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                           (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
     if (eligible && h->split_env > 0) split_r = r_try;
     else if (eligible) {
-      // cost model (ms), calibrated on the bench workloads (DESIGN 5d).  Chunked pass: the plan's recurrence estimate + the feed-forward of
+      // cost model (ms), calibrated on the bench workloads (DESIGN 5b).  Chunked pass: the plan's recurrence estimate + the feed-forward of
       // every row on the whole chip (projections at 1.4 PFLOP/s, 3 ns of LayerNorm + head; the pack hides under the recurrence) + 30 us
       // per chunk.  Split pass: the slower of the 16 R-slot recurrence at 2.0 us per step and the feed-forward on 8 - R of 8 XCDs (pack
       // included, at 5.3 TB/s), + 1.5 ms of pipeline fill and the head behind the pass.
@@ -1088,6 +1133,13 @@ extern "C" int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream) {
     (void)hipMemset(h->abort_word, 0, sizeof ab);
     // codes: 1 = the recurrence's gather / rendezvous; 2 = a pass launch without the verified placement; 3 = the recurrence of a split pass
     // waiting for its input projection; 0x100 + k = wait k of the feed-forward launch of a split pass (ff_pass.hip)
+    if (ab >= 2) {
+      // the two launches of a split pass did not run side by side (a profiler that collects counters serialises kernel dispatches; another
+      // process holds the XCDs): this handle keeps to the chunked pass from here on
+      h->split_env = 0;
+      return fail(PREGO_ETIMEOUT, "split pass: the recurrence and feed-forward launches did not run concurrently [code 0x%x] (kernel-serialising "
+                  "profiler?); the results of that call are invalid, this handle now uses the chunked pass (PREGO_SPLIT_PASS=0 selects it from the start)", ab);
+    }
     return fail(PREGO_ETIMEOUT, "GRU recurrence kernel timed out waiting for a producer workgroup (not all %d workgroups resident?) [code 0x%x]",
                 h->G * h->P, ab);
   }

@@ -63,3 +63,10 @@ if os.environ.get("PREGO_SPLIT_STATS") and hasattr(eng.lib, "prego_miniroad_debu
     v = [x / 1e5 / max(1, reps) for x in out]          # 10 ns ticks -> ms, per pass (summed over the feed-forward workgroups)
     print(f"feed-forward workgroup-ms per pass: pack {v[0]:.1f}  layer1 {v[1]:.1f}  ln {v[2]:.1f}  w_ih {v[3]:.1f}  waits {v[4]:.1f}  tickets {v[5]:.1f}  "
           f"lifetime {v[7]:.1f}  jobs {out[6] // max(1, reps)}", flush=True)
+if os.environ.get("PREGO_GRU_STAMPS") and not os.environ.get("PREGO_SPLIT_STATS") and hasattr(eng.lib, "prego_miniroad_debug_stamps"):
+    out = (C.c_uint64 * 8)(); eng.lib.prego_miniroad_debug_stamps(eng.h, out)
+    steps = max(1, out[6])
+    names = ["rest of gather + mfma", "step top -> first segment valid", "reduce+barrier", "gates+publish", "outputs"]
+    tot = sum(out[i] for i in range(5))
+    print(f"recurrence workgroup 0 / wave 0 (s_memtime ticks of 10 ns per step, {steps} steps): total {tot/steps:.1f}: " +
+          ", ".join(f"{names[i]} {out[i]/steps:.1f}" for i in range(5)) + f"; retry rounds/step {out[5]/steps:.2f}", flush=True)

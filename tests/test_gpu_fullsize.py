@@ -165,7 +165,7 @@ def test_overlap_stays_off_without_a_verified_placement():
 
 
 def test_config4_multitile_kernel_is_bit_identical_to_the_classic_kernel():
-    """512 clips x 512 frames = four clip tiles per group: the software-pipelined multi-tile recurrence (default) against the
+    """512 clips x 512 frames = four clip tiles per group: the software-pipelined multi-tile recurrence (HISTORY 5d, default) against the
     classic one-tile-at-a-time kernel (handle created under PREGO_GRU_NO_MT=1), bit for bit, in the shipped default dtype."""
     cfg = assembly101_cfg()
     sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)

@@ -1,4 +1,4 @@
-"""The split pass (DESIGN 5d; csrc/ff_pass.hip + the PASS instantiation of csrc/gru_recurrence.hip): the recurrence of a whole call as one
+"""The split pass (DESIGN 5b; csrc/ff_pass.hip + the PASS instantiation of csrc/gru_recurrence.hip): the recurrence of a whole call as one
 launch on R XCDs beside ONE persistent feed-forward launch on the others, instead of a chain of launches per chunk.
 
 Same tiles, same K order, same step arithmetic: every output must equal, BIT FOR BIT, the chunked pass of a handle created under
