@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     }
   };
 
-  const bool stamp = a.stamps != nullptr && blockIdx.x == 0 && q == 0;
+  const bool stamp = a.stamps != nullptr && (PASS ? (g == 0 && w == 0) : blockIdx.x == 0) && q == 0;   // pass mode: workgroup 0 may sit on an XCD without a group
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long st_t = 0;
 #define STAMP(i) do { if (stamp) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; } } while (0)

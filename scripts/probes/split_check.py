@@ -42,6 +42,9 @@ print(f"call 0: mode {info['mode']} steps {info['steps']} slots {info['slots']} 
 ref_o, ref_a = torch.cat(o0), torch.cat(a0)
 eng.timing_enable(True)
 import ctypes as C
+if (os.environ.get("PREGO_GRU_STAMPS") or os.environ.get("PREGO_SPLIT_STATS")) and hasattr(eng.lib, "prego_miniroad_debug_stamps"):
+    _o = (C.c_uint64 * 8)(); eng.lib.prego_miniroad_debug_stamps(eng.h, _o)          # drop call 0's stamps: the report below is about calls 1 .. reps
+    print("call 0 stamps:", [int(x) for x in _o], flush=True)
 for k in range(1, reps + 1):
     o, a, t = run()
     info = eng.pass_info()
