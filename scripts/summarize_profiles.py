@@ -9,14 +9,15 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
-st = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]          # gpurun_out/ keeps the files of earlier collections of the same tag
+st = newest(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True))
 if st:
     shutil.copy(st[0], os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
 
 
 def pmc(name, counter):
     out = defaultdict(lambda: [0, 0.0])
-    for f in glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 k = r["Kernel_Name"].split("(")[0]
