@@ -201,7 +201,7 @@ __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ 
 
 // rows [row0, row0 + nrows) of the packed feature matrix (pack_rows_kernel's element arithmetic).  A wave owns 32 consecutive rows: lanes
 // 0 .. 31 look their (clip, frame) up side by side (one chain of table reads per wave instead of one per row: a persistent workgroup has
-// no other workgroups to hide that latency behind), then the wave copies two rows at a time with every load of both in flight before
+// no other workgroups to hide that latency behind), then the wave copies four rows at a time with every load of the four in flight before
 // the first conversion.
 template <typename OT>
 __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
@@ -229,25 +229,25 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
     if (rgb) srgb = (const char*)rgb + (size_t)t * a.d_rgb * es;
     if (flow) sflow = (const char*)flow + (size_t)t * a.d_flow * es;
   }
-  for (int rr = 0; rr < 32; rr += 2) {
+  constexpr int PR = 4;                                          // rows of a wave in flight together (PR x 4 chunks x 32 B per lane)
+  for (int rr = 0; rr < 32; rr += PR) {
     const int r0 = wave * 32 + rr;
     if (r0 >= nrows) break;
-    const char* pr[2]; const char* pf[2];
+    const char* pr[PR]; const char* pf[PR];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      pr[e] = (const char*)__shfl((unsigned long long)srgb, rr + e, 64) ;
+    for (int e = 0; e < PR; ++e) {
+      pr[e] = (const char*)__shfl((unsigned long long)srgb, rr + e, 64);
       pf[e] = (const char*)__shfl((unsigned long long)sflow, rr + e, 64);
     }
-    const bool two = r0 + 1 < nrows;
-    for (int c0 = lane * 8; c0 < din; c0 += 2048) {              // four 512-column chunks of both rows per round
-      u32x4 v[2][4][2];
+    for (int c0 = lane * 8; c0 < din; c0 += 2048) {              // four 512-column chunks of the PR rows per round
+      u32x4 v[PR][4][2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < PR; ++e)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int c = c0 + b * 512;
           const char* src = nullptr;
-          if (c < din && (e == 0 || two)) src = c < a.d_rgb ? (pr[e] ? pr[e] + (size_t)c * es : nullptr) : (pf[e] ? pf[e] + (size_t)(c - a.d_rgb) * es : nullptr);
+          if (c < din && r0 + e < nrows) src = c < a.d_rgb ? (pr[e] ? pr[e] + (size_t)c * es : nullptr) : (pf[e] ? pf[e] + (size_t)(c - a.d_rgb) * es : nullptr);
           v[e][b][0] = (u32x4){0u, 0u, 0u, 0u}; v[e][b][1] = v[e][b][0];
           if (src) {
             v[e][b][0] = __builtin_nontemporal_load((const u32x4*)src);
@@ -255,11 +255,11 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
           }
         }
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < PR; ++e)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int c = c0 + b * 512;
-          if (c < din && (e == 0 || two)) {
+          if (c < din && r0 + e < nrows) {
             u32x4 o = v[e][b][0];
             if (!a.in16) {
               const u32x4 x = v[e][b][0], y = v[e][b][1];
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   const int n_rounds = (n_q + sg - 1) / sg + a.lag3;
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
   const bool stats = a.stats != nullptr && tid == 0;
-  if (stats) { st_t0 = __builtin_amdgcn_s_memrealtime(); st_t = st_t0; }
+  unsigned long long st_c0 = 0;
+  if (stats) { st_t0 = __builtin_amdgcn_s_memrealtime(); st_t = st_t0; st_c0 = __builtin_amdgcn_s_memtime(); }
 #define FSTAT(i) do { if (stats) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += n_ - st_t; st_t = n_; } } while (0)
   for (;;) {
     __syncthreads();                                                         // s_job of the previous iteration has been read
@@ -409,7 +410,6 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // my stores have reached the L2 (sc1: memory)
     __syncthreads();
     FSTAT(type);
-    if (stats) st_acc[6] += 1;
     if (tid == 0) {
       if (type == 0) __hip_atomic_store(a.pack_done + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else if (type == 1) __hip_atomic_fetch_add(a.l1_cnt + u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -423,6 +423,7 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   }
   if (stats) {                               // debug (PREGO_SPLIT_STATS=1): 10 ns ticks summed over the feed-forward workgroups
     st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_t0;
+    st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0;          // shader-clock cycles over the same span: [6] / [7] x 100 MHz = this XCD's clock
     for (int e = 0; e < 8; ++e) atomicAdd(a.stats + e, st_acc[e]);
   }
 #undef FSTAT

@@ -88,7 +88,7 @@ struct FfPassArgs {
   int sg;                       // units per super-round of an XCD's ticket order
   int lag1, lag2, lag3;         // super-rounds between PACK and L1 / LN / WIH of a unit
   int dbg;                      // timing experiments only (PREGO_SPLIT_DBG; wrong results): 1 skip the pack copies, 2 skip the LayerNorm rows
-  unsigned long long* stats;    // debug, nullable: [8] tick sums (pack, l1, ln, wih, waits, ticket, jobs, lifetime)
+  unsigned long long* stats;    // debug, nullable: [8] 10 ns tick sums (pack, l1, ln, wih, waits, ticket), [6] shader-clock cycles and [7] ticks of the workgroups' lifetime
   int f16;
   unsigned* tick;               // [8] per-XCD job tickets
   unsigned* pack_done; unsigned* l1_cnt; unsigned* ln_done; unsigned* wih_cnt;   // [n_units]

@@ -133,7 +133,11 @@ struct prego_miniroad {
   int split_r = 0; int plan_force_slots = 0;
   int split_env = -1;           // PREGO_SPLIT_PASS at create: -1 unset = decide per call (cost model), 0 = never, R = whenever a call is eligible
   double plan_cost_us = 0;      // recurrence cost estimate of the cached plan (kStepCost tables)
-  std::vector<int32_t> split_seen_lens; int split_seen_key = -1, split_seen_r = 0;   // the last decision (same clips, same call shape: same answer)
+  std::vector<int32_t> split_seen_lens; int split_seen_key = -1; double split_seen_est_c = 0, split_seen_est_s = 0;   // the last estimates (same clips, same call shape)
+  // the cost model is corrected by what passes of either kind actually took on THIS device (devices of one pool differ: a sustained
+  // split pass runs its GEMM tiles 35 % slower on some, where it then loses to the chunked pass): measured / estimated, per kind
+  hipEvent_t ev_meas[2] = {nullptr, nullptr}; bool meas_pending = false, meas_armed = false; int meas_mode = 0; double meas_est = 0;
+  double ratio_chunked = 1.0, ratio_split = 1.0; bool have_ratio_chunked = false, have_ratio_split = false;
   char* split_buf = nullptr; size_t split_bytes = 0;
   hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
   double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
@@ -236,6 +240,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->tile_ctr, 4096 * sizeof(unsigned));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin_place, 64, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_place, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_meas[0]);
+  if (e == hipSuccess) e = hipEventCreate(&h->ev_meas[1]);
   h->xcd_overlap = getenv("PREGO_NO_XCD_OVERLAP") == nullptr;       // A/B knob: PREGO_NO_XCD_OVERLAP=1 = the serial pass of round 2
   if (const char* sp = getenv("PREGO_SPLIT_PASS")) h->split_env = atoi(sp);
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
@@ -262,6 +268,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_place) (void)hipEventDestroy(h->ev_place);
+  for (hipEvent_t ev : h->ev_meas) if (ev) (void)hipEventDestroy(ev);
   if (h->pin_place) (void)hipHostFree(h->pin_place);
   if (h->split_buf) (void)hipFree(h->split_buf);
   delete h;
@@ -767,6 +774,7 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   if (launch_head_softmax(true, HR, h->w_c, h->b_c, plan, 0, total, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s,
                           RM, h->f16))
     return fail(PREGO_EINVAL, "head: unsupported num_classes %d", h->ncls);
+  if (h->meas_armed) { HIPCHK(hipEventRecord(h->ev_meas[1], s)); h->meas_pending = true; h->meas_armed = false; }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
@@ -802,25 +810,42 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   // enough clips to fill the slots and enough frames to amortise the pipeline fill; needs the verified placement (group := XCD) that an
   // earlier full-width launch of this handle established, so a handle's first call is always the chunked pass.
   int split_r = 0;
+  h->meas_armed = false;
   {
     long long frames = 0;
     for (int i = 0; i < n_clips; ++i) frames += lens[i] > 0 ? lens[i] : 0;
     const int r_try = h->split_env > 0 ? h->split_env : 3;
     const bool with_flow_ = flow != nullptr && h->d_flow > 0 && flow[0] != nullptr;
-    const bool eligible = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
-                          h->placement == 1 && h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * r_try && frames >= 262144 &&
+    // everything but the placement (which a handle's first, chunked, call establishes)
+    const bool shape_ok = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
+                          h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * r_try && frames >= 262144 &&
                           frames < (1ll << 31) - 65536 && (out || argmax) && split_workspace_ok(h, r_try, workspace_bytes) &&
+                          (h->d_rgb > 0 ? h->d_rgb : h->d_flow) >= 128 &&
                           (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
+    const bool eligible = shape_ok && h->placement == 1;
     if (eligible && h->split_env > 0) split_r = r_try;
-    else if (eligible) {
+    else if (shape_ok) {
       // cost model (ms), calibrated on the bench workloads.  Chunked pass: the plan's recurrence estimate + the feed-forward of
       // every row on the whole chip (projections at 1.4 PFLOP/s, 3 ns of LayerNorm + head; the pack hides under the recurrence) + 30 us
       // per chunk.  Split pass: the slower of the 16 R-slot recurrence at 2.0 us per step and the feed-forward on 8 - R of 8 XCDs (pack
-      // included, at 5.3 TB/s), + 1.5 ms of pipeline fill and the head behind the pass.
+      // included, at 5.3 TB/s), + 1.5 ms of pipeline fill and the head behind the pass.  Both are scaled by what passes of that kind
+      // took on this device so far (measured / estimated, events around every call of this shape class).
+      // while one of the two kinds has never been timed on this handle, the host waits here for the pending measurement (at most the
+      // handle's first two calls of this class lose their run-ahead); afterwards measurements are picked up when they happen to be done
+      if (h->meas_pending && !(h->have_ratio_split && h->have_ratio_chunked)) (void)hipEventSynchronize(h->ev_meas[1]);
+      if (h->meas_pending && hipEventQuery(h->ev_meas[1]) == hipSuccess) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, h->ev_meas[0], h->ev_meas[1]) == hipSuccess && ms > 0 && h->meas_est > 0) {
+          const double r = ms / h->meas_est;
+          double& ratio = h->meas_mode ? h->ratio_split : h->ratio_chunked;
+          bool& have = h->meas_mode ? h->have_ratio_split : h->have_ratio_chunked;
+          ratio = have ? 0.25 * ratio + 0.75 * r : r;
+          have = true;
+        }
+        h->meas_pending = false;
+      }
       const int key = (with_flow_ ? 1 : 0) | (in16 ? 2 : 0) | (int)((workspace_bytes >> 20) << 2);
-      if (key == h->split_seen_key && (int)h->split_seen_lens.size() == n_clips && std::equal(lens, lens + n_clips, h->split_seen_lens.begin()))
-        split_r = h->split_seen_r;
-      else {
+      if (!(key == h->split_seen_key && (int)h->split_seen_lens.size() == n_clips && std::equal(lens, lens + n_clips, h->split_seen_lens.begin()))) {
         const double kx_ = h->d_rgb + (with_flow_ ? h->d_flow : 0), E_ = h->emb, H3 = 3.0 * h->hid;
         const double gemm_ns = (2.0 * kx_ * E_ + 2.0 * E_ * H3) / 1.4e15 * 1e9;
         const double pack_ns = kx_ * ((in16 ? 2.0 : 4.0) + 2.0) / 5.3e12 * 1e9;
@@ -828,12 +853,22 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
         if (rc0) return rc0;
         const RowBytes rb0 = row_bytes(h, with_flow_, flags);
         const double chunk_rows = std::max(1.0, (double)((workspace_bytes - 12 * 256) / rb0.total));
-        const double est_chunked = h->plan_cost_us * 1e-3 + frames * (gemm_ns + 3.0) * 1e-6 + 0.03 * std::ceil(frames / chunk_rows);
+        h->split_seen_est_c = h->plan_cost_us * 1e-3 + frames * (gemm_ns + 3.0) * 1e-6 + 0.03 * std::ceil(frames / chunk_rows);
         rc0 = build_plan(h, n_clips, lens, false, 0, 16 * r_try);
         if (rc0) return rc0;
-        const double est_split = std::max(h->t_max * 2.0e-3, frames * (gemm_ns + pack_ns + 1.5) * 1e-6 * 8.0 / (8 - r_try)) + 1.5;
-        split_r = est_split < 0.93 * est_chunked ? r_try : 0;
-        h->split_seen_lens.assign(lens, lens + n_clips); h->split_seen_key = key; h->split_seen_r = split_r;
+        h->split_seen_est_s = std::max(h->t_max * 2.0e-3, frames * (gemm_ns + pack_ns + 1.5) * 1e-6 * 8.0 / (8 - r_try)) + 1.5;
+        h->split_seen_lens.assign(lens, lens + n_clips); h->split_seen_key = key;
+      }
+      if (eligible) {
+        const double es = h->split_seen_est_s * h->ratio_split, ec = h->split_seen_est_c * h->ratio_chunked;
+        if (!h->have_ratio_split) split_r = es < 1.05 * ec ? r_try : 0;       // never timed here: worth a trial when the model says it is close
+        else if (!h->have_ratio_chunked) split_r = 0;                          // time the chunked pass once, too
+        else split_r = es < 0.98 * ec ? r_try : 0;
+      }
+      if (!h->meas_pending) {                   // time this call (one measurement in flight at a time)
+        h->meas_armed = true; h->meas_mode = split_r > 0 ? 1 : 0;
+        h->meas_est = split_r > 0 ? h->split_seen_est_s : h->split_seen_est_c;
+        HIPCHK(hipEventRecord(h->ev_meas[0], s));
       }
     }
   }
@@ -1084,6 +1119,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
   if (hostfeat && (h->feed_upto.empty() || h->feed_upto.back() < h->t_max))
     return fail(PREGO_EINVAL, "feed events cover steps < %d, the call has %d", h->feed_upto.empty() ? 0 : h->feed_upto.back(), h->t_max);
+  if (h->meas_armed) { HIPCHK(hipEventRecord(h->ev_meas[1], s)); h->meas_pending = true; h->meas_armed = false; }
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

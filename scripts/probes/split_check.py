@@ -65,7 +65,7 @@ if os.environ.get("PREGO_SPLIT_STATS") and hasattr(eng.lib, "prego_miniroad_debu
     out = (C.c_uint64 * 8)(); eng.lib.prego_miniroad_debug_stamps(eng.h, out)
     v = [x / 1e5 / max(1, reps) for x in out]          # 10 ns ticks -> ms, per pass (summed over the feed-forward workgroups)
     print(f"feed-forward workgroup-ms per pass: pack {v[0]:.1f}  layer1 {v[1]:.1f}  ln {v[2]:.1f}  w_ih {v[3]:.1f}  waits {v[4]:.1f}  tickets {v[5]:.1f}  "
-          f"lifetime {v[7]:.1f}  jobs {out[6] // max(1, reps)}", flush=True)
+          f"lifetime {v[7]:.1f}  shader clock of the feed-forward XCDs {out[6] / max(1, out[7]) * 100:.0f} MHz", flush=True)
 if os.environ.get("PREGO_GRU_STAMPS") and not os.environ.get("PREGO_SPLIT_STATS") and hasattr(eng.lib, "prego_miniroad_debug_stamps"):
     out = (C.c_uint64 * 8)(); eng.lib.prego_miniroad_debug_stamps(eng.h, out)
     steps = max(1, out[6])

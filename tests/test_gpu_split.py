@@ -115,19 +115,24 @@ def test_split_pass_with_flow_16bit_features_logits_and_argmax_only(weights):
 
 
 def test_split_pass_is_chosen_per_call_and_falls_back(weights):
-    """default handle (no PREGO_SPLIT_PASS): long ragged clips go through the split pass once the placement is known; a call that needs
-    h_last, one with too few clips and one with too few frames stay on the chunked pass - and all agree with the never-split handle"""
+    """default handle (no PREGO_SPLIT_PASS): the library picks the pass per call - a cost model, corrected by what passes of either kind
+    took on this device - so WHICH pass runs is not asserted for eligible calls (devices of the pool differ), only that every call agrees
+    bit for bit with the never-split handle; a call that needs h_last, one with too few clips and one with too few frames must stay
+    on the chunked pass"""
     cfg, sd = weights
     lens = _lens(60, 3000, 5000, 13) + [12000] * 4     # four long videos: the chunked pass is bound by their 12 000 sequential steps
     rgb = [_feat((T, 2048), 500 + i) for i, T in enumerate(lens)]
     _, e0 = _engine(sd, cfg, "fp16", "0")
     _, ea = _engine(sd, cfg, "fp16", None)
     ref_o, ref_a, _ = _run(e0, rgb, None, softmax=True, want_out=True, want_argmax=True)
-    _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)
-    o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)
-    assert info["mode"] == 3, f"cost model kept the chunked pass: {info}"
-    for i in range(len(lens)):
-        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i])
+    modes = []
+    for _ in range(5):
+        o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)
+        modes.append(info["mode"])
+        for i in range(len(lens)):
+            assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), (modes, i)
+    assert modes[0] == 0 and set(modes) <= {0, 3}, modes
+    print("passes chosen by the default handle:", modes)
     o, _, hl = ea.forward_ragged(rgb, None, want_h_last=True)            # one clip per slot, state handed back: chunked
     ea.check()
     assert ea.pass_info()["mode"] == 0 and hl.shape == (64, 1024)
@@ -142,7 +147,7 @@ def test_split_pass_is_chosen_per_call_and_falls_back(weights):
     o, _, _ = ea.forward_ragged(short, None)
     ea.check()
     assert ea.pass_info()["mode"] == 0
-    o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)      # and back
-    assert info["mode"] == 3
+    o, a, info = _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)      # and back to the long clips
+    assert info["mode"] in (0, 3)
     for i in range(len(lens)):
         assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i])
