@@ -160,3 +160,32 @@ def test_split_operand_handle_and_feed_event_misuse():
         assert np.array_equal(arg.cpu().numpy(), o.argmax(1))
     finally:
         lib.prego_miniroad_destroy(h)
+
+
+def test_pass_info_reports_the_last_forward_and_validates_its_handle():
+    """prego_miniroad_pass_info (ABI 5): NULL handle -> PREGO_EINVAL; after a small forward: chunked pass (mode 0), the plan's steps and slots;
+    NULL out-pointers are allowed"""
+    lib = _lib.load()
+    m, st, sl = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+    assert lib.prego_miniroad_pass_info(None, C.byref(m), C.byref(st), C.byref(sl)) == -1
+    h = C.c_void_p()
+    din, emb, hid, ncls = 4096, 2048, 1024, 86
+    assert lib.prego_miniroad_create(C.byref(h), 2048, 2048, emb, hid, ncls, _lib.PREGO_F16) == 0
+    try:
+        w = _weights(din, emb, hid, ncls)
+        assert lib.prego_miniroad_set_weights(h, *[t.data_ptr() for t in w], None) == 0
+        lens_l = [40, 25, 33]
+        rgb = [torch.rand((T, 2048), device="cuda") for T in lens_l]
+        out = [torch.empty((T, ncls), device="cuda") for T in lens_l]
+        lens = (C.c_int32 * 3)(*lens_l)
+        p_rgb = (C.c_void_p * 3)(*[t.data_ptr() for t in rgb])
+        p_out = (C.c_void_p * 3)(*[t.data_ptr() for t in out])
+        need = lib.prego_miniroad_workspace_bytes(h, 3, lens, 128, 0)
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        assert lib.prego_miniroad_forward(h, 3, lens, p_rgb, None, p_out, None, None, None, 1, ws.data_ptr(), need, None) == 0
+        assert lib.prego_miniroad_check(h, None) == 0
+        assert lib.prego_miniroad_pass_info(h, C.byref(m), C.byref(st), C.byref(sl)) == 0
+        assert (m.value, st.value, sl.value) == (0, 40, 3)
+        assert lib.prego_miniroad_pass_info(h, None, None, None) == 0
+    finally:
+        lib.prego_miniroad_destroy(h)
