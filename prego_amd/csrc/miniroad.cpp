@@ -679,6 +679,12 @@ static SplitRings split_rings(const prego_miniroad* h, int R) {
 }
 static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_bytes) { return workspace_bytes >= split_rings(h, R).total; }
 
+// Split passes of DIFFERENT handles on one device must not interleave: handle A's feed-forward launch resident on XCDs R .. 7 with handle
+// B's recurrence launch resident on XCDs 0 .. R - 1 wait for each other's partner, which can never be dispatched (bounded, but both calls
+// are lost).  Every split pass therefore starts behind the end of the previous one on the device, whatever handle / stream it came from.
+static std::mutex g_split_mu;
+static hipEvent_t g_split_last[64] = {};
+
 static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bool in16, int kx, const SlotPlan& plan,
                          const float* const* d_rgb_ptrs, const float* const* d_flow_ptrs, float* const* d_out_ptrs, int* const* d_arg_ptrs,
                          void* workspace, size_t workspace_bytes, hipStream_t s) {
@@ -758,6 +764,11 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   // everything the recurrence launch needs done first goes IN FRONT of the fork: once the feed-forward kernel is resident it fills its CUs
   // completely, and an ordinary kernel of the caller's stream (the arm kernel, a memset) would wait for it - with the recurrence queued behind
   launch_gru_arm(true, H, h->G, h->hx, h->flags, s);
+  std::lock_guard<std::mutex> split_lock(g_split_mu);          // held until this pass is enqueued and its end event recorded
+  int dev_ = 0;
+  HIPCHK(hipGetDevice(&dev_));
+  const bool dev_ok = dev_ >= 0 && dev_ < 64;
+  if (dev_ok && g_split_last[dev_]) HIPCHK(hipStreamWaitEvent(s, g_split_last[dev_], 0));
   HIPCHK(hipEventRecord(h->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
   EventPair* evf = ev_begin(h, 2, h->side);       // timing_read: the feed-forward launch of a split pass is reported in the pack slot
@@ -770,6 +781,10 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   ev_end(evr, s);
   HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   side_join.pending = false;
+  if (dev_ok) {
+    if (!g_split_last[dev_]) HIPCHK(hipEventCreateWithFlags(&g_split_last[dev_], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(g_split_last[dev_], s));
+  }
   if (h->timing) { h->gemm_flop += 2.0 * total * ((double)E * kx + 3.0 * H * E); h->split_passes++; h->split_steps += h->t_max; }
   if (launch_head_softmax(true, HR, h->w_c, h->b_c, plan, 0, total, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s,
                           RM, h->f16))

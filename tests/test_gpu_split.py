@@ -151,3 +151,41 @@ def test_split_pass_is_chosen_per_call_and_falls_back(weights):
     assert info["mode"] in (0, 3)
     for i in range(len(lens)):
         assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i])
+
+
+def test_two_handles_on_two_streams_and_a_bystander_kernel(weights):
+    """split passes of two handles enqueued back to back on two streams (the library orders them one behind the other on the device: the
+    four persistent launches of two interleaved passes would wait for each other), while a third stream runs ordinary kernels that have
+    to wait for the pass's XCDs: everything completes, nothing times out, results equal the chunked pass"""
+    cfg, sd = weights
+    lens = _lens(56, 4300, 5600, 21)
+    rgb = [_feat((T, 2048), 700 + i) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    ref_o, ref_a, _ = _run(e0, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    _, ea = _engine(sd, cfg, "fp16", "3")
+    _, eb = _engine(sd, cfg, "fp16", "3")
+    _run(ea, rgb, None, softmax=True, want_out=True, want_argmax=True)      # first calls: chunked, placement
+    _run(eb, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    sa, sb, sc = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    x = torch.ones(1 << 20, device="cuda")
+    res = {}
+    for rep in range(2):
+        with torch.cuda.stream(sa):
+            res["a"] = ea.forward_ragged(rgb, None, softmax=True, want_out=True, want_argmax=True)
+        with torch.cuda.stream(sb):
+            res["b"] = eb.forward_ragged(rgb, None, softmax=True, want_out=True, want_argmax=True)
+        with torch.cuda.stream(sc):
+            y = (x * 2.0 + 1.0).sum()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(sa):
+        ea.check()
+        assert ea.pass_info()["mode"] == 3
+    with torch.cuda.stream(sb):
+        eb.check()
+        assert eb.pass_info()["mode"] == 3
+    assert float(y) == 3.0 * (1 << 20)
+    for k in ("a", "b"):
+        o, a, _ = res[k]
+        for i in range(len(lens)):
+            assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), (k, i)
