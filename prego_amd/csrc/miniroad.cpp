@@ -137,7 +137,7 @@ struct prego_miniroad {
   // the cost model is corrected by what passes of either kind actually took on THIS device (devices of one pool differ: a sustained
   // split pass runs its GEMM tiles 35 % slower on some, where it then loses to the chunked pass): measured / estimated, per kind
   hipEvent_t ev_meas[2] = {nullptr, nullptr}; bool meas_pending = false, meas_armed = false; int meas_mode = 0; double meas_est = 0;
-  double ratio_chunked = 1.0, ratio_split = 1.0; bool have_ratio_chunked = false, have_ratio_split = false;
+  double ratio_chunked = 1.0, ratio_split = 1.0; bool have_ratio_chunked = false, have_ratio_split = false, split_warm = false;
   char* split_buf = nullptr; size_t split_bytes = 0;
   hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
   double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
@@ -704,7 +704,9 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   const size_t hr_bytes = align_up((size_t)total * H * 2, 256), rm_bytes = align_up((size_t)total * 8, 256);
   const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 16;
   const size_t need = hr_bytes + rm_bytes + align_up(n_ctr * 4, 256);
+  if (!h->split_warm) { h->meas_armed = false; h->split_warm = true; }       // a handle's first split pass loads kernels: not a measurement
   if (need > h->split_bytes) {                      // outside the steady state: a bigger pass than any before
+    h->meas_armed = false;                          // ... and the allocation sits inside the timed window
     HIPCHK(hipStreamSynchronize(s));
     if (h->split_buf) (void)hipFree(h->split_buf);
     h->split_buf = nullptr; h->split_bytes = 0;
@@ -875,12 +877,14 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
         h->split_seen_lens.assign(lens, lens + n_clips); h->split_seen_key = key;
       }
       if (eligible) {
+        // learning order: a chunked pass first (the handle's very first call does not count: kernels are still being loaded, and it ran
+        // before the placement was known), then a split trial if the model says it is close, then the corrected comparison
         const double es = h->split_seen_est_s * h->ratio_split, ec = h->split_seen_est_c * h->ratio_chunked;
-        if (!h->have_ratio_split) split_r = es < 1.05 * ec ? r_try : 0;       // never timed here: worth a trial when the model says it is close
-        else if (!h->have_ratio_chunked) split_r = 0;                          // time the chunked pass once, too
+        if (!h->have_ratio_chunked) split_r = 0;
+        else if (!h->have_ratio_split) split_r = es < 1.05 * ec ? r_try : 0;
         else split_r = es < 0.98 * ec ? r_try : 0;
       }
-      if (!h->meas_pending) {                   // time this call (one measurement in flight at a time)
+      if (eligible && !h->meas_pending) {       // time this call (one measurement in flight at a time)
         h->meas_armed = true; h->meas_mode = split_r > 0 ? 1 : 0;
         h->meas_est = split_r > 0 ? h->split_seen_est_s : h->split_seen_est_c;
         HIPCHK(hipEventRecord(h->ev_meas[0], s));
