@@ -133,7 +133,7 @@ struct prego_miniroad {
   int split_r = 0; int plan_force_slots = 0;
   int split_env = -1;           // PREGO_SPLIT_PASS at create: -1 unset = decide per call (cost model), 0 = never, R = whenever a call is eligible
   double plan_cost_us = 0;      // recurrence cost estimate of the cached plan (kStepCost tables)
-  std::vector<int32_t> split_seen_lens; int split_seen_key = -1; double split_seen_est_c = 0, split_seen_est_s = 0;   // the last estimates (same clips, same call shape)
+  std::vector<int32_t> split_seen_lens; int split_seen_key = -1, split_seen_r = 3; double split_seen_est_c = 0, split_seen_est_s = 0;   // the last estimates (same clips, same call shape)
   // the cost model is corrected by what passes of either kind actually took on THIS device (devices of one pool differ: a sustained
   // split pass runs its GEMM tiles 35 % slower on some, where it then loses to the chunked pass): measured / estimated, per kind
   hipEvent_t ev_meas[2] = {nullptr, nullptr}; bool meas_pending = false, meas_armed = false; int meas_mode = 0; double meas_est = 0;
@@ -831,7 +831,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   {
     long long frames = 0;
     for (int i = 0; i < n_clips; ++i) frames += lens[i] > 0 ? lens[i] : 0;
-    const int r_try = h->split_env > 0 ? h->split_env : 3;
+    int r_try = h->split_env > 0 ? h->split_env : 3;       // unset: the candidate with the best estimate (below); 3 until estimated
     const bool with_flow_ = flow != nullptr && h->d_flow > 0 && flow[0] != nullptr;
     // everything but the placement (which a handle's first, chunked, call establishes)
     const bool shape_ok = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
@@ -871,11 +871,19 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
         const RowBytes rb0 = row_bytes(h, with_flow_, flags);
         const double chunk_rows = std::max(1.0, (double)((workspace_bytes - 12 * 256) / rb0.total));
         h->split_seen_est_c = h->plan_cost_us * 1e-3 + frames * (gemm_ns + 3.0) * 1e-6 + 0.03 * std::ceil(frames / chunk_rows);
-        rc0 = build_plan(h, n_clips, lens, false, 0, 16 * r_try);
-        if (rc0) return rc0;
-        h->split_seen_est_s = std::max(h->t_max * 2.0e-3, frames * (gemm_ns + pack_ns + 1.5) * 1e-6 * 8.0 / (8 - r_try)) + 1.5;
+        // how many XCDs for the recurrence: more slots shorten it (steps = frames / 16 R once every slot is busy), fewer XCDs lengthen the
+        // feed-forward: R = 3 balances the rgb + flow workload, a zero-flow call (half of layer1's K) is better off with R = 4
+        h->split_seen_est_s = 1e30; h->split_seen_r = r_try;
+        for (int r = 3; r <= 4; ++r) {
+          if (n_clips < 16 * r || !split_workspace_ok(h, r, workspace_bytes)) continue;
+          rc0 = build_plan(h, n_clips, lens, false, 0, 16 * r);
+          if (rc0) return rc0;
+          const double e = std::max(h->t_max * 2.0e-3, frames * (gemm_ns + pack_ns + 1.5) * 1e-6 * 8.0 / (8 - r)) + 1.5;
+          if (e < h->split_seen_est_s) { h->split_seen_est_s = e; h->split_seen_r = r; }
+        }
         h->split_seen_lens.assign(lens, lens + n_clips); h->split_seen_key = key;
       }
+      r_try = h->split_seen_r;
       if (eligible) {
         // learning order: a chunked pass first (the handle's very first call does not count: kernels are still being loaded, and it ran
         // before the placement was known), then a split trial if the model says it is close, then the corrected comparison
