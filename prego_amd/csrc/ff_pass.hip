@@ -66,7 +66,10 @@ __device__ __forceinline__ bool ffp_wait_ge(const unsigned* p, unsigned need, un
 template <typename OT, bool SC1OUT>
 __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ A, int lda, int rows, const bf16_t* __restrict__ B, int ldb,
                                          const float* __restrict__ bias, bf16_t* __restrict__ C, int ldc, int K) {
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));       // opaque per call: the lane-derived addresses below must not be hoisted out of the job loop (they would
+                                      // be ~20 VGPRs alive across every job, spilled around the K loop)
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wc = wave & 3;
   const int nk = K / FBK;
@@ -205,7 +208,9 @@ __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ 
 // the first conversion.
 template <typename OT>
 __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));      // per call (see ffp_tile): nothing lane-derived is carried across the job loop
+  const int lane = tid_ & 63, wave = tid_ >> 6;
   const int din = a.kx;
   const int rl = wave * 32 + (lane & 31);                       // my row of the unit (lanes 32 .. 63 mirror 0 .. 31)
   int clip = 0, t = 0;
@@ -277,7 +282,9 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
 // rows of a wave in flight together (a lone row is three dependent round trips: load, two wave reductions)
 template <typename OT, int MAXV, int NR>
 __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));      // per call (see ffp_tile)
+  const int lane = tid_ & 63, wave = tid_ >> 6;
   const int E = a.E, nv = E / 512;
   for (int rb = wave; rb < nrows; rb += 8 * NR) {
     float v[NR][MAXV][8];
@@ -348,11 +355,14 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   // workgroups that run side by side share a weight slab (read once from the fabric, sg - 1 times from this XCD's L2) and each unit's A rows
   const int sg = a.sg, tpr = sg * (2 + a.nt1 + a.nt2);
   const int n_rounds = (n_q + sg - 1) / sg + a.lag3;
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = 0, st_t0 = 0;
+  // job-time sums (debug): kept in LDS, touched by thread 0 only - in registers they would be 22 VGPRs alive across the GEMM tiles
+  __shared__ unsigned long long s_stat[11];                      // [0..7] sums, [8] last stamp, [9] first stamp, [10] first shader-clock stamp
   const bool stats = a.stats != nullptr && tid == 0;
-  unsigned long long st_c0 = 0;
-  if (stats) { st_t0 = __builtin_amdgcn_s_memrealtime(); st_t = st_t0; st_c0 = __builtin_amdgcn_s_memtime(); }
-#define FSTAT(i) do { if (stats) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); st_acc[i] += n_ - st_t; st_t = n_; } } while (0)
+  if (stats) {
+    for (int e = 0; e < 8; ++e) s_stat[e] = 0;
+    s_stat[9] = __builtin_amdgcn_s_memrealtime(); s_stat[8] = s_stat[9]; s_stat[10] = __builtin_amdgcn_s_memtime();
+  }
+#define FSTAT(i) do { if (stats) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); s_stat[i] += n_ - s_stat[8]; s_stat[8] = n_; } } while (0)
   for (;;) {
     __syncthreads();                                                         // s_job of the previous iteration has been read
     if (tid == 0) s_job[0] = (int)__hip_atomic_fetch_add(a.tick + q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -422,9 +432,9 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
     }
   }
   if (stats) {                               // debug (PREGO_SPLIT_STATS=1): 10 ns ticks summed over the feed-forward workgroups
-    st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_t0;
-    st_acc[6] = __builtin_amdgcn_s_memtime() - st_c0;          // shader-clock cycles over the same span: [6] / [7] x 100 MHz = this XCD's clock
-    for (int e = 0; e < 8; ++e) atomicAdd(a.stats + e, st_acc[e]);
+    s_stat[7] = __builtin_amdgcn_s_memrealtime() - s_stat[9];
+    s_stat[6] = __builtin_amdgcn_s_memtime() - s_stat[10];     // shader-clock cycles over the same span: [6] / [7] x 100 MHz = this XCD's clock
+    for (int e = 0; e < 8; ++e) atomicAdd(a.stats + e, s_stat[e]);
   }
 #undef FSTAT
 }

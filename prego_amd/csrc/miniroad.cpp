@@ -839,6 +839,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                           frames < (1ll << 31) - 65536 && (out || argmax) && split_workspace_ok(h, r_try, workspace_bytes) &&
                           (h->d_rgb > 0 ? h->d_rgb : h->d_flow) >= 128 &&
                           (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
+    // a call of this class is worth one wait for the placement word of an earlier launch (the handle's second call otherwise races it)
+    if (shape_ok && h->placement < 0 && h->place_pending) { (void)hipEventSynchronize(h->ev_place); refresh_placement(h); }
     const bool eligible = shape_ok && h->placement == 1;
     if (eligible && h->split_env > 0) split_r = r_try;
     else if (shape_ok) {
