@@ -142,6 +142,34 @@ def test_config1_overlap_worker_is_bit_identical_to_the_serial_pass():
         assert torch.equal(aa[i], bb[i])
 
 
+def test_config1_split_pass_is_bit_identical_to_the_chunked_pass():
+    """BASELINE configs[1] at the bench's size (182 ragged clips, 2.3 M frames, rgb + flow): the split pass (recurrence of the whole
+    call on 3 XCDs beside one persistent feed-forward launch on the other 5; what `python bench.py` runs) against the chunked pass of a
+    handle created under PREGO_SPLIT_PASS=0, bit for bit, probabilities and argmax, two split passes in a row."""
+    from prego_amd.workloads import assembly101_eval_lengths
+    cfg = assembly101_cfg()
+    sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
+    lens = assembly101_eval_lengths(seed=20)
+    rgb = [_feat((T, 2048), 50 + i) for i, T in enumerate(lens)]
+    flow = [_feat((T, 2048), 5000 + i) for i, T in enumerate(lens)]
+    m_c = _model(cfg, sd, "fp16")
+    e_c = _with_env("PREGO_SPLIT_PASS", "0", m_c.engine)
+    m_s = _model(cfg, sd, "fp16")
+    e_s = _with_env("PREGO_SPLIT_PASS", "3", m_s.engine)
+    b, bb, _ = e_c.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)
+    e_c.check()
+    assert e_c.pass_info()["mode"] == 0
+    e_s.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)                 # first call: chunked, verifies the placement
+    for _ in range(2):
+        a, aa, _ = e_s.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True)
+        e_s.check()
+        info = e_s.pass_info()
+        assert info["mode"] == 3 and info["slots"] == 48 and info["steps"] <= int(1.01 * sum(lens) / 48) + 1, info   # packed to within 1 % of frames / slots
+        for i in range(len(lens)):
+            assert torch.equal(a[i], b[i]), f"clip {i}: the split pass changed the result"
+            assert torch.equal(aa[i], bb[i])
+
+
 def test_overlap_stays_off_without_a_verified_placement():
     """a handle whose recurrence never verifies the one-group-per-XCD placement (PREGO_GRU_NO_LOCAL=1: no rendezvous at all) must not
     launch the layer1 worker beside a recurrence that then runs full width (round-3 advisor): the host mirrors the kernel's
