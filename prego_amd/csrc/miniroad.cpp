@@ -662,8 +662,9 @@ static void refresh_placement(prego_miniroad* h) {
 
 // ---- split pass ----------------------------------------------------------------------------------------------------------------
 // Geometry: units of 256 packed rows; chunks of 64 units (16 384 rows) are what the two kernels tell each other about; X / Y / E rings
-// of 8 units per feed-forward XCD, a GI ring of 4 chunks.  The rings come out of the caller's workspace (they fit the default one),
-// relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer (the head runs behind the pass).
+// of 24 units (six super-rounds of four) per feed-forward XCD, a GI ring of 256 units = 4 chunks.  The rings come out of the caller's
+// workspace (0.9 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer
+// (the head runs once, behind the pass).
 static const int kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
 static const int kSplitChunkUnitShift = getenv("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(getenv("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
