@@ -278,30 +278,46 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
   }
 }
 
-// LayerNorm + ReLU of nrows 16-bit rows (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order), a wave per row and NR
-// rows of a wave in flight together (a lone row is three dependent round trips: load, two wave reductions)
+// LayerNorm + ReLU of nrows 16-bit rows (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order), a wave per row, NR
+// rows of a wave in flight together and the NEXT NR rows requested before this batch is reduced (a lone row is three dependent round
+// trips - load, two wave reductions - and a persistent workgroup has nobody to hide them behind: 111 us per 256-row job without the prefetch)
 template <typename OT, int MAXV, int NR>
 __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));      // per call (see ffp_tile)
   const int lane = tid_ & 63, wave = tid_ >> 6;
   const int E = a.E, nv = E / 512;
+  u32x4 raw[NR][MAXV], nxt[NR][MAXV];
+  auto request = [&](u32x4 (&dst)[NR][MAXV], int rb) {
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      int r = rb + 8 * e;
+      if (r >= nrows) r = wave < nrows ? wave : 0;              // a missing row repeats an existing one (its result is not stored)
+      const bf16_t* y = Ys + (size_t)r * E;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i)
+        if (i < nv) dst[e][i] = *(const u32x4*)(y + (i * 64 + lane) * 8);
+    }
+  };
+  if (wave < nrows) request(raw, wave);
   for (int rb = wave; rb < nrows; rb += 8 * NR) {
-    float v[NR][MAXV][8];
+    if (rb + 8 * NR < nrows) request(nxt, rb + 8 * NR);
+    // the rows stay in their 16-bit form (raw) and are unpacked where they are used - three times: the fp32 copy of NR rows would be
+    // 32 NR registers on top of the two raw batches
+    auto unpack = [](const u32x4 w, float (&f)[8]) {
+      f[0] = op16<OT>::lo(w[0]); f[1] = op16<OT>::hi(w[0]); f[2] = op16<OT>::lo(w[1]); f[3] = op16<OT>::hi(w[1]);
+      f[4] = op16<OT>::lo(w[2]); f[5] = op16<OT>::hi(w[2]); f[6] = op16<OT>::lo(w[3]); f[7] = op16<OT>::hi(w[3]);
+    };
     float s[NR];
 #pragma unroll
     for (int e = 0; e < NR; ++e) {
-      const int r = rb + 8 * e < nrows ? rb + 8 * e : rb;         // a missing row repeats the first (its result is not stored)
-      const bf16_t* y = Ys + (size_t)r * E;
       s[e] = 0.f;
 #pragma unroll
       for (int i = 0; i < MAXV; ++i)
         if (i < nv) {
-          const u32x4 w = *(const u32x4*)(y + (i * 64 + lane) * 8);
-          const float4 p = make_float4(op16<OT>::lo(w[0]), op16<OT>::hi(w[0]), op16<OT>::lo(w[1]), op16<OT>::hi(w[1]));
-          const float4 q = make_float4(op16<OT>::lo(w[2]), op16<OT>::hi(w[2]), op16<OT>::lo(w[3]), op16<OT>::hi(w[3]));
-          v[e][i][0] = p.x; v[e][i][1] = p.y; v[e][i][2] = p.z; v[e][i][3] = p.w; v[e][i][4] = q.x; v[e][i][5] = q.y; v[e][i][6] = q.z; v[e][i][7] = q.w;
-          s[e] += ((p.x + p.y) + (p.z + p.w)) + ((q.x + q.y) + (q.z + q.w));
+          float f[8];
+          unpack(raw[e][i], f);
+          s[e] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
         }
     }
     float mu[NR], rstd[NR];
@@ -313,8 +329,10 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
 #pragma unroll
       for (int i = 0; i < MAXV; ++i)
         if (i < nv) {
+          float f[8];
+          unpack(raw[e][i], f);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { const float d = v[e][i][k] - mu[e]; qq += d * d; }
+          for (int k = 0; k < 8; ++k) { const float d = f[k] - mu[e]; qq += d * d; }
         }
       rstd[e] = qq;
     }
@@ -330,14 +348,22 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
         for (int e = 0; e < NR; ++e) {
-          float o[8];
+          float f[8], o[8];
+          unpack(raw[e][i], f);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) o[k] = fmaxf((v[e][i][k] - mu[e]) * rstd[e] * gg[k] + bb[k], 0.f);
+          for (int k = 0; k < 8; ++k) o[k] = fmaxf((f[k] - mu[e]) * rstd[e] * gg[k] + bb[k], 0.f);
           uint4 w;
           w.x = op16<OT>::pack2_sat(o[0], o[1]); w.y = op16<OT>::pack2_sat(o[2], o[3]); w.z = op16<OT>::pack2_sat(o[4], o[5]); w.w = op16<OT>::pack2_sat(o[6], o[7]);
           if (rb + 8 * e < nrows) *(uint4*)(Es + (size_t)(rb + 8 * e) * E + c) = w;
         }
       }
+    if (rb + 8 * NR < nrows) {
+#pragma unroll
+      for (int e = 0; e < NR; ++e)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i)
+          if (i < nv) raw[e][i] = nxt[e][i];
+    }
   }
 }
 
