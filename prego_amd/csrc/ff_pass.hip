@@ -204,8 +204,7 @@ __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ 
 
 // rows [row0, row0 + nrows) of the packed feature matrix (pack_rows_kernel's element arithmetic).  A wave owns 32 consecutive rows: lanes
 // 0 .. 31 look their (clip, frame) up side by side (one chain of table reads per wave instead of one per row: a persistent workgroup has
-// no other workgroups to hide that latency behind), then the wave copies four rows at a time with every load of the four in flight before
-// the first conversion.
+// no other workgroups to hide that latency behind), then the wave streams its rows through two register buffers (below).
 template <typename OT>
 __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
   int tid_ = threadIdx.x;
@@ -234,47 +233,56 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
     if (rgb) srgb = (const char*)rgb + (size_t)t * a.d_rgb * es;
     if (flow) sflow = (const char*)flow + (size_t)t * a.d_flow * es;
   }
-  constexpr int PR = 4;                                          // rows of a wave in flight together (PR x 4 chunks x 32 B per lane)
-  for (int rr = 0; rr < 32; rr += PR) {
-    const int r0 = wave * 32 + rr;
-    if (r0 >= nrows) break;
-    const char* pr[PR]; const char* pf[PR];
+  // rounds of PR rows x four 512-column chunks (32 B per lane and chunk), double buffered: round k + 1 is requested before round k is
+  // converted and stored, so the wave always has a round of loads in flight (burst - wait - burst left a persistent workgroup at 28 GB/s)
+  constexpr int PR = 2;
+  const int cpr = (din + 2047) / 2048;                           // column rounds per row batch
+  const int my_rows = nrows - wave * 32 < 32 ? nrows - wave * 32 : 32;
+  const int n_rounds = my_rows > 0 ? ((my_rows + PR - 1) / PR) * cpr : 0;
+  auto issue = [&](u32x4 (&v)[PR][4][2], int k) {
+    const int rr = (k / cpr) * PR, c0 = lane * 8 + (k % cpr) * 2048;
 #pragma unroll
     for (int e = 0; e < PR; ++e) {
-      pr[e] = (const char*)__shfl((unsigned long long)srgb, rr + e, 64);
-      pf[e] = (const char*)__shfl((unsigned long long)sflow, rr + e, 64);
-    }
-    for (int c0 = lane * 8; c0 < din; c0 += 2048) {              // four 512-column chunks of the PR rows per round
-      u32x4 v[PR][4][2];
+      const char* pr_ = (const char*)__shfl((unsigned long long)srgb, rr + e, 64);
+      const char* pf_ = (const char*)__shfl((unsigned long long)sflow, rr + e, 64);
 #pragma unroll
-      for (int e = 0; e < PR; ++e)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int c = c0 + b * 512;
-          const char* src = nullptr;
-          if (c < din && r0 + e < nrows) src = c < a.d_rgb ? (pr[e] ? pr[e] + (size_t)c * es : nullptr) : (pf[e] ? pf[e] + (size_t)(c - a.d_rgb) * es : nullptr);
-          v[e][b][0] = (u32x4){0u, 0u, 0u, 0u}; v[e][b][1] = v[e][b][0];
-          if (src) {
-            v[e][b][0] = __builtin_nontemporal_load((const u32x4*)src);
-            if (!a.in16) v[e][b][1] = __builtin_nontemporal_load((const u32x4*)src + 1);
-          }
+      for (int b = 0; b < 4; ++b) {
+        const int c = c0 + b * 512;
+        const char* src = nullptr;
+        if (c < din && rr + e < my_rows) src = c < a.d_rgb ? (pr_ ? pr_ + (size_t)c * es : nullptr) : (pf_ ? pf_ + (size_t)(c - a.d_rgb) * es : nullptr);
+        v[e][b][0] = (u32x4){0u, 0u, 0u, 0u}; v[e][b][1] = v[e][b][0];
+        if (src) {
+          v[e][b][0] = __builtin_nontemporal_load((const u32x4*)src);
+          if (!a.in16) v[e][b][1] = __builtin_nontemporal_load((const u32x4*)src + 1);
         }
-#pragma unroll
-      for (int e = 0; e < PR; ++e)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int c = c0 + b * 512;
-          if (c < din && r0 + e < nrows) {
-            u32x4 o = v[e][b][0];
-            if (!a.in16) {
-              const u32x4 x = v[e][b][0], y = v[e][b][1];
-              o[0] = op16<OT>::pack2_sat(__uint_as_float(x[0]), __uint_as_float(x[1])); o[1] = op16<OT>::pack2_sat(__uint_as_float(x[2]), __uint_as_float(x[3]));
-              o[2] = op16<OT>::pack2_sat(__uint_as_float(y[0]), __uint_as_float(y[1])); o[3] = op16<OT>::pack2_sat(__uint_as_float(y[2]), __uint_as_float(y[3]));
-            }
-            *(u32x4*)(Xs + (size_t)(r0 + e) * din + c) = o;
-          }
-        }
+      }
     }
+  };
+  auto drain = [&](const u32x4 (&v)[PR][4][2], int k) {
+    const int rr = (k / cpr) * PR, c0 = lane * 8 + (k % cpr) * 2048;
+#pragma unroll
+    for (int e = 0; e < PR; ++e)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = c0 + b * 512;
+        if (c < din && rr + e < my_rows) {
+          u32x4 o = v[e][b][0];
+          if (!a.in16) {
+            const u32x4 x = v[e][b][0], y = v[e][b][1];
+            o[0] = op16<OT>::pack2_sat(__uint_as_float(x[0]), __uint_as_float(x[1])); o[1] = op16<OT>::pack2_sat(__uint_as_float(x[2]), __uint_as_float(x[3]));
+            o[2] = op16<OT>::pack2_sat(__uint_as_float(y[0]), __uint_as_float(y[1])); o[3] = op16<OT>::pack2_sat(__uint_as_float(y[2]), __uint_as_float(y[3]));
+          }
+          *(u32x4*)(Xs + (size_t)(wave * 32 + rr + e) * din + c) = o;
+        }
+      }
+  };
+  u32x4 va[PR][4][2], vb[PR][4][2];
+  if (n_rounds > 0) issue(va, 0);
+  for (int k = 0; k < n_rounds; k += 2) {
+    if (k + 1 < n_rounds) issue(vb, k + 1);
+    drain(va, k);
+    if (k + 2 < n_rounds) issue(va, k + 2);
+    if (k + 1 < n_rounds) drain(vb, k + 1);
   }
 }
 
