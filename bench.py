@@ -589,7 +589,8 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
     flow = [torch.randn((T_, 2048), device=dev, generator=gen).clamp_(min=0) for T_ in lens]
     other = "bf16" if head_dtype == "fp16" else "fp16"
     # ... and with split fp16 operands (fp16x2: three fp16 products per product, fp32-class results - the argmax-identical mode)
-    for dt_, n_, warm_ in ((other, 5, 2), ("fp16x2", 4, 1), ("fp32", 2, 1)):
+    # (four warm-up passes for the 16-bit type: a fresh handle times its chunked pass and a split trial before it settles, DESIGN 5b "When")
+    for dt_, n_, warm_ in ((other, 5, 4), ("fp16x2", 4, 1), ("fp32", 2, 1)):
         mx = build_model(assembly101_cfg(compute_dtype=dt_), dev)
         mx.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         mx.eval()
@@ -598,6 +599,7 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
         eng.check()
         res[f"value_{dt_}"] = sum(lens) / ms * 1e3
         res[f"{dt_}_pass_ms"] = ms
+        res[f"{dt_}_pass_mode"] = eng.pass_info()["mode"]          # 0 chunked, R = split pass on R XCDs
         del mx, eng
         torch.cuda.empty_cache()
     return res
