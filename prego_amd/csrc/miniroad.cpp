@@ -680,6 +680,26 @@ static SplitRings split_rings(const prego_miniroad* h, int R) {
 }
 static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_bytes) { return workspace_bytes >= split_rings(h, R).total; }
 
+// handle-owned buffer of a split pass: relu(h) rows | row map | counters.  Grown outside the steady state; false = the device has no room
+// (the caller then keeps the chunked pass)
+static size_t split_buf_need(const prego_miniroad* h, long long total) {
+  const long long n_units = (total + 255) / 256;
+  const long long n_chunks = (n_units + (1 << kSplitChunkUnitShift) - 1) >> kSplitChunkUnitShift;
+  return align_up((size_t)total * h->hid * 2, 256) + align_up((size_t)total * 8, 256) + align_up(((size_t)4 * n_units + 2 * (size_t)n_chunks + 16) * 4, 256);
+}
+static bool split_reserve(prego_miniroad* h, long long total, hipStream_t s, bool* grew) {
+  const size_t need = split_buf_need(h, total);
+  *grew = false;
+  if (need <= h->split_bytes) return true;
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  if (h->split_buf) (void)hipFree(h->split_buf);
+  h->split_buf = nullptr; h->split_bytes = 0;
+  if (hipMalloc((void**)&h->split_buf, need + need / 8) != hipSuccess) { (void)hipGetLastError(); h->split_buf = nullptr; return false; }
+  h->split_bytes = need + need / 8;
+  *grew = true;
+  return true;
+}
+
 // Split passes of DIFFERENT handles on one device must not interleave: handle A's feed-forward launch resident on XCDs R .. 7 with handle
 // B's recurrence launch resident on XCDs 0 .. R - 1 wait for each other's partner, which can never be dispatched (bounded, but both calls
 // are lost).  Every split pass therefore starts behind the end of the previous one on the device, whatever handle / stream it came from.
@@ -704,16 +724,10 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   // handle-owned: relu(h) of every packed row, the row map, the counters
   const size_t hr_bytes = align_up((size_t)total * H * 2, 256), rm_bytes = align_up((size_t)total * 8, 256);
   const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 16;
-  const size_t need = hr_bytes + rm_bytes + align_up(n_ctr * 4, 256);
   if (!h->split_warm) { h->meas_armed = false; h->split_warm = true; }       // a handle's first split pass loads kernels: not a measurement
-  if (need > h->split_bytes) {                      // outside the steady state: a bigger pass than any before
-    h->meas_armed = false;                          // ... and the allocation sits inside the timed window
-    HIPCHK(hipStreamSynchronize(s));
-    if (h->split_buf) (void)hipFree(h->split_buf);
-    h->split_buf = nullptr; h->split_bytes = 0;
-    HIPCHK(hipMalloc((void**)&h->split_buf, need + need / 8));
-    h->split_bytes = need + need / 8;
-  }
+  bool grew = false;
+  if (!split_reserve(h, total, s, &grew)) return fail(PREGO_EHIP, "split pass: no device memory for %zu B of relu(h) rows", split_buf_need(h, total));
+  if (grew) h->meas_armed = false;                  // the allocation sat inside the timed window
   char* HR = h->split_buf;
   char* RM = HR + hr_bytes;
   unsigned* ctr = (unsigned*)(RM + rm_bytes);
@@ -901,6 +915,13 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
         HIPCHK(hipEventRecord(h->ev_meas[0], s));
       }
     }
+  }
+  if (split_r > 0) {                                 // the pass keeps relu(h) of every frame: make room now, or stay chunked for good
+    long long frames_ = 0;
+    for (int i = 0; i < n_clips; ++i) frames_ += lens[i];
+    bool grew_ = false;
+    if (!split_reserve(h, frames_, s, &grew_)) { split_r = 0; h->split_env = 0; h->meas_armed = false; }
+    else if (grew_) h->meas_armed = false;
   }
   h->split_r = split_r;
   int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes, split_r > 0 ? 16 * split_r : 0);
