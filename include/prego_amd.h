@@ -10,7 +10,9 @@
  *    (`prego_stream_t` is a `hipStream_t` passed as void*; NULL = the default stream).
  *  - every pointer called "device" is HBM memory of the current HIP device, fp32, row-major contiguous.
  *  - functions return 0 on success, a negative PREGO_E* code otherwise; prego_last_error() gives the text.
- *  - calls only enqueue work on the caller's stream; nothing synchronises except prego_miniroad_check().
+ *  - calls only enqueue work on the caller's stream; nothing waits for the END of device work except prego_miniroad_check().  One
+ *    documented wait for a START: a prego_miniroad_forward() that runs the split pass returns once the stream has reached its two
+ *    persistent launches and they have confirmed each other resident (normally at once; behind earlier work of the stream otherwise).
  *  - the caller owns inputs, outputs and the workspace; they must stay valid until the stream reaches the
  *    end of the call.  The handle owns converted weight copies, the plan tables (pre-sized at create for clips of up to
  *    131 072 frames: forward() allocates nothing below that) and a pinned staging buffer for the per-call pointer tables
@@ -30,8 +32,12 @@ extern "C" {
 /* 1: round 1.  2: round 2 entry points (step, adamw, vit, attention layer, window vote) and the grown forward workspace.
  * 3: round 3 (fp16 operand mode, device AP, window_vote marks windows with an id outside [0, n_classes) as -1).
  * 4: round 4 (PREGO_F16X2 split-operand mode; the prego_debug_* / _debug_stamps entry points left this header and the product library:
- *    prego_amd_debug.h / libprego_amd_debug.so). */
-#define PREGO_ABI_VERSION 5
+ *    prego_amd_debug.h / libprego_amd_debug.so).
+ * 5: round 4, later (prego_miniroad_pass_info; the split pass behind prego_miniroad_forward).
+ * 6: round 5 (no new entry point; behaviour: a forward() that runs the split pass returns once its two launches have met - see
+ *    prego_miniroad_forward -, a pass that cannot run side by side is re-run chunked inside the same call instead of being reported as
+ *    PREGO_ETIMEOUT by prego_miniroad_check; tuning environment knobs are read by the debug library only). */
+#define PREGO_ABI_VERSION 6
 
 enum {
   PREGO_OK = 0,
@@ -104,7 +110,11 @@ size_t prego_miniroad_workspace_bytes(const prego_miniroad* h, int n_clips, cons
  *   argmax[i]          device int32 [lens[i]]: np.argmax(prob, axis=1) of eval.py:53, first max wins; nullable
  *   h0 / h_last        device fp32 [n_clips, hid] GRU state before frame 0 / after the last frame of each clip;
  *                      NULL h0 = zeros (rnn.py:49,60).  Chaining h_last -> h0 gives streaming inference.
- * The pointer arrays themselves are host arrays (copied during the call). */
+ * The pointer arrays themselves are host arrays (copied during the call).
+ * Which pass runs (prego_miniroad_pass_info reports it) is the library's choice per call and never changes a result bit.  The split pass
+ * needs its two persistent launches resident together: they start with a bounded handshake, the call returns once it has succeeded, and
+ * if it fails (a profiler that serialises kernel dispatches, another tenant holding the XCDs) both launches leave before either has
+ * written anything and THIS call runs the chunked pass instead - no call is ever lost to the choice of pass. */
 int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* rgb,
                            const float* const* flow, float* const* out, int32_t* const* argmax, const float* h0,
                            float* h_last, int flags, void* workspace, size_t workspace_bytes,
@@ -327,18 +337,16 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
                                    float* const* grads, int n_tensors, void* workspace, size_t workspace_bytes,
                                    prego_stream_t stream);
 
-/* Environment knobs the library reads (each ONCE, when a handle is created or a launcher is first used; none is needed in
- * production, every one selects between two code paths that both stay tested - DESIGN.md section 6 says what each measured):
- *   PREGO_NO_XCD_OVERLAP, PREGO_OVERLAP_NARROW, PREGO_OVERLAP_MAX_GD, PREGO_GRU_COMPACT   layer1 worker on the XCDs the recurrence left
- *   PREGO_GRU_NO_MT, PREGO_GRU_MT_SPEC, PREGO_GRU_NO_LOCAL, PREGO_GRU_STAMPS, PREGO_NO_ARM_FUSE   recurrence kernel choice / hand-off
- *   PREGO_NO_PACK_PREFETCH, PREGO_PACK_PREFETCH_GRID, PREGO_PACK_EARLY, PREGO_SIDE_PRIO    where / on what stream the next chunk's pack runs
- *   PREGO_PLAN_SLOTS, PREGO_FP32_INTERMEDIATES                                             planner calibration, fp32 Y / GI in 16-bit modes
- *   PREGO_SPLIT_PASS (0 = never, R = on R XCDs whenever a call is eligible; unset = per-call cost model), PREGO_SPLIT_LAG1/2/3,
- *   PREGO_SPLIT_CHUNK_SHIFT, PREGO_SPLIT_STATS                                             split pass: forcing, job lags, chunk size, job-time sums
- *   PREGO_GEMM_NO_PINGPONG, PREGO_GEMM_NO_BIG, PREGO_HEAD_V1, PREGO_BPTT_STEPWISE, PREGO_STEP_NO_LN_FUSE, PREGO_VIT_TOKENS_KERNEL,
- *   PREGO_ATTN_NW                                                                          older kernels kept as A/B references
- * The probe / unit-test entry points (prego_debug_*, prego_miniroad_debug_stamps) are NOT part of this library: they are declared in
- * prego_amd_debug.h and exist only in libprego_amd_debug.so (the same sources built with -DPREGO_DEBUG_ABI). */
+/* Environment switches THIS library reads (each once, when a handle is created; none is needed in production).  Four, each between two
+ * code paths that the driver-run GPU tests hold bit-identical to each other:
+ *   PREGO_SPLIT_PASS      0 = never the split pass, R = on R XCDs whenever a call is eligible; unset = per call (cost model)   tests/test_gpu_split.py
+ *   PREGO_NO_XCD_OVERLAP  no layer1 worker on the XCDs a thinned-out recurrence has left (the serial chunked pass)            tests/test_gpu_fullsize.py
+ *   PREGO_GRU_NO_LOCAL    never the XCD-local hand-off of the recurrence (sc1 stores / loads everywhere)                      tests/test_gpu_miniroad.py
+ *   PREGO_GRU_NO_MT       multi-tile steps on the classic recurrence kernel                                                   tests/test_gpu_fullsize.py
+ * Every tuning / calibration / diagnostic knob (PREGO_SPLIT_LAG1..3, PREGO_SPLIT_CHUNK_SHIFT, PREGO_SPLIT_STATS, PREGO_PLAN_SLOTS,
+ * PREGO_SIDE_PRIO, PREGO_PACK_*, PREGO_GRU_STAMPS, PREGO_GRU_MT_SPEC, PREGO_GEMM_NO_*, PREGO_HEAD_V1, PREGO_ATTN_NW, ...) is read by
+ * libprego_amd_debug.so ONLY (csrc/kernels.h: prego_tune_env returns NULL in this library), like the probe / unit-test entry points
+ * (prego_debug_*, prego_miniroad_debug_stamps: include/prego_amd_debug.h; the same sources built with -DPREGO_DEBUG_ABI). */
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,19 @@ int prego_debug_recurrence_only(prego_miniroad* h, int n_slots, int n_steps, int
 int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, float* C, int M, int N, int K, int xcd_lo,
                             unsigned* counter, int grid, prego_stream_t stream);
 
+/* The split pass's start handshake (DESIGN 5b "fail-safe") under test, and the replay entries counter collection needs.  One shot: applies
+ * to the NEXT split pass of the handle.
+ *   mode 1: the recurrence launch is withheld - the feed-forward launch's handshake wait runs out, it leaves without having written anything
+ *           and prego_miniroad_forward re-runs the call as a chunked pass (tests/test_gpu_split.py)
+ *   mode 2: the feed-forward launch is withheld (the recurrence's leader gives up; same outcome)
+ *   mode 3: ONLY the feed-forward launch, handshake pre-decided and the recurrence's chunk counters pre-armed: the launch runs alone at full
+ *           length (rocprofv3 --pmc serialises dispatches, so the pair can never be profiled together).  No head, outputs untouched
+ *   mode 4: ONLY the recurrence launch on whatever (finite) rows an earlier pass left in the GI ring; no head, outputs untouched
+ * split_state: fallbacks = calls re-run chunked behind a failed handshake, fails = failed handshakes (3 = chunked for good),
+ * skip = eligible calls still to be kept chunked by the back-off, split_env = the handle's PREGO_SPLIT_PASS state (-1 auto, 0 never, R). */
+int prego_debug_split_fault(prego_miniroad* h, int mode);
+int prego_debug_split_state(const prego_miniroad* h, int64_t* fallbacks, int32_t* fails, int64_t* skip, int32_t* split_env);
+
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */
 int prego_debug_gemm_bf16(int variant, const void* A, const void* B, const float* bias, float* C, int M, int N, int K,

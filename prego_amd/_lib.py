@@ -39,7 +39,8 @@ SYMBOLS = [
 ]
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
 DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
-                 "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only"]
+                 "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
+                 "prego_debug_split_fault", "prego_debug_split_state"]
 
 
 class PregoError(RuntimeError):
@@ -139,6 +140,8 @@ def _open(path: str, debug: bool) -> C.CDLL:
         lib.prego_debug_recurrence_only.argtypes = [vp, i32, i32, i32, vp, vp, vp]
         lib.prego_debug_gemm_worker.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]
         lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
+        lib.prego_debug_split_fault.argtypes = [vp, i32]
+        lib.prego_debug_split_state.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
     return lib
 
 

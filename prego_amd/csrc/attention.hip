@@ -299,7 +299,7 @@ int launch_flash_attention_v2(const void* Q, const void* K, const void* V, void*
   if (!drop_thresh) drop_scale = 1.f;
   // long sequences: 8 waves x 16 queries (two waves per SIMD: one wave's softmax and LDS waits hide under the other's MFMAs);
   // 129-token windows: 4 waves x 16 queries = 3 x 64 query slots instead of 2 x 128
-  static const int nw_env = getenv("PREGO_ATTN_NW") ? atoi(getenv("PREGO_ATTN_NW")) : 0;      // A/B knob: 4 = round-2 shape (4 waves x 32 queries)
+  static const int nw_env = prego_tune_env("PREGO_ATTN_NW") ? atoi(prego_tune_env("PREGO_ATTN_NW")) : 0;      // A/B knob: 4 = round-2 shape (4 waves x 32 queries)
   const bool longq = Nq > 192;
   const int nw = nw_env == 4 ? 4 : (nw_env == 8 ? 8 : (longq ? 8 : 4));
   const int qg = longq && nw == 4 ? 2 : 1;

@@ -26,13 +26,17 @@
 // running tile stream its own 2 MB slab over the fabric: 0.7 TB/s per XCD, and the pass ran at half the chunked GEMM rate).
 // Tickets are claimed in order by resident workgroups that run every job to completion, so a wait can only be for a job that is
 // already running.
-// Every wait is bounded (2 s of s_memrealtime): a timeout raises the abort word that ends both kernels (no hung GPU).
+// Both launches start with a bounded HANDSHAKE (kernels.h: PassHandshake): no job runs before the recurrence is known to be resident
+// beside this kernel, so a pass that cannot run concurrently ends before it has written anything.  Every later wait is bounded too
+// (2 s of s_memrealtime: a timeout raises the abort word that ends both kernels - no hung GPU), but behind a successful handshake every
+// producer of every wait is resident and running.
 //
 // Arithmetic: the tile loop is the ping-pong K loop of gemm_pp.hip (same fragment order, same MFMA order), the row jobs are the
 // bodies of pack_rows_kernel / ln_relu_rows_kernel (rowwise.hip) on a wave per row: every GI element is bit-identical to the
 // chunked pass.
 #include "common.h"
 #include "kernels.h"
+#include "pass_handshake.h"
 
 #define FBK 64
 #define FHALF 16384
@@ -382,6 +386,14 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   const int tid = threadIdx.x;
   const int xcc = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);           // HW_REG_XCC_ID
   if (xcc < a.xcd_lo) return;                                                // the recurrence's XCDs
+  // start handshake (kernels.h: PassHandshake): nothing is read or written before the recurrence's leader has seen both launches resident;
+  // a bounded wait that runs out ends BOTH launches before either has touched memory (the host then runs the chunked pass)
+  if (tid == 0) {
+    __hip_atomic_fetch_add(a.hs.ff_here + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_job[1] = hs_wait(a.hs, a.hs.ticks_all) == PREGO_HS_GO ? 1 : 0;
+  }
+  __syncthreads();
+  if (!__builtin_amdgcn_readfirstlane(s_job[1])) return;
   const int q = xcc - a.xcd_lo, nf = 8 - a.xcd_lo;
   const int n_q = a.n_units > q ? (a.n_units - q + nf - 1) / nf : 0;         // units of this XCD: q, q + nf, ...
   // ticket k = job (k mod T) of super-round (k div T), T = sg (2 + nt1 + nt2): the sg units of a super-round go through each job kind

@@ -349,7 +349,7 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
                              int N, int K, GemmEpi epi, hipStream_t s) {
   if (M <= 0) return;
   // whole-chip shapes: the 256x256 ping-pong kernel carries the same epilogues with 16-byte accesses (gemm_pp.hip)
-  static const bool no_pp = getenv("PREGO_GEMM_NO_PINGPONG") != nullptr;
+  static const bool no_pp = prego_tune_env("PREGO_GEMM_NO_PINGPONG") != nullptr;
   if (M >= 4096 && !no_pp) {
     void* cdst = epi.mode == EPI_STORE_BF16 ? epi.out_b : (void*)C;
     if (launch_gemm_bf16_pingpong_epi(A, lda, B, ldb, bias, cdst, ldc, M, N, K, epi, s) == 0) return;
@@ -397,9 +397,9 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
     launch_gemm_bf16_nt_epi(A, lda, B, ldb, bias, C, ldc, M, N, K, e16, s);
     return;
   }
-  static const bool no_big = getenv("PREGO_GEMM_NO_BIG") != nullptr;
+  static const bool no_big = prego_tune_env("PREGO_GEMM_NO_BIG") != nullptr;
   if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles: ping-pong 8-phase schedule with 16-byte stores (gemm_pp.hip)
-    static const bool no_pp = getenv("PREGO_GEMM_NO_PINGPONG") != nullptr;      // A/B knob: the previous production kernel
+    static const bool no_pp = prego_tune_env("PREGO_GEMM_NO_PINGPONG") != nullptr;      // A/B knob: the previous production kernel
     if (no_pp || launch_gemm_bf16_pingpong(A, lda, B, ldb, bias, C, ldc, M, N, K, s) != 0)
       launch_gemm_bf16_experimental(9, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
     return;

@@ -38,6 +38,7 @@
 //  * every spin is bounded; a timeout raises an abort word that ends the launch (no hung GPU).
 #include "common.h"
 #include "kernels.h"
+#include "pass_handshake.h"
 #include <cstdlib>
 
 #define SPIN_LIMIT (1u << 22)
@@ -98,9 +99,35 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const bool compact_ok = a.sync != nullptr && a.G == 8 && gridDim.x == 8 * P && a.Gd > 0 && a.Gd < a.G &&
                             __hip_atomic_load(a.sync + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u;
     s_place[3] = compact_ok ? 1 : 0;
-    if (PASS && !compact_ok) {                 // a pass launch shares the device with the feed-forward kernel: never full width
-      __hip_atomic_store(a.abort_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      loc = -1;
+    if constexpr (PASS) {
+      // pass launch: shares the device with the feed-forward kernel (never full width), and starts with the handshake of kernels.h:
+      // no workgroup proceeds before the leader (XCD 0's first ticket) has seen exactly-P-workgroups on each of the Gd recurrence XCDs
+      // and a feed-forward workgroup on each of the others; every wait is bounded and a FAIL ends both launches before they wrote anything
+      if (!compact_ok) { hs_decide(a.hs, PREGO_HS_FAIL); loc = -1; }
+      else {
+        const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
+        if (xcc >= a.Gd) loc = -2;
+        else {
+          const unsigned ticket = __hip_atomic_fetch_add(a.sync + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ticket >= (unsigned)P) hs_decide(a.hs, PREGO_HS_FAIL);            // more than P workgroups on one XCD: not the verified placement
+          else if (xcc == 0 && ticket == 0u) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+              bool all = true;
+              for (int x = 0; x < 8; ++x) {
+                const unsigned v = __hip_atomic_load(x < a.Gd ? a.sync + x : a.hs.ff_here + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && v >= (x < a.Gd ? (unsigned)P : 1u);
+              }
+              if (all) { hs_decide(a.hs, PREGO_HS_GO); break; }
+              if (__hip_atomic_load(a.hs.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+              if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)a.hs.ticks_lead) { hs_decide(a.hs, PREGO_HS_FAIL); break; }
+              __builtin_amdgcn_s_sleep(16);
+            }
+          }
+          if (hs_wait(a.hs, a.hs.ticks_all) == PREGO_HS_GO && ticket < (unsigned)P) { loc = 1; gg = xcc; ww = (int)ticket; }
+          else loc = -1;
+        }
+      }
     } else
     if (compact_ok) {
       // compacted launch (a.Gd groups; probe of DESIGN 5c): the rendezvous is per XCD - a workgroup on an XCD without a group leaves
@@ -1059,7 +1086,7 @@ int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s)
   // (a caller-chosen chunk of a million rows) stay on the classic kernel and its 64-bit addressing
   const bool rows_ok = a.rows > 0 && (long long)a.rows * hid * 2 < (1ll << 31) - 65536;
   if (bf16 && a.gi_bf16 && nct >= 2 && nct <= 4 && !train && !no_mt && stamps_ok && rows_ok) {
-    static const int spec_env = getenv("PREGO_GRU_MT_SPEC") ? atoi(getenv("PREGO_GRU_MT_SPEC")) : -1;     // A/B: tag check inside (1) / before (0) the multiply
+    static const int spec_env = prego_tune_env("PREGO_GRU_MT_SPEC") ? atoi(prego_tune_env("PREGO_GRU_MT_SPEC")) : -1;     // A/B: tag check inside (1) / before (0) the multiply
     const bool spec = spec_env >= 0 ? spec_env != 0 : nct >= 3;
     // reduction buffers + two gather images per wave + the gi rows of two steps
     const size_t lds = (size_t)2 * 4 * 3 * 2 * 64 * 16 + (size_t)2 * 4 * 8 * 1024 + (size_t)2 * (nct == 2 ? 2 : 4) * 3 * 1024;

@@ -355,7 +355,7 @@ int launch_head_softmax(bool bf16, const void* Hrelu, const void* Wc, const floa
                         float* const* out_ptrs, int* const* argmax_ptrs, hipStream_t s, const void* rowmap, bool f16) {
   if (nrows <= 0) return 0;
   const int ntc = (C + 15) / 16;
-  static const bool no_v2 = getenv("PREGO_HEAD_V1") != nullptr;                // A/B knob
+  static const bool no_v2 = prego_tune_env("PREGO_HEAD_V1") != nullptr;                // A/B knob
   if (bf16 && hid == 1024 && ntc <= 6 && !no_v2) {     // the register-resident form, for EVERY size: a row's result must not depend on the batch
     const int nblk = (nrows + 31) / 32;
     const int grid2 = nblk < 256 ? nblk : 256;

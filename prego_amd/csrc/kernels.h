@@ -5,6 +5,12 @@
 #include <stdint.h>
 #include <mutex>
 
+// Tuning / A-B / diagnostic environment knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_GRU_STAMPS, PREGO_ATTN_NW, ...): only the
+// DEBUG library (libprego_amd_debug.so, -DPREGO_DEBUG_ABI) reads them; in the product library this returns nullptr and every one of
+// them stays at its default.  The product library reads exactly four switches between code paths that are both held by the driver-run
+// tests: PREGO_SPLIT_PASS, PREGO_NO_XCD_OVERLAP, PREGO_GRU_NO_LOCAL, PREGO_GRU_NO_MT (include/prego_amd.h).  Defined in miniroad.cpp.
+const char* prego_tune_env(const char* name);
+
 // One-time per-DEVICE setup at a launch site (hipFuncSetAttribute, symbol addresses): function attributes and __device__
 // symbols belong to the device that was current when they were set / resolved, so a process that drives several GPUs
 // needs them once per device, and the first calls may race between host threads.
@@ -29,6 +35,22 @@ struct SlotPlan {
 };
 #define PREGO_HAVE_SLOTPLAN 1
 #endif
+
+// Start handshake of a split pass (DESIGN 5b "fail-safe"): both persistent launches must be resident TOGETHER, or neither may touch
+// memory.  `word` (device, zeroed per pass) is decided ONCE by compare-and-swap: 1 = GO (the recurrence's leader has seen P workgroups on
+// each of its XCDs and at least one feed-forward workgroup on each of the others), 2 = FAIL (somebody's bounded wait ran out: a
+// dispatch-serialising profiler, another tenant on the XCDs).  Whoever decides also writes (seq << 2) | state to the pinned host word
+// the calling thread polls: on FAIL both launches leave without having written anything and the host runs the chunked pass instead.
+struct PassHandshake {
+  unsigned* word;               // device: 0 undecided, 1 GO, 2 FAIL
+  unsigned* ff_here;            // device [8]: feed-forward workgroups that have started, per XCD
+  unsigned* host;               // pinned host memory, nullable
+  unsigned seq;
+  unsigned ticks_lead;          // s_memrealtime ticks (100 MHz) the recurrence's leader waits for the other launch
+  unsigned ticks_all;           // ... everyone waits for a decision before voting FAIL
+};
+#define PREGO_HS_GO 1u
+#define PREGO_HS_FAIL 2u
 
 struct GruArgs {
   const void* whh;       // [3H][H] bf16 or f32, reference layout of gru.weight_hh_l0 (rows r|z|n)
@@ -63,6 +85,7 @@ struct GruArgs {
   int chunk_shift, n_chunks;
   int units_per_chunk, units_last;   // what gi_cnt[c] must reach (last chunk: units_last)
   unsigned gi_row_mask;
+  PassHandshake hs;            // pass mode only
 };
 // ---- split pass (ff_pass.hip + the PASS instantiation of gru_recurrence.hip): the feed-forward of a whole pass as one persistent
 // kernel on XCDs xcd_lo .. 7 beside one persistent recurrence launch on XCDs 0 .. xcd_lo - 1
@@ -95,6 +118,7 @@ struct FfPassArgs {
   unsigned* gi_cnt;             // [n_chunks] completed units per chunk (read by the recurrence)
   const unsigned* rec_cnt;      // [n_chunks] recurrence waves done with the chunk
   unsigned* abort_word;
+  PassHandshake hs;
 };
 int launch_ff_pass(const FfPassArgs& a, hipStream_t s);
 // the recurrence of a whole pass as one launch on XCDs 0 .. a.Gd - 1 (GruArgs pass fields); 16-bit operands, 16-bit GI ring, one tile

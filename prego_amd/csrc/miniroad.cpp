@@ -9,6 +9,8 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -49,6 +51,15 @@ int prego_fail_(int code, const char* fmt, ...) {
     hipError_t e_ = (x);                                                                            \
     if (e_ != hipSuccess) return fail(PREGO_EHIP, "%s failed: %s", #x, hipGetErrorString(e_));      \
   } while (0)
+
+const char* prego_tune_env(const char* name) {          // kernels.h
+#ifdef PREGO_DEBUG_ABI
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -139,6 +150,10 @@ struct prego_miniroad {
   hipEvent_t ev_meas[2] = {nullptr, nullptr}; bool meas_pending = false, meas_armed = false; int meas_mode = 0; double meas_est = 0;
   double ratio_chunked = 1.0, ratio_split = 1.0; bool have_ratio_chunked = false, have_ratio_split = false, split_warm = false;
   char* split_buf = nullptr; size_t split_bytes = 0;
+  // start handshake of a split pass (kernels.h: PassHandshake): the pinned word the two launches report their GO / FAIL decision in, the
+  // pass counter, and the back-off after a FAIL (the call itself is re-run as a chunked pass: no call is ever lost)
+  unsigned* pin_hs = nullptr; unsigned hs_seq = 0; int split_fails = 0; long long split_skip = 0; long long split_fallbacks = 0;
+  int dbg_fault = 0;            // debug library only (prego_debug_split_fault): what the NEXT split pass does differently, one shot
   hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
   double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
@@ -217,18 +232,18 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->pin_ev, hipEventDisableTiming);
   h->no_local = getenv("PREGO_GRU_NO_LOCAL") != nullptr;
   h->no_mt = getenv("PREGO_GRU_NO_MT") != nullptr;
-  h->pack_prefetch = getenv("PREGO_NO_PACK_PREFETCH") == nullptr;
+  h->pack_prefetch = prego_tune_env("PREGO_NO_PACK_PREFETCH") == nullptr;
   // the pack beside the recurrence slows its L2 hand-off; capped at 512 workgroups it still ends inside a 49 152-row launch and
   // costs the pass 0.9 ms less than unthrottled (sweep: scripts/probes/env_sweep.sh, 128: +10 ms, 256: +1, 512: -0.9, 1024: 0)
   h->prefetch_grid = 512;
-  if (const char* pg = getenv("PREGO_PACK_PREFETCH_GRID")) h->prefetch_grid = atoi(pg);
+  if (const char* pg = prego_tune_env("PREGO_PACK_PREFETCH_GRID")) h->prefetch_grid = atoi(pg);
   // The side stream must run BESIDE the caller's stream.  HIP maps streams onto a handful of hardware queues in creation order and
   // two streams on one queue execute in submission order (round 4: an eval loop whose copy stream shared the compute stream's queue
   // lost all of its overlap), and a queue has one priority: a LOW-priority side stream never shares the queue of a normal-priority
   // caller, and its pack / layer1 worker yield to the recurrence where they compete.  PREGO_SIDE_PRIO=0: the plain stream (A/B).
   if (e == hipSuccess) {
     int lo = 0, hi = 0;
-    static const bool plain = getenv("PREGO_SIDE_PRIO") != nullptr && atoi(getenv("PREGO_SIDE_PRIO")) == 0;
+    static const bool plain = prego_tune_env("PREGO_SIDE_PRIO") != nullptr && atoi(prego_tune_env("PREGO_SIDE_PRIO")) == 0;
     if (!plain && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
       e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo);       // lo = numerically greatest = least priority
     else
@@ -240,13 +255,15 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A((void**)&h->tile_ctr, 4096 * sizeof(unsigned));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin_place, 64, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_place, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->pin_hs, 64, hipHostMallocDefault);
+  if (e == hipSuccess) *(volatile unsigned*)h->pin_hs = 0u;
   if (e == hipSuccess) e = hipEventCreate(&h->ev_meas[0]);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_meas[1]);
   h->xcd_overlap = getenv("PREGO_NO_XCD_OVERLAP") == nullptr;       // A/B knob: PREGO_NO_XCD_OVERLAP=1 = the serial pass of round 2
   if (const char* sp = getenv("PREGO_SPLIT_PASS")) h->split_env = atoi(sp);
   A((void**)&h->st_scratch, (size_t)16 * ((size_t)emb * 6 + (size_t)3 * H * 8));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, 8 * sizeof(unsigned long long));
-  h->use_stamps = getenv("PREGO_GRU_STAMPS") != nullptr;
+  h->use_stamps = prego_tune_env("PREGO_GRU_STAMPS") != nullptr;
   if (e == hipSuccess) e = hipMemset(h->hx, 0, h->x2 ? gru_x2_hx_bytes(H, h->G) : gru_hx_bytes(h->bf16, H, h->G));
   if (e == hipSuccess) e = hipMemset(h->flags, 0, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
   if (e != hipSuccess) { prego_miniroad_destroy(h); return fail(PREGO_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
@@ -270,6 +287,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->ev_place) (void)hipEventDestroy(h->ev_place);
   for (hipEvent_t ev : h->ev_meas) if (ev) (void)hipEventDestroy(ev);
   if (h->pin_place) (void)hipHostFree(h->pin_place);
+  if (h->pin_hs) (void)hipHostFree(h->pin_hs);
   if (h->split_buf) (void)hipFree(h->split_buf);
   delete h;
 }
@@ -390,7 +408,7 @@ static int build_plan(prego_miniroad* h, int n, const int32_t* lens, bool want_s
     return c;
   };
   Cand best;
-  static const int force_slots = getenv("PREGO_PLAN_SLOTS") ? atoi(getenv("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
+  static const int force_slots = prego_tune_env("PREGO_PLAN_SLOTS") ? atoi(prego_tune_env("PREGO_PLAN_SLOTS")) : 0;   // debug / calibration of kStepCost
   if (slots_arg > 0) {                                                    // split pass: one tile on each of its groups
     best = pack(std::min(n, slots_arg));
     // every slot is alive to the end of a split pass, so the pass takes as long as the most loaded slot: LPT leaves it a few percent above
@@ -596,7 +614,7 @@ struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, map, total; };
 // 1.40; the numpy emulation of the whole path moves the worst probability error from 2.0e-3 to 2.5e-3 (tolerance 1e-2).
 // Training keeps them fp32 (LayerNorm backward reads Y).  PREGO_FP32_INTERMEDIATES=1 restores fp32 for A/B.
 static bool inter16(const prego_miniroad* h, int flags) {
-  static const bool force32 = getenv("PREGO_FP32_INTERMEDIATES") != nullptr;
+  static const bool force32 = prego_tune_env("PREGO_FP32_INTERMEDIATES") != nullptr;
   return h->bf16 && !(flags & PREGO_FWD_KEEP) && !force32;
 }
 static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
@@ -666,7 +684,7 @@ static void refresh_placement(prego_miniroad* h) {
 // workspace (0.9 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer
 // (the head runs once, behind the pass).
 static const int kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
-static const int kSplitChunkUnitShift = getenv("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(getenv("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
+static const int kSplitChunkUnitShift = prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
   SplitRings g;
@@ -685,7 +703,7 @@ static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_
 static size_t split_buf_need(const prego_miniroad* h, long long total) {
   const long long n_units = (total + 255) / 256;
   const long long n_chunks = (n_units + (1 << kSplitChunkUnitShift) - 1) >> kSplitChunkUnitShift;
-  return align_up((size_t)total * h->hid * 2, 256) + align_up((size_t)total * 8, 256) + align_up(((size_t)4 * n_units + 2 * (size_t)n_chunks + 16) * 4, 256);
+  return align_up((size_t)total * h->hid * 2, 256) + align_up((size_t)total * 8, 256) + align_up(((size_t)4 * n_units + 2 * (size_t)n_chunks + 32) * 4, 256);
 }
 static bool split_reserve(prego_miniroad* h, long long total, hipStream_t s, bool* grew) {
   const size_t need = split_buf_need(h, total);
@@ -706,9 +724,12 @@ static bool split_reserve(prego_miniroad* h, long long total, hipStream_t s, boo
 static std::mutex g_split_mu;
 static hipEvent_t g_split_last[64] = {};
 
+// *fell_back = true (with PREGO_OK): the start handshake of the two launches failed - they left without writing anything, the caller
+// runs the chunked pass for this call.
 static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bool in16, int kx, const SlotPlan& plan,
                          const float* const* d_rgb_ptrs, const float* const* d_flow_ptrs, float* const* d_out_ptrs, int* const* d_arg_ptrs,
-                         void* workspace, size_t workspace_bytes, hipStream_t s) {
+                         void* workspace, size_t workspace_bytes, hipStream_t s, bool* fell_back) {
+  *fell_back = false;
   const int H = h->hid, E = h->emb, din = h->d_rgb + h->d_flow;
   const int total = h->h_rowoff[h->t_max];
   const int n_units = (total + 255) / 256;
@@ -723,7 +744,7 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   unsigned short* GI = (unsigned short*)wp;
   // handle-owned: relu(h) of every packed row, the row map, the counters
   const size_t hr_bytes = align_up((size_t)total * H * 2, 256), rm_bytes = align_up((size_t)total * 8, 256);
-  const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 16;
+  const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 32;
   if (!h->split_warm) { h->meas_armed = false; h->split_warm = true; }       // a handle's first split pass loads kernels: not a measurement
   bool grew = false;
   if (!split_reserve(h, total, s, &grew)) return fail(PREGO_EHIP, "split pass: no device memory for %zu B of relu(h) rows", split_buf_need(h, total));
@@ -731,10 +752,31 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   char* HR = h->split_buf;
   char* RM = HR + hr_bytes;
   unsigned* ctr = (unsigned*)(RM + rm_bytes);
-  unsigned* tick = ctr; unsigned* pack_done = ctr + 16; unsigned* l1_cnt = pack_done + n_units; unsigned* ln_done = l1_cnt + n_units;
+  unsigned* tick = ctr; unsigned* hs_word = ctr + 8; unsigned* ff_here = ctr + 16; unsigned* pack_done = ctr + 32; unsigned* l1_cnt = pack_done + n_units; unsigned* ln_done = l1_cnt + n_units;
   unsigned* wih_cnt = ln_done + n_units; unsigned* gi_cnt = wih_cnt + n_units; unsigned* rec_cnt = gi_cnt + n_chunks;
   HIPCHK(hipMemsetAsync(ctr, 0, n_ctr * 4, s));
   HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)h->n_slots * H * 4, s));
+  // start handshake (kernels.h: PassHandshake).  Bounds: the two launches are released by the same fork point and start microseconds
+  // apart; 50 / 100 ms leave room for another stream's kernels draining from the CUs first.  A pass that cannot run side by side costs
+  // that long ONCE (the back-off in prego_miniroad_forward keeps the handle chunked afterwards)
+  PassHandshake hs{};
+  h->hs_seq = (h->hs_seq + 1u) & 0x3FFFFFFFu;
+  if (h->hs_seq == 0u) h->hs_seq = 1u;
+  hs.word = hs_word; hs.ff_here = ff_here; hs.host = h->pin_hs; hs.seq = h->hs_seq; hs.ticks_lead = 5000000u; hs.ticks_all = 10000000u;
+  int fault = 0;
+#ifdef PREGO_DEBUG_ABI
+  fault = h->dbg_fault; h->dbg_fault = 0;           // prego_debug_split_fault: one shot
+  if (fault == 3 || fault == 4) {
+    // replay of ONE of the two launches alone (counter collection serialises dispatches, so the pair cannot run under it): the handshake
+    // is pre-decided and the other side's counters pre-armed - the feed-forward launch never waits for a GI ring slot, the recurrence
+    // launch reads whatever finite rows an earlier pass left in the ring.  Same instruction stream and memory traffic, meaningless outputs
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)hs_word, PREGO_HS_GO, 1, s));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)ff_here, 1, 8, s));
+    if (fault == 3) HIPCHK(hipMemsetD32Async((hipDeviceptr_t)rec_cnt, R * h->P * 4, n_chunks, s));
+    else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)gi_cnt, upc, n_chunks, s));
+    hs.host = nullptr;
+  }
+#endif
 
   FfPassArgs fa{};
   fa.rgb_ptrs = d_rgb_ptrs; fa.flow_ptrs = with_flow ? d_flow_ptrs : nullptr; fa.plan = plan; fa.rowmap = RM;
@@ -744,18 +786,18 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = kSplitGiRingUnits;
   fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = kSplitChunkUnitShift;
   fa.rec_expect = R * h->P * 4; fa.nt1 = E / 256; fa.nt2 = 3 * H / 256;
-  static const int lag1 = getenv("PREGO_SPLIT_LAG1") ? atoi(getenv("PREGO_SPLIT_LAG1")) : 2;
-  static const int lag2 = getenv("PREGO_SPLIT_LAG2") ? atoi(getenv("PREGO_SPLIT_LAG2")) : 3;
-  static const int lag3 = getenv("PREGO_SPLIT_LAG3") ? atoi(getenv("PREGO_SPLIT_LAG3")) : 4;
-  static const bool want_stats = getenv("PREGO_SPLIT_STATS") != nullptr;
+  static const int lag1 = prego_tune_env("PREGO_SPLIT_LAG1") ? atoi(prego_tune_env("PREGO_SPLIT_LAG1")) : 2;
+  static const int lag2 = prego_tune_env("PREGO_SPLIT_LAG2") ? atoi(prego_tune_env("PREGO_SPLIT_LAG2")) : 3;
+  static const int lag3 = prego_tune_env("PREGO_SPLIT_LAG3") ? atoi(prego_tune_env("PREGO_SPLIT_LAG3")) : 4;
+  static const bool want_stats = prego_tune_env("PREGO_SPLIT_STATS") != nullptr;
   fa.sg = kSplitSg; fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
   fa.stats = want_stats ? h->stamps : nullptr;
 #ifdef PREGO_DEBUG_ABI
-  static const int dbg = getenv("PREGO_SPLIT_DBG") ? atoi(getenv("PREGO_SPLIT_DBG")) : 0;     // timing experiments (wrong results): debug library only
+  static const int dbg = prego_tune_env("PREGO_SPLIT_DBG") ? atoi(prego_tune_env("PREGO_SPLIT_DBG")) : 0;     // timing experiments (wrong results): debug library only
   fa.dbg = dbg;
 #endif
   fa.tick = tick; fa.pack_done = pack_done; fa.l1_cnt = l1_cnt; fa.ln_done = ln_done; fa.wih_cnt = wih_cnt; fa.gi_cnt = gi_cnt;
-  fa.rec_cnt = rec_cnt; fa.abort_word = h->abort_word;
+  fa.rec_cnt = rec_cnt; fa.abort_word = h->abort_word; fa.hs = hs;
   // a job may only ever wait for jobs with earlier tickets: the previous holder of a ring slot (ring / sg super-rounds back) must have been
   // issued before the job that overwrites the slot
   const int ring_sr = kSplitRingPerXcd / kSplitSg;
@@ -771,6 +813,7 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   ga.sync = h->flags; ga.armed = 0; ga.Gd = R;
   ga.gi_cnt = gi_cnt; ga.rec_cnt = rec_cnt; ga.chunk_shift = kSplitChunkUnitShift + 8; ga.n_chunks = n_chunks;
   ga.units_per_chunk = upc; ga.units_last = n_units - upc * (n_chunks - 1); ga.gi_row_mask = (unsigned)kSplitGiRingUnits * 256u - 1u;
+  ga.hs = hs;
 
   // the feed-forward launch goes to the side stream (another hardware queue: it must be resident TOGETHER with the recurrence), forked
   // from and joined to the caller's stream by events
@@ -788,19 +831,50 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   if (dev_ok && g_split_last[dev_]) HIPCHK(hipStreamWaitEvent(s, g_split_last[dev_], 0));
   HIPCHK(hipEventRecord(h->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-  EventPair* evf = ev_begin(h, 2, h->side);       // timing_read: the feed-forward launch of a split pass is reported in the pack slot
-  if (launch_ff_pass(fa, h->side)) return fail(PREGO_EINVAL, "split pass: feed-forward shape E=%d kx=%d", E, kx);
+  const bool run_ff = fault != 2 && fault != 4, run_rec = fault != 1 && fault != 3;
+  const size_t ev_mark = h->ev_used;
+  EventPair* evf = run_ff ? ev_begin(h, 2, h->side) : nullptr;       // timing_read: the feed-forward launch of a split pass is reported in the pack slot
+  if (run_ff && launch_ff_pass(fa, h->side)) return fail(PREGO_EINVAL, "split pass: feed-forward shape E=%d kx=%d", E, kx);
   ev_end(evf, h->side);
   side_join.pending = true;
   HIPCHK(hipEventRecord(h->ev_join, h->side));
-  EventPair* evr = ev_begin(h, 1, s);
-  if (launch_gru_recurrence_pass(H, ga, s)) return fail(PREGO_EINVAL, "split pass: recurrence launch");
+  EventPair* evr = run_rec ? ev_begin(h, 1, s) : nullptr;
+  if (run_rec && launch_gru_recurrence_pass(H, ga, s)) return fail(PREGO_EINVAL, "split pass: recurrence launch");
   ev_end(evr, s);
   HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
   side_join.pending = false;
   if (dev_ok) {
     if (!g_split_last[dev_]) HIPCHK(hipEventCreateWithFlags(&g_split_last[dev_], hipEventDisableTiming));
     HIPCHK(hipEventRecord(g_split_last[dev_], s));
+  }
+  if (fault == 3 || fault == 4) { HIPCHK(hipGetLastError()); return PREGO_OK; }      // replay of one launch: no head, outputs untouched
+  // The calling thread waits here until the two launches have met (normally: the moment the stream reaches them).  GO: both are resident,
+  // every wait of the pass has a running producer, the head is enqueued behind it.  FAIL: they have left without writing anything
+  {
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    unsigned state = 0u; long long polls = 0;
+    for (;;) {
+      const unsigned v = __atomic_load_n(h->pin_hs, __ATOMIC_ACQUIRE);
+      if ((v >> 2) == hs.seq && (v & 3u)) { state = v & 3u; break; }
+      if ((++polls & 63) == 0) {
+        // both launches gone and nobody decided (cannot happen: every workgroup of either launch votes within its bound): not a pass
+        if (hipStreamQuery(s) == hipSuccess) {
+          const unsigned v2 = __atomic_load_n(h->pin_hs, __ATOMIC_ACQUIRE);
+          state = ((v2 >> 2) == hs.seq && (v2 & 3u)) ? (v2 & 3u) : PREGO_HS_FAIL;
+          break;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300))
+          return fail(PREGO_ETIMEOUT, "split pass: the stream did not reach the pass within 300 s");
+      }
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    if (state != PREGO_HS_GO) {
+      h->ev_used = ev_mark;                    // the two launches' timing events do not describe a pass
+      h->meas_armed = false;
+      *fell_back = true;
+      HIPCHK(hipGetLastError());
+      return PREGO_OK;
+    }
   }
   if (h->timing) { h->gemm_flop += 2.0 * total * ((double)E * kx + 3.0 * H * E); h->split_passes++; h->split_steps += h->t_max; }
   if (launch_head_softmax(true, HR, h->w_c, h->b_c, plan, 0, total, H, h->ncls, (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s,
@@ -856,7 +930,9 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                           (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
     // a call of this class is worth one wait for the placement word of an earlier launch (the handle's second call otherwise races it)
     if (shape_ok && h->placement < 0 && h->place_pending) { (void)hipEventSynchronize(h->ev_place); refresh_placement(h); }
-    const bool eligible = shape_ok && h->placement == 1;
+    bool backing_off = false;                       // a failed start handshake keeps the next eligible calls chunked
+    if (shape_ok && h->split_skip > 0) { --h->split_skip; backing_off = true; }
+    const bool eligible = shape_ok && h->placement == 1 && !backing_off;
     if (eligible && h->split_env > 0) split_r = r_try;
     else if (shape_ok) {
       // cost model (ms), calibrated on the bench workloads.  Chunked pass: the plan's recurrence estimate + the feed-forward of
@@ -866,7 +942,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       // took on this device so far (measured / estimated, events around every call of this shape class).
       // while one of the two kinds has never been timed on this handle, the host waits here for the pending measurement (at most the
       // handle's first two calls of this class lose their run-ahead); afterwards measurements are picked up when they happen to be done
-      if (h->meas_pending && !(h->have_ratio_split && h->have_ratio_chunked)) (void)hipEventSynchronize(h->ev_meas[1]);
+      // (only for the FIRST measurement of a kind: a handle whose model never trials the split pass stops waiting after one chunked call)
+      if (h->meas_pending && !(h->meas_mode ? h->have_ratio_split : h->have_ratio_chunked)) (void)hipEventSynchronize(h->ev_meas[1]);
       if (h->meas_pending && hipEventQuery(h->ev_meas[1]) == hipSuccess) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, h->ev_meas[0], h->ev_meas[1]) == hipSuccess && ms > 0 && h->meas_est > 0) {
@@ -952,8 +1029,19 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   const bool with_flow = any_flow;
   const int kx = h->d_rgb + (with_flow ? h->d_flow : 0);      // K of the layer1 GEMM actually multiplied
   if (kx == 0) return fail(PREGO_EINVAL, "a model without rgb features (--no_rgb) needs the flow tensors");
-  if (split_r > 0)
-    return forward_split(h, split_r, flags, with_flow, in16, kx, plan, d_rgb_ptrs, d_flow_ptrs, d_out_ptrs, d_arg_ptrs, workspace, workspace_bytes, s);
+  if (split_r > 0) {
+    bool fell_back = false;
+    rc = forward_split(h, split_r, flags, with_flow, in16, kx, plan, d_rgb_ptrs, d_flow_ptrs, d_out_ptrs, d_arg_ptrs, workspace, workspace_bytes, s,
+                       &fell_back);
+    if (rc || !fell_back) return rc;
+    // The two launches could not run side by side (a profiler that serialises dispatches, another tenant on the XCDs) and left before
+    // touching anything: THIS call runs as a chunked pass, right here, behind them in the stream.  Back-off: the next 16, then 64 eligible
+    // calls stay chunked, a third failure keeps the handle chunked for good
+    h->split_fails++; h->split_fallbacks++;
+    if (h->split_fails >= 3) h->split_env = 0;
+    else h->split_skip = 16ll << (2 * (h->split_fails - 1));
+    return prego_miniroad_forward(h, n_clips, lens, rgb, flow, out, argmax, h0, h_last, flags, workspace, workspace_bytes, stream);
+  }
   const int din = h->d_rgb + h->d_flow;
   const RowBytes rb = row_bytes(h, with_flow, flags);
   const int total_rows = h->h_rowoff[h->t_max];
@@ -1062,7 +1150,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     l1_done = false;
     // PREGO_PACK_EARLY=1 (A/B): X is dead from here on, so the next chunk's pack may run beside LayerNorm + the W_ih GEMM (MFMA-bound,
     // HBM half idle) instead of beside the recurrence (whose L2 hand-off it slows)
-    static const bool pack_early = getenv("PREGO_PACK_EARLY") != nullptr;
+    static const bool pack_early = prego_tune_env("PREGO_PACK_EARLY") != nullptr;
     const bool early = pack_early && prefetch && t1 < h->t_max;
     if (early) {
       HIPCHK(hipEventRecord(h->ev_fork, s));
@@ -1072,7 +1160,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     }
     // the LayerNorm launch also re-arms the recurrence's exchange buffers and rendezvous words (it runs after the previous recurrence
     // launch of this stream and before the next): one launch and one launch gap fewer per chunk (PREGO_NO_ARM_FUSE=1: A/B)
-    static const bool arm_fuse = getenv("PREGO_NO_ARM_FUSE") == nullptr;
+    static const bool arm_fuse = prego_tune_env("PREGO_NO_ARM_FUSE") == nullptr;
     const GruArm arm = h->x2 ? gru_x2_arm_desc(h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags)
                              : gru_arm_desc(h->bf16, h->hid, h->G, h->hx, h->no_local ? nullptr : h->flags);
     if (h->x2) launch_ln_relu_x2((const float*)Y, h->ln_g, h->ln_b, rows, E, 1e-5f, Eb, s, arm_fuse ? &arm : nullptr);
@@ -1097,7 +1185,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     {
       // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
       // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)
-      static const bool compact = getenv("PREGO_GRU_COMPACT") != nullptr;
+      static const bool compact = prego_tune_env("PREGO_GRU_COMPACT") != nullptr;
       const int live0 = h->h_nact[t0];
       ga.Gd = (compact && live0 <= 16 * h->G) ? std::max(1, std::min(h->G, (live0 + 15) / 16)) : 0;
     }
@@ -1110,14 +1198,14 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       const int live0 = h->h_nact[t0];
       const int gd0 = (live0 + 15) / 16;
       const int rows_n = h->h_rowoff[chunk_end(t1)] - h->h_rowoff[t1];
-      static const int max_gd = getenv("PREGO_OVERLAP_MAX_GD") ? atoi(getenv("PREGO_OVERLAP_MAX_GD")) : 7;     // A/B knob
+      static const int max_gd = prego_tune_env("PREGO_OVERLAP_MAX_GD") ? atoi(prego_tune_env("PREGO_OVERLAP_MAX_GD")) : 7;     // A/B knob
       if (live0 <= 16 * h->G && gd0 < h->G && gd0 <= max_gd && rows_n >= 4096) {
         // how many groups?  The fewest (gd0) frees the most XCDs; more groups mean fewer columns per group and a faster step
         // (1.67 us + 0.0102 us per live column of the fullest group).  Take the widest spread that still leaves the worker enough
         // XCD-time for the whole layer1 GEMM of the next chunk (13 ns per row on the whole chip, probe: >= proportional on a part)
         const double l1_ms = rows_n * 13.0e-6;
         int pick = std::max(1, gd0);
-        static const bool wide = getenv("PREGO_OVERLAP_NARROW") == nullptr;     // A/B knob: always the fewest groups (same device: 127.2 vs 125.5 ms)
+        static const bool wide = prego_tune_env("PREGO_OVERLAP_NARROW") == nullptr;     // A/B knob: always the fewest groups (same device: 127.2 vs 125.5 ms)
         for (int g2 = h->G - 1; wide && g2 > pick; --g2) {
           const double rec_ms = (t1 - t0) * (1.67 + 0.0102 * ((live0 + g2 - 1) / g2)) * 1e-3;
           if (l1_ms * h->G / (h->G - g2) <= 0.85 * rec_ms) { pick = g2; break; }
@@ -1197,7 +1285,7 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   StreamGemv l1{h->w1, rgb, with_flow ? flow : nullptr, h->b1, Y, E, din, h->d_rgb, h->d_rgb, h->d_flow, 0};
   if (launch_stream_gemv(1, &l1, n_streams, s, h->f16)) return fail(PREGO_EINVAL, "step: unsupported layer1 shape %d x %d", E, din);
   // LayerNorm + ReLU: inside the W_ih product for <= 4 streams (three launches per frame), the batched kernel otherwise
-  static const bool no_fuse = getenv("PREGO_STEP_NO_LN_FUSE") != nullptr;
+  static const bool no_fuse = prego_tune_env("PREGO_STEP_NO_LN_FUSE") != nullptr;
   const bool fuse_ln = n_streams <= 4 && E % 2048 == 0 && !no_fuse;
   if (!fuse_ln) launch_ln_relu(true, Y, h->ln_g, h->ln_b, n_streams, E, 1e-5f, Eb, nullptr, 0.f, 0ull, 0, s, 1, false, h->f16);
   StreamGemv g2[2] = {{h->w_ih, fuse_ln ? (const void*)Y : (const void*)Eb, nullptr, h->bias2, GI, 3 * H, E, E, E, 0, fuse_ln ? 0 : 1},
@@ -1218,14 +1306,15 @@ extern "C" int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream) {
   HIPCHK(hipMemcpy(&ab, h->abort_word, sizeof ab, hipMemcpyDeviceToHost));
   if (ab) {
     (void)hipMemset(h->abort_word, 0, sizeof ab);
-    // codes: 1 = the recurrence's gather / rendezvous; 2 = a pass launch without the verified placement; 3 = the recurrence of a split pass
+    // codes: 1 = the recurrence's gather / rendezvous; 3 = the recurrence of a split pass
     // waiting for its input projection; 0x100 + k = wait k of the feed-forward launch of a split pass (ff_pass.hip)
     if (ab >= 2) {
-      // the two launches of a split pass did not run side by side (a profiler that collects counters serialises kernel dispatches; another
-      // process holds the XCDs): this handle keeps to the chunked pass from here on
+      // a wait INSIDE a split pass ran out although its start handshake had seen both launches resident (launches that cannot run side by
+      // side never get this far: they leave at the handshake and the call is re-run chunked, prego_miniroad_forward).  A stuck workgroup or a
+      // bug: report it, keep this handle on the chunked pass
       h->split_env = 0;
-      return fail(PREGO_ETIMEOUT, "split pass: the recurrence and feed-forward launches did not run concurrently [code 0x%x] (kernel-serialising "
-                  "profiler?); the results of that call are invalid, this handle now uses the chunked pass (PREGO_SPLIT_PASS=0 selects it from the start)", ab);
+      return fail(PREGO_ETIMEOUT, "split pass: a wait timed out behind a successful start handshake [code 0x%x]; the results of that call are "
+                  "invalid, this handle now uses the chunked pass (PREGO_SPLIT_PASS=0 selects it from the start)", ab);
     }
     return fail(PREGO_ETIMEOUT, "GRU recurrence kernel timed out waiting for a producer workgroup (not all %d workgroups resident?) [code 0x%x]",
                 h->G * h->P, ab);
@@ -1345,6 +1434,20 @@ extern "C" int prego_miniroad_debug_stamps(prego_miniroad* h, unsigned long long
   return PREGO_OK;
 }
 
+// fault injection / replay for the NEXT split pass of the handle (one shot; include/prego_amd_debug.h)
+extern "C" int prego_debug_split_fault(prego_miniroad* h, int mode) {
+  if (!h || mode < 0 || mode > 4) return fail(PREGO_EINVAL, "debug split fault: mode %d", mode);
+  h->dbg_fault = mode;
+  return PREGO_OK;
+}
+extern "C" int prego_debug_split_state(const prego_miniroad* h, int64_t* fallbacks, int32_t* fails, int64_t* skip, int32_t* split_env) {
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (fallbacks) *fallbacks = h->split_fallbacks;
+  if (fails) *fails = h->split_fails;
+  if (skip) *skip = h->split_skip;
+  if (split_env) *split_env = h->split_env;
+  return PREGO_OK;
+}
 #endif  // PREGO_DEBUG_ABI
 
 // ================================================================================================
@@ -1548,7 +1651,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   // A/B reference (PREGO_BPTT_STEPWISE=1)
   bool persistent = false;
   {
-    static const bool stepwise = getenv("PREGO_BPTT_STEPWISE") != nullptr;
+    static const bool stepwise = prego_tune_env("PREGO_BPTT_STEPWISE") != nullptr;
     const int slots = (h->n_slots + h->G - 1) / h->G;
     const int nct = (slots + 15) / 16;
     if (!stepwise) {

@@ -328,7 +328,7 @@ extern "C" int prego_vit_forward(prego_vit* h, int batch, const float* rgb, cons
   launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s, h->f16);
   // ViT.py:125-129: the encoding GEMM writes the residual stream itself (frame rows + positional rows in its epilogue: no fp32
   // encoding tensor, no token kernel pass); the cls row of every window is B short rows
-  static const bool no_epi_tokens = getenv("PREGO_VIT_TOKENS_KERNEL") != nullptr;       // A/B: the separate token kernel
+  static const bool no_epi_tokens = prego_tune_env("PREGO_VIT_TOKENS_KERNEL") != nullptr;       // A/B: the separate token kernel
   if (no_epi_tokens || B * T < 4096) {       // small batches: the 128 x 128 kernel's per-element epilogue costs more than the token kernel
     launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s, h->f16);
     launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, (float*)(ws + w.x), s);

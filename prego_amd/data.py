@@ -177,7 +177,9 @@ class EpochWindowSampler(data.Sampler):
         order = torch.randperm(n, generator=g).tolist()
         bg, b = self.world * self.batch_size, self.batch_size
         total = self._steps(n) * bg
-        order += [i + n for i in order[: total - n]]              # pads: index + n = "that window, zero target"
+        # pads: index + n = "that window, zero target"; cyclic, so that a dataset smaller than the padding (n < total - n: a tiny set
+        # against world x batch) still gives every rank the same number of entries (a short order would hang the gradient all-reduce)
+        order += [order[k % n] + n for k in range(total - n)] if n > 0 else []
         mine = []
         for j in range(0, total, bg):
             mine += order[j + self.rank * b: j + (self.rank + 1) * b]

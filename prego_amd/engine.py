@@ -47,8 +47,9 @@ class MiniRoadEngine:
     same speed, 8x less operand rounding, inference only) or 'fp32' (exact-fp32 MFMA, the parity mode)."""
 
     def __init__(self, d_rgb: int, d_flow: int, emb: int, hid: int, n_classes: int, device,
-                 compute_dtype: str = "bf16"):
-        self.lib = _lib.load()
+                 compute_dtype: str = "bf16", lib=None):
+        # lib: tests that inject faults run a handle on libprego_amd_debug.so (_lib.load_debug()); everything else runs the product library
+        self.lib = lib if lib is not None else _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise PregoError("prego_amd runs on an MI355X only (device must be cuda:N); there is no CPU path")
@@ -314,6 +315,7 @@ class MiniRoadEngine:
         # the first two are announced by events recorded inside the backward, the last one is final when backward returns
         o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
         self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]
+        self._grad_offsets = {k: (o, n) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}     # where each tensor lives in the flat bucket
         self._grad_events = None
         self._early_done = set()
         self._cb_error = None

@@ -164,11 +164,17 @@ class Evaluate(nn.Module):
             tgt = [b[2].to(dev, non_blocking=True) for b in batch]                   # only needed behind the forward
             ready = torch.cuda.Event()
             ready.record(self._copy_stream)
-        for t in rgb + [f for f in (flow or []) if f is not None] + tgt:
-            t.record_stream(self._copy_stream)
+        for t in rgb + [f for f in (flow or []) if f is not None]:
+            t.record_stream(self._copy_stream)                 # allocated on `cur`, written on the copy stream
+        for t in tgt:
+            t.record_stream(cur)                               # allocated on the copy stream (inside its context), read on `cur`
         self._feed_events = events                           # keep the hipEvent_t objects alive until the stream has used them
         eng.set_feed_events(upto, events, row_bytes)
-        probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        try:
+            probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
+        except BaseException:
+            eng.set_feed_events([], [], 0)                     # a forward that never reached the library must not leave its feed events armed for the next one
+            raise
         cur.wait_event(ready)
         return probs, args, tgt
 

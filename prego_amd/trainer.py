@@ -35,6 +35,13 @@ def _arm_early_allreduce(model, weight: float = 1.0):
         return
     if not hasattr(eng, "set_bucket_hook"):
         return
+    if any(p.grad is not None for p in model.parameters()):
+        # gradients are being ACCUMULATED (no zero_grad(set_to_none=True) in front of this backward): autograd adds this backward's
+        # result into the existing .grad tensors instead of adopting the views of the flat bucket, so an in-place reduce of the bucket
+        # from inside the backward would reduce the wrong thing (and race autograd's read of it).  _allreduce_grads takes the generic
+        # gather / reduce / scatter path behind the backward instead
+        eng.set_bucket_hook(None)
+        return
     compress = getattr(model, "grad_compress", None)
 
     def hook(e, i):
@@ -65,6 +72,30 @@ def _allreduce_grads(model, weight: float = 1.0):
         else:
             allreduce_mean_(flat, world, weight, force)
         return
+    early = set(getattr(eng, "_early_done", ()) or ()) if eng is not None else set()
+    if early and flat is not None:
+        # The bucket hook already reduced (and scaled) sub-buckets of the flat tensor in place from inside the backward, but autograd
+        # did not adopt the flat tensor's views as .grad (AccumulateGrad copied them): wait for those collectives, hand their result to
+        # the copies - the hook is only ever armed when .grad was None, so the copy holds exactly this backward's gradient - and reduce
+        # only what is left.  Reducing everything again would average those buckets twice (and apply `weight` twice)
+        from .distributed import allreduce_join_
+        allreduce_join_(flat)
+        bounds, offsets = getattr(eng, "_grad_bounds", None), getattr(eng, "_grad_offsets", None)
+        if not bounds or not offsets:
+            raise RuntimeError("early gradient buckets were reduced in place but the engine does not say where its tensors live "
+                               "(_grad_offsets): cannot finish the all-reduce")
+        named = dict(model.named_parameters())
+        done = set()
+        for k, (o, n) in offsets.items():
+            p = named.get(k)
+            if p is None or p.grad is None:
+                continue
+            if any(i in early and lo <= o < hi for i, (lo, hi) in enumerate(bounds)):
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                done.add(id(p))
+        ps = [p for p in ps if id(p) not in done]
+        if not ps:
+            return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])        # generic modules: gather, reduce, scatter
     allreduce_mean_(flat, world, weight, force)
     o = 0

@@ -184,6 +184,55 @@ class _BucketMROAD(_TinyMROAD):
             p.register_post_accumulate_grad_hook(hook)
 
 
+class _EarlyHookMROAD(_TinyMROAD):
+    """the HIP engine's early bucket hook (trainer._arm_early_allreduce) in the situation the round-4 advisor described: the backward
+    writes the gradients into one flat tensor and calls the hook for bucket 0 from inside the backward (the trainer reduces that slice IN
+    PLACE there), but autograd ends up with COPIES of the flat tensor's slices as .grad, not views.  _allreduce_grads must hand the
+    reduced slice to the copies and reduce only the rest - not average bucket 0 twice"""
+
+    def __init__(self):
+        super().__init__()
+        names = [k for k, _ in self.named_parameters()]
+        ps = list(self.parameters())
+        offs = [0]
+        for p in ps:
+            offs.append(offs[-1] + p.numel())
+        mid = offs[len(ps) // 2]
+        model = self
+
+        class _E:
+            _bucket_hook = None
+
+            def check(self):
+                pass
+
+            def set_bucket_hook(self, fn):
+                self._bucket_hook = fn
+        e = self._engine = _E()
+        e._grad_flat = torch.zeros(offs[-1])
+        e._grad_bounds = [(mid, offs[-1]), (0, mid)]
+        e._grad_offsets = {k: (o, p.numel()) for k, o, p in zip(names, offs, ps)}
+        e._grad_events = [None, None]
+        e._early_done = set()
+        self.hook_calls = 0
+        last_of_bucket0 = ps[len(ps) // 2]           # autograd reaches the LATER tensors first; bucket 0 = [mid, end) is final once
+        first_seen = {"n": 0}                        # every tensor of the second half has its gradient
+
+        for p, o in zip(ps, offs):
+            def hook(param, o=o):
+                e._grad_flat[o:o + param.numel()].copy_(param.grad.reshape(-1))          # .grad stays a separate tensor (a copy)
+                if o >= mid:
+                    first_seen["n"] += 1
+                    if first_seen["n"] == len(ps) - len(ps) // 2 and e._bucket_hook is not None:
+                        e._bucket_hook(e, 0)
+                        model.hook_calls += 1
+            p.register_post_accumulate_grad_hook(hook)
+
+    def engine(self, train=False):
+        self._engine._early_done = set()
+        return self._engine
+
+
 def _oad_loss_torch(out, target):          # criterions/loss.py:15-34
     lg, tg = out["logits"][:, -1, :], target[:, -1, :]
     return torch.mean(torch.sum(-torch.nn.functional.normalize(tg) * torch.log_softmax(lg, -1), dim=1))
@@ -217,10 +266,12 @@ def _train_worker(rank, world, port, q, kind="tiny"):
         sampler = _S()
 
     loader = _Loader([(rgb[sl], flow[sl], tgt[sl], ("v",) * per, torch.zeros(per), torch.zeros(per))])
-    model = _TinyMROAD() if kind == "tiny" else _BucketMROAD("bf16" if kind == "bucket_bf16" else None)
+    model = _TinyMROAD() if kind == "tiny" else _EarlyHookMROAD() if kind == "early_copy" else _BucketMROAD("bf16" if kind == "bucket_bf16" else None)
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
     loss = train_one_epoch(loader, model, _oad_loss_torch, opt, None, 3, "cpu")
     assert loader.sampler.epoch == 3                  # DistributedSampler-style samplers get the epoch
+    if kind == "early_copy" and world > 1:
+        assert model.hook_calls == 1 and model._engine._early_done == {0}      # the hook did fire from inside the backward
     if rank == 0:
         q.put((float(loss), [p.detach().numpy().tolist() for p in model.parameters()]))
     if world > 1:
@@ -249,7 +300,7 @@ def test_train_one_epoch_allreduces_grads_like_the_global_batch():
     assert not torch.allclose(torch.tensor(res[1][1][0]), _TinyMROAD().l1.weight)      # the step did move the weights
 
 
-@pytest.mark.parametrize("kind", ["bucket", "bucket_bf16"])
+@pytest.mark.parametrize("kind", ["bucket", "bucket_bf16", "early_copy"])
 def test_train_one_epoch_bucketed_allreduce_matches_global_batch(kind):
     """the flat-bucket path of _allreduce_grads (what the HIP engine's backward feeds): sub-buckets reduced in place, in fp32
     (exactly the global-batch step) and bf16-compressed (within bf16 rounding of it)"""
@@ -268,7 +319,7 @@ def test_train_one_epoch_bucketed_allreduce_matches_global_batch(kind):
     init = [p.detach() for p in _TinyMROAD().parameters()]
     for a, b, p0 in zip(res[1][1], res[2][1], init):
         a, b = torch.tensor(a), torch.tensor(b)
-        if kind == "bucket":
+        if kind in ("bucket", "early_copy"):
             assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
         else:       # the update (lr * mean gradient) carries bf16 rounding: 2^-8 relative on the step, not on the weight
             step = (a - p0).abs().max().item()
@@ -300,6 +351,26 @@ def test_epoch_window_sampler_partitions_and_reshuffles():
     assert list(iter(s)) != parts[3]
     ds.extend(range(5))                                               # _init_features() changed the window count
     assert len(s) == 28 and len(list(iter(s))) == 28                  # 108 windows: 14 global steps
+
+
+def test_epoch_window_sampler_pads_a_tiny_dataset_cyclically():
+    """3 windows against a global batch of 8 (2 ranks x 4): five pads are needed, more than there are windows - every rank must still get
+    the same number of entries (a short order would leave one rank a step short and hang the gradient all-reduce)"""
+    from prego_amd.data import EpochWindowSampler
+
+    class _DS(list):
+        pass
+
+    ds = _DS(range(3))
+    got = []
+    for rank in range(2):
+        s = EpochWindowSampler.__new__(EpochWindowSampler)
+        s.dataset, s.world, s.rank, s.batch_size, s.seed, s.epoch = ds, 2, rank, 4, 0, 0
+        got.append(list(iter(s)))
+        assert len(got[-1]) == len(s) == 4
+        assert s.step_weight(0) == 8 / 3
+    flat = got[0] + got[1]
+    assert sorted(i for i in flat if i < 3) == [0, 1, 2] and sum(i >= 3 for i in flat) == 5 and all(3 <= i < 6 for i in flat if i >= 3)
 
 
 def _short_batch_worker(rank, world, port, q):

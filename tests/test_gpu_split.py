@@ -189,3 +189,94 @@ def test_two_handles_on_two_streams_and_a_bystander_kernel(weights):
         o, a, _ = res[k]
         for i in range(len(lens)):
             assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), (k, i)
+
+
+def _debug_engine(sd, cfg, dtype, split):
+    """an engine on libprego_amd_debug.so (the product sources + the fault-injection entry points of include/prego_amd_debug.h)"""
+    import ctypes as C
+    from prego_amd import _lib
+    from prego_amd.engine import MiniRoadEngine
+    from prego_amd.config import FEATURE_SIZES
+    dbg = _lib.load_debug()
+
+    def make():
+        e = MiniRoadEngine(FEATURE_SIZES[cfg["rgb_type"]], FEATURE_SIZES[cfg["flow_type"]], cfg["embedding_dim"], cfg["hidden_dim"],
+                           cfg["num_classes"], "cuda:0", dtype, lib=dbg)
+        e.set_weights({k: torch.from_numpy(v).cuda() for k, v in sd.items()})
+        return e
+    eng = _with_env("PREGO_SPLIT_PASS", split, make)
+
+    def state():
+        fb, sk = C.c_int64(), C.c_int64()
+        fl, env = C.c_int32(), C.c_int32()
+        assert dbg.prego_debug_split_state(eng.h, C.byref(fb), C.byref(fl), C.byref(sk), C.byref(env)) == 0
+        return dict(fallbacks=fb.value, fails=fl.value, skip=sk.value, env=env.value)
+    return eng, dbg, state
+
+
+@pytest.mark.parametrize("withheld", [1, 2], ids=["recurrence_withheld", "feed_forward_withheld"])
+def test_a_split_pass_that_cannot_run_side_by_side_loses_no_call(weights, withheld):
+    """The split pass needs its two persistent launches resident TOGETHER.  When they are not (a profiler that serialises dispatches,
+    another tenant on the XCDs - here: the debug library withholds one of the two launches), the start handshake of the launch that did
+    start runs out, it leaves without having written anything, and prego_miniroad_forward runs THE SAME CALL as a chunked pass: the
+    outputs equal the never-split handle bit for bit, check() reports nothing, pass_info says mode 0, the detour costs well under half a
+    second, the next calls are fine (chunked while the back-off lasts, split again afterwards)."""
+    import time
+    cfg, sd = weights
+    lens = _lens(64, 3000, 6200, 31)
+    rgb = [_feat((T, 2048), 1300 + i) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    ref_o, ref_a, _ = _run(e0, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    eng, dbg, state = _debug_engine(sd, cfg, "fp16", "3")
+    _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)                      # placement
+    o, a, info = _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    assert info["mode"] == 3 and state()["fallbacks"] == 0
+    torch.cuda.synchronize()
+    t_ok = time.perf_counter()
+    _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    t_ok = time.perf_counter() - t_ok
+    # poison the outputs' storage so that a call that wrote nothing cannot pass
+    assert dbg.prego_debug_split_fault(eng.h, withheld) == 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    o, a, info = _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)         # check() inside: no error
+    dt = time.perf_counter() - t0
+    st = state()
+    assert info["mode"] == 0, info
+    assert st["fallbacks"] == 1 and st["fails"] == 1 and st["skip"] > 0, st
+    assert dt < 0.5, f"the detour took {dt:.3f} s (a healthy split pass: {t_ok:.3f} s)"
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), i
+    o, a, info = _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)         # next call: backing off, chunked, correct
+    assert info["mode"] == 0 and state()["fallbacks"] == 1
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), i
+    for _ in range(st["skip"] - 1):                                                          # the back-off ends: split again
+        eng.forward_ragged(rgb, None, softmax=True, want_out=False, want_argmax=True)
+    eng.check()
+    o, a, info = _run(eng, rgb, None, softmax=True, want_out=True, want_argmax=True)
+    assert info["mode"] == 3, (info, state())
+    for i in range(len(lens)):
+        assert torch.equal(o[i], ref_o[i]) and torch.equal(a[i], ref_a[i]), i
+    print(f"handshake failure ({withheld}): detour {dt * 1e3:.1f} ms, healthy split pass {t_ok * 1e3:.1f} ms")
+
+
+def test_three_failed_handshakes_keep_the_handle_chunked(weights):
+    cfg, sd = weights
+    lens = _lens(64, 4100, 4200, 33)
+    rgb = [_feat((T, 2048), 1500 + i) for i, T in enumerate(lens)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    _, ref_a, _ = _run(e0, rgb, None, softmax=True, want_out=False, want_argmax=True)
+    eng, dbg, state = _debug_engine(sd, cfg, "fp16", "3")
+    _run(eng, rgb, None, softmax=True, want_out=False, want_argmax=True)
+    for k in range(3):
+        while state()["skip"] > 0:
+            eng.forward_ragged(rgb, None, softmax=True, want_out=False, want_argmax=True)
+        assert dbg.prego_debug_split_fault(eng.h, 1) == 0
+        _, a, info = _run(eng, rgb, None, softmax=True, want_out=False, want_argmax=True)
+        assert info["mode"] == 0 and state()["fails"] == k + 1
+        for i in range(len(lens)):
+            assert torch.equal(a[i], ref_a[i])
+    assert state()["env"] == 0
+    _, a, info = _run(eng, rgb, None, softmax=True, want_out=False, want_argmax=True)
+    assert info["mode"] == 0

@@ -18,7 +18,7 @@ def test_abi_library_builds_loads_and_exports_every_declared_symbol():
     ge.build()
     from prego_amd import _lib
     lib = _lib.load()
-    assert lib.prego_abi_version() == 5
+    assert lib.prego_abi_version() == 6
     hdr = open(os.path.join(ROOT, "include", "prego_amd.h")).read()
     declared = sorted(set(re.findall(r"\b(prego_[a-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations found"
