@@ -341,11 +341,24 @@ def main():
                        "frac_of_its_xcds": ff_tflops / (peak * share), "traffic": traffic.get("ff_pass_bytes_per_launch"),
                        "avg_launch_ms": ff_ms / max(1, kt["pack_launches"]), "launches": kt["pack_launches"], "ms_per_step": ff_ms / args.steps,
                        "note": "achieved = the two projections' algorithmic flops / the launch's duration; the launch also streams the features (pack) and normalises the rows",
-                       "traffic_note": "null: rocprofv3 counter collection serialises kernel dispatches and the two launches of a split pass only make progress side by side "
-                                       "(a serialised pass ends in the bounded timeout, PREGO_ETIMEOUT); the chunked pass's per-kernel PMC traffic is in profiles/*_pmc_traffic.csv"}
+                       "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) of this launch REPLAYED ALONE on the same workload (scripts/split_replay.py on the "
+                                       "debug library: counter collection serialises dispatches, so the pair itself can never run under it); "
+                                       "algorithmic = 47 104 B per frame (DESIGN 4): what exceeds it is weight slabs and ring rows that were re-read over the fabric "
+                                       "instead of from the unit's own XCD's L2 (Infinity-Cache hits are counted)"}
+            alg_ff = traffic.get("ff_pass_algorithmic_bytes_per_launch")
+            if rl_gemm["traffic"] and alg_ff:
+                rl_gemm["traffic_algorithmic"] = alg_ff
+                rl_gemm["traffic_over_algorithmic"] = rl_gemm["traffic"] / alg_ff
             rl_gru.update({"kernel": f"gru_recurrence_kernel<PASS> (one launch per pass on {R} of 8 XCDs, {pinfo['slots']} slots)", "xcds": R,
                            "us_per_timestep": kt["gru_ms"] / args.steps * 1e3 / max(1, pinfo["steps"]), "sequential_timesteps": pinfo["steps"],
                            "traffic": traffic.get("gru_pass_bytes_per_launch")})
+            alg_rec = traffic.get("gru_pass_algorithmic_bytes_per_launch")
+            if rl_gru["traffic"] and alg_rec:
+                rl_gru["traffic_algorithmic"] = alg_rec          # 6 144 B of GI in + 2 048 B of relu(h) out per frame; the per-step hand-off stays in the XCDs' L2
+                rl_gru["traffic_over_algorithmic"] = rl_gru["traffic"] / alg_rec
+            if traffic.get("split_source") and traffic_source is not None:
+                traffic_source = dict(traffic_source, file=traffic.get("split_source"), collected_at_git=traffic.get("split_git"),
+                                      workload=traffic.get("split_workload"))
             rl_pack = None
             dominant = rl_gemm       # both launches span the pass; the feed-forward one holds the larger share of the chip
         line = {

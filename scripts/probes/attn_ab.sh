@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # Runs ON THE GPU BOX: A/B of the attention forward shapes (PREGO_ATTN_NW=4: 4 waves x 32 queries; default: 8 waves x 16 queries)
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_transformer.py tests/test_gpu_vit_train.py -x -q 2>&1 | tail -3

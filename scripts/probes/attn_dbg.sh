@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # Runs ON THE GPU BOX: what each part of the attention tile loop costs.  Needs a DIAGNOSTIC build of csrc/attention.hip that is not
 # in the tree (results are wrong by construction): an extra kernel argument `dbg` read from PREGO_ATTN_DBG, bit 1 skips the in-loop
 # LDS-DMA, bit 2 the softmax (P := constant), bit 4 the QK^T MFMAs, bit 8 the PV MFMAs.  Round-2 result (B=16, L=1024, 8 x 256, us):

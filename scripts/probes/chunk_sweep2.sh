@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # rows-per-chunk sweep on the bench workload, pack prefetch grid 512, two rounds
 export PREGO_PACK_PREFETCH_GRID=${GRID:-512}
 for i in 1 2; do

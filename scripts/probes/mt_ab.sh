@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # multi-tile recurrence steps: classic kernel (PREGO_GRU_NO_MT=1) vs the software-pipelined kernel, synth512 forced into 128 / 256 / 512
 # slots = 1 / 2 / 4 clip tiles per group.  Runs on the GPU box.
 for mt in 1 0; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # recurrence cost per time step by live tiles per group (calibrates kStepCost in csrc/miniroad.cpp): synth512 workload,
 # slots forced to 128 / 256 / 512 = 1 / 2 / 4 tiles per group
 for sl in 128 256 512; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # Runs ON THE GPU BOX: knob sweep of the split pass on one device (bench workload, forced R = 3; zero-flow forced R = 4)
 cd $GRAFT_REPO_ROOT
 run() { timeout 300 python3 bench.py --no-cpu-baseline --no-secondary --steps 6 2>&1 | tail -1 | python3 -c "

@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # Runs ON THE GPU BOX: ViTEnc forward (129-token windows) with the 4-wave (3 x 64 query slots) vs the 8-wave (2 x 128) attention shape
 cd /tmp && export TMPDIR=/tmp
 for NW in 4 8; do

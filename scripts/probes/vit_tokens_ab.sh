@@ -1,4 +1,5 @@
 #!/bin/bash
+export PREGO_AMD_DEBUG_LIB=1   # tuning knobs (PREGO_SPLIT_LAG*, PREGO_PLAN_SLOTS, PREGO_ATTN_NW, ...) are read by the debug library only (csrc/kernels.h: prego_tune_env)
 # Runs ON THE GPU BOX: ViTEnc forward with the token rows written by the encoding GEMM's epilogue (default) vs the separate token kernel
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_transformer.py tests/test_gpu_vit_train.py -x -q 2>&1 | tail -2
