@@ -175,6 +175,9 @@ int prego_miniroad_set_dropout(prego_miniroad* h, float p, uint64_t seed);
  * dlogits[i] (array nullable): device fp32 [lens[i], n_classes] := grad_scale * dloss/dlogits (zero except last frame). */
 int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
                    int n_classes, float* loss_out, float* const* dlogits, float grad_scale, prego_stream_t stream);
+/* OadLoss(cfg, reduction) (loss.py:8-11,30-33): reduction 0 = 'mean' (what main.py builds; prego_oad_loss), 1 = 'sum' over the batch. */
+int prego_oad_loss_reduce(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
+                          int n_classes, int reduction, float* loss_out, float* const* dlogits, float grad_scale, prego_stream_t stream);
 
 /* loss.backward() through MROAD (train.py:23).  Must follow a forward() with PREGO_FWD_KEEP of the same clips whose
  * workspace is passed back as fwd_workspace (untouched in between).  dlogits[i]: device fp32 [lens[i], n_classes]

@@ -482,7 +482,28 @@ def g9():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-GROUPS = {"g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
+def g4s():
+    """OadLoss(cfg, reduction='sum') (criterions/loss.py:8-11,30-33) and its gradient, beside 'mean', on one batch of logits: 6 windows x
+    5 frames x 86 classes, one all-zero last-frame target row (front padding) and one multi-label row."""
+    from criterions.loss import OadLoss
+    cfg = assembly101_cfg()
+    B, T, C = 6, 5, cfg["num_classes"]
+    logits = (W.uniform01((B, T, C), 20, "g4s.logits") * 8.0 - 4.0).astype(np.float32)
+    tgt = make_targets(B, T, C, 20, "g4s.tgt")
+    tgt[4, -1] = 0.0
+    tgt[1, -1, 7] = 1.0
+    save = {"logits": logits, "target": tgt}
+    for red in ("mean", "sum"):
+        lg = torch.from_numpy(logits).clone().requires_grad_(True)
+        loss = OadLoss(cfg, reduction=red)({"logits": lg}, torch.from_numpy(tgt))
+        loss.backward()
+        save[f"loss_{red}"] = np.float64(loss.item())
+        save[f"dlogits_{red}"] = lg.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g4s_oadloss_sum.npz"), **save)
+    print("g4s", float(save["loss_mean"]), float(save["loss_sum"]))
+
+
+GROUPS = {"g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -126,9 +126,9 @@ def oad_loss(logits, target, reduction="mean"):
     return per.mean() if reduction == "mean" else per.sum()
 
 
-def oad_loss_grad(logits, target):
-    """d mean-loss / d logits ([B,T,C], non-zero only at t = T-1)."""
-    B = logits.shape[0]
+def oad_loss_grad(logits, target, reduction="mean"):
+    """d loss / d logits ([B,T,C], non-zero only at t = T-1); reduction 'mean' or 'sum' (loss.py:30-33)."""
+    B = logits.shape[0] if reduction == "mean" else 1
     lg = logits[:, -1, :]
     tg = target[:, -1, :]
     nrm = np.maximum(np.sqrt((tg ** 2).sum(axis=1, keepdims=True)), 1e-12)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_last_error", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
-    "prego_miniroad_set_dropout", "prego_oad_loss",
+    "prego_miniroad_set_dropout", "prego_oad_loss", "prego_oad_loss_reduce",
     "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
@@ -82,6 +82,8 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_miniroad_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
     lib.prego_oad_loss.argtypes = [i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), i32, vp, C.POINTER(vp),
                                    C.c_float, vp]
+    lib.prego_oad_loss_reduce.argtypes = [i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp), i32, i32, vp, C.POINTER(vp),
+                                          C.c_float, vp]
     lib.prego_miniroad_backward_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32)]
     lib.prego_miniroad_backward_workspace_bytes.restype = sz
     lib.prego_miniroad_backward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp)] + [vp] * 10 + [vp, sz, vp, sz, vp]

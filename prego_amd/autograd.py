@@ -40,16 +40,16 @@ def miniroad_train_forward(model, rgb_input, flow_input):
 
 class _OadLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target):
-        loss, dl = oad_loss(logits, target, want_grad=True)
+    def forward(ctx, logits, target, reduction="mean"):
+        loss, dl = oad_loss(logits, target, want_grad=True, reduction=reduction)
         ctx.save_for_backward(dl)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None
+        return dl * g, None, None
 
 
-def oad_loss_autograd(logits, target):
-    return _OadLossFn.apply(logits, target)
+def oad_loss_autograd(logits, target, reduction="mean"):
+    return _OadLossFn.apply(logits, target, reduction)

@@ -222,7 +222,7 @@ void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add
 
 // training path (train.hip)
 void launch_oad_loss(const float* const* logit_ptrs, const float* const* target_ptrs, const int* lens, int n_clips, int C,
-                     float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s);
+                     float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s, bool sum = false);
 void launch_gather_dlogits(bool bf16, const float* const* dl_ptrs, const int* rowoff, const int* sorted_clip, int t_max,
                            int nrows, int C, int Cpad, void* out, hipStream_t s);
 void launch_transpose_convert(bool in_bf16, bool out_bf16, const void* src, int M, int N, int ld_src, void* dst, int Mpad,

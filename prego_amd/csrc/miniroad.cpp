@@ -1468,6 +1468,12 @@ extern "C" int prego_miniroad_set_dropout(prego_miniroad* h, float p, uint64_t s
 extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
                               int n_classes, float* loss_out, float* const* dlogits, float grad_scale,
                               prego_stream_t stream) {
+  return prego_oad_loss_reduce(n_clips, lens, logits, target, n_classes, 0, loss_out, dlogits, grad_scale, stream);
+}
+extern "C" int prego_oad_loss_reduce(int n_clips, const int32_t* lens, const float* const* logits, const float* const* target,
+                                     int n_classes, int reduction, float* loss_out, float* const* dlogits, float grad_scale,
+                                     prego_stream_t stream) {
+  if (reduction != 0 && reduction != 1) return fail(PREGO_EINVAL, "loss: reduction %d (0 = 'mean', 1 = 'sum')", reduction);
   if (!lens || !logits || !target || !loss_out) return fail(PREGO_EINVAL, "loss: NULL argument");
   if (n_clips <= 0 || n_clips > LOSS_MAX_CLIPS) return fail(PREGO_EINVAL, "loss: %d clips (max %d)", n_clips, LOSS_MAX_CLIPS);
   if (n_classes <= 0 || n_classes > 128) return fail(PREGO_EINVAL, "loss: num_classes %d must be in 1..128", n_classes);
@@ -1501,7 +1507,7 @@ extern "C" int prego_oad_loss(int n_clips, const int32_t* lens, const float* con
   HIPCHK(hipEventRecord(sc.ev, s));
   sc.busy = true;
   launch_oad_loss((const float* const*)d, (const float* const*)(d + MC), (const int*)(d + 3 * MC), n_clips, n_classes,
-                  loss_out, dlogits ? (float* const*)(d + 2 * MC) : nullptr, grad_scale, s);
+                  loss_out, dlogits ? (float* const*)(d + 2 * MC) : nullptr, grad_scale, s, reduction == 1);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }

@@ -22,7 +22,7 @@
 __global__ __launch_bounds__(64 * OAD_WAVES) void oad_loss_kernel(
     const float* const* __restrict__ logit_ptrs, const float* const* __restrict__ target_ptrs,
     const int* __restrict__ lens, int n_clips, int C, float* __restrict__ loss_out,
-    float* const* __restrict__ dlogit_ptrs /*nullable*/, float grad_scale) {
+    float* const* __restrict__ dlogit_ptrs /*nullable*/, float grad_scale, float denom /* n_clips: reduction='mean'; 1: 'sum' (loss.py:30-33) */) {
   __shared__ float s_per[OAD_MAX_LDS_CLIPS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool serial = n_clips > OAD_MAX_LDS_CLIPS;       // more clips than the LDS table holds: one wave does all, as before
@@ -65,14 +65,14 @@ __global__ __launch_bounds__(64 * OAD_WAVES) void oad_loss_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int c = lane + 64 * i;
-        if (c < C) dl[(size_t)(T - 1) * C + c] = (expf(l[i] - lse) * ysum - y[i]) * grad_scale / (float)n_clips;
+        if (c < C) dl[(size_t)(T - 1) * C + c] = (expf(l[i] - lse) * ysum - y[i]) * grad_scale / denom;
       }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (!serial) for (int b = 0; b < n_clips; ++b) total += s_per[b];
-    loss_out[0] = total / (float)n_clips;
+    loss_out[0] = total / denom;
   }
 }
 
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(256) void ln_relu_bwd_rows_kernel(
 
 // ---- launchers -------------------------------------------------------------------------------------
 void launch_oad_loss(const float* const* logit_ptrs, const float* const* target_ptrs, const int* lens, int n_clips, int C,
-                     float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s) {
-  oad_loss_kernel<<<1, 64 * OAD_WAVES, 0, s>>>(logit_ptrs, target_ptrs, lens, n_clips, C, loss_out, dlogit_ptrs, grad_scale);
+                     float* loss_out, float* const* dlogit_ptrs, float grad_scale, hipStream_t s, bool sum) {
+  oad_loss_kernel<<<1, 64 * OAD_WAVES, 0, s>>>(logit_ptrs, target_ptrs, lens, n_clips, C, loss_out, dlogit_ptrs, grad_scale, sum ? 1.0f : (float)n_clips);
 }
 void launch_gather_dlogits(bool bf16, const float* const* dl_ptrs, const int* rowoff, const int* sorted_clip, int t_max,
                            int nrows, int C, int Cpad, void* out, hipStream_t s) {

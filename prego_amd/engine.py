@@ -366,9 +366,11 @@ class MiniRoadEngine:
                     gru_launches=n[1].value, pack_ms=d[3].value, pack_launches=n[2].value, pack_bytes=d[4].value)
 
 
-def oad_loss(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0):
-    """OadLoss on the device (criterions/loss.py:15-34) for uniform [B,T,C] tensors.
+def oad_loss(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True, grad_scale: float = 1.0, reduction: str = "mean"):
+    """OadLoss on the device (criterions/loss.py:15-34) for uniform [B,T,C] tensors; reduction 'mean' or 'sum' (loss.py:30-33).
     Returns (loss scalar tensor, dlogits [B,T,C] or None)."""
+    if reduction not in ("mean", "sum"):
+        raise PregoError(f"oad_loss: reduction {reduction!r} (the reference knows 'mean' and 'sum', loss.py:30-33)")
     lib = _lib.load()
     if target.shape[1] != logits.shape[1]:
         # `Transformer` emits ONE logit row per window ([B,1,C], ViT.py:140) while the target keeps every frame ([B,T,C]):
@@ -389,6 +391,6 @@ def oad_loss(logits: torch.Tensor, target: torch.Tensor, want_grad: bool = True,
     tp = ptr_array([target.data_ptr() + b * T * Cn * 4 for b in range(B)])
     dp = None if dl is None else ptr_array([dl.data_ptr() + b * T * Cn * 4 for b in range(B)])
     with torch.cuda.device(dev):
-        check(lib.prego_oad_loss(B, lens_arr, lp, tp, Cn, C.c_void_p(loss.data_ptr()), dp, float(grad_scale),
-                                 C.c_void_p(_stream_ptr(dev))))
+        check(lib.prego_oad_loss_reduce(B, lens_arr, lp, tp, Cn, 1 if reduction == "sum" else 0, C.c_void_p(loss.data_ptr()), dp, float(grad_scale),
+                                        C.c_void_p(_stream_ptr(dev))))
     return loss, dl

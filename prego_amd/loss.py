@@ -13,10 +13,10 @@ from .registry import CRITERIONS
 class OadLoss(nn.Module):
     def __init__(self, cfg, reduction="mean"):
         super().__init__()
-        if reduction != "mean":
-            raise NotImplementedError("the reference only ever builds OadLoss with reduction='mean' (loss.py:9)")
+        if reduction not in ("mean", "sum"):         # loss.py:30-33 knows these two (anything else leaves `loss` unbound there)
+            raise ValueError(f"OadLoss: reduction {reduction!r}: expected 'mean' or 'sum'")
         self.reduction = reduction
         self.num_classes = cfg["num_classes"]
 
     def forward(self, out_dict, target):
-        return oad_loss_autograd(out_dict["logits"], target)
+        return oad_loss_autograd(out_dict["logits"], target, self.reduction)

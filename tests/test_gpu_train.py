@@ -32,6 +32,29 @@ def _build(cfg, sd):
     return m.train(), build_criterion(cfg, "cuda:0")
 
 
+def test_g4s_oadloss_reduction_sum_and_mean_against_the_reference():
+    """CRITERIONS["NONUNIFORM"] with reduction='sum' (criterions/loss.py:8-11,30-33): value and dL/dlogits from the HIP kernel against
+    what the reference's OadLoss produced (fixture G4s: an all-zero padding row and a multi-label row among the last frames), through the
+    registry class with autograd, and through the C ABI entry point with a gradient scale"""
+    from prego_amd.loss import OadLoss
+    from prego_amd.engine import oad_loss
+    g = np.load(os.path.join(G, "g4s_oadloss_sum.npz"))
+    cfg = assembly101_cfg()
+    tgt = torch.from_numpy(g["target"]).cuda()
+    for red in ("mean", "sum"):
+        lg = torch.from_numpy(g["logits"]).cuda().requires_grad_(True)
+        loss = OadLoss(cfg, reduction=red)({"logits": lg}, tgt)
+        loss.backward()
+        ref = float(g[f"loss_{red}"])
+        assert abs(loss.item() - ref) < 2e-6 * max(1.0, abs(ref)), (red, loss.item(), ref)
+        assert np.abs(lg.grad.cpu().numpy() - g[f"dlogits_{red}"]).max() < 2e-7
+        l2, dl = oad_loss(lg.detach(), tgt, want_grad=True, grad_scale=128.0, reduction=red)       # --amp: scaled gradients
+        assert abs(l2.item() - ref) < 2e-6 * max(1.0, abs(ref))
+        assert np.abs(dl.cpu().numpy() - 128.0 * g[f"dlogits_{red}"]).max() < 3e-5
+    with pytest.raises(ValueError):
+        OadLoss(cfg, reduction="none")
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_g4b_loss_and_grads_full_dims(dtype):
     g = np.load(os.path.join(G, "g4b_miniroad_train_full.npz"))

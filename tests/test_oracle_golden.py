@@ -109,6 +109,16 @@ def test_g4_loss_grads_adamw_small():
                 assert np.abs(sd[k] - g[f"param{step + 1}." + k]).max() < 2e-6, k
 
 
+def test_g4s_oadloss_reduction_sum():
+    """OadLoss(reduction='sum') of the reference (criterions/loss.py:30-33) beside 'mean': value and gradient"""
+    g = _ld("g4s_oadloss_sum.npz")
+    lg, tg = g["logits"].astype(np.float64), g["target"].astype(np.float64)
+    for red in ("mean", "sum"):
+        assert abs(O.oad_loss(lg, tg, red) - float(g[f"loss_{red}"])) < 2e-6 * max(1.0, abs(float(g[f"loss_{red}"])))
+        assert np.abs(O.oad_loss_grad(lg, tg, red) - g[f"dlogits_{red}"]).max() < 2e-7
+    assert abs(float(g["loss_sum"]) - 6 * float(g["loss_mean"])) < 1e-4
+
+
 def test_g4b_loss_grads_full_dims():
     g = _ld("g4b_miniroad_train_full.npz")
     cfg = assembly101_cfg(dropout=0.0)
