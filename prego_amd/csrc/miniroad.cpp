@@ -683,7 +683,9 @@ static void refresh_placement(prego_miniroad* h) {
 // of 24 units (six super-rounds of four) per feed-forward XCD, a GI ring of 256 units = 4 chunks.  The rings come out of the caller's
 // workspace (0.9 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer
 // (the head runs once, behind the pass).
-static const int kSplitGiRingUnits = 256, kSplitSg = 4, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
+static const int kSplitGiRingUnits = 256, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
+static const int kSplitSg = (prego_tune_env("PREGO_SPLIT_SG") && kSplitRingPerXcd % std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) == 0)
+                                ? std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) : 4;     // units per super-round (debug library: sweep)
 static const int kSplitChunkUnitShift = prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
