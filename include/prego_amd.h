@@ -74,9 +74,16 @@ const char* prego_last_error(void);     /* most recent error text of the calling
 
 /* MROAD.__init__ (rnn.py:21-49): d_rgb/d_flow = FEATURE_SIZES of cfg['rgb_type'/'flow_type'] (0 when
  * --no_rgb/--no_flow), emb = cfg['embedding_dim'], hid = cfg['hidden_dim'], n_classes = cfg['num_classes'].
- * Supported on gfx950: hid == 1024, emb % 512 == 0 (<= 4096), d_rgb % 64 == 0, d_flow % 64 == 0, n_classes <= 128. */
+ * Supported on gfx950: hid in {512, 1024, 2048} (see prego_miniroad_create_layers), emb % 512 == 0 (<= 4096), d_rgb % 64 == 0,
+ * d_flow % 64 == 0, n_classes <= 128.  One GRU layer. */
 int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
                           int compute_dtype);
+/* The same with cfg['num_layers'] (rnn.py:32,38: nn.GRU(embedding_dim, hidden_dim, num_layers)): 1 or 2.  Hidden sizes (rnn.py:31): 512,
+ * 1024, 2048 with 16-bit operands; 512, 1024 with PREGO_F32; 1024 with PREGO_F16X2 (the recurrence keeps its slice of W_hh in registers:
+ * what does not fit is refused here with a message).  Two layers: PREGO_F32 / PREGO_BF16 / PREGO_F16.  Inference (forward without
+ * PREGO_FWD_KEEP) covers all of these; training, prego_miniroad_step and the split pass stay with hidden_dim 1024 / one layer. */
+int prego_miniroad_create_layers(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes, int num_layers,
+                                 int compute_dtype);
 void prego_miniroad_destroy(prego_miniroad* h);
 /* text of the last error raised by an entry point of THIS handle (handles are independent: one per (device, stream)) */
 const char* prego_miniroad_last_error(const prego_miniroad* h);
@@ -89,6 +96,11 @@ const char* prego_miniroad_last_error(const prego_miniroad* h);
 int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1_w, const float* layer1_b, const float* ln_w,
                                const float* ln_b, const float* w_ih, const float* w_hh, const float* b_ih,
                                const float* b_hh, const float* fc_w, const float* fc_b, prego_stream_t stream);
+
+/* Layer 1 of a two-layer handle (state_dict keys gru.weight_ih_l1 [3*hid, hid], gru.weight_hh_l1 [3*hid, hid], gru.bias_ih_l1,
+ * gru.bias_hh_l1 [3*hid]); layer 0 comes with prego_miniroad_set_weights.  h0 / h_last of such a handle are [2][n_clips][hid]. */
+int prego_miniroad_set_gru_layer(prego_miniroad* h, int layer, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                                 prego_stream_t stream);
 
 /* Largest number of clips one forward() call accepts (8192).  The call packs them, longest first, into its recurrence
  * slots (continuous batching: a slot runs several clips back to back, h restarts from 0 at every clip boundary), so

@@ -503,7 +503,33 @@ def g4s():
     print("g4s", float(save["loss_mean"]), float(save["loss_sum"]))
 
 
-GROUPS = {"g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
+def g10():
+    """MROAD eval at the dimensions the shipped yamls do not use (rnn.py:31-38 takes any): hidden_dim 512 / 2048 and num_layers 2.
+    Full feature and embedding sizes (2048 + 2048 -> 2048), 86 classes, head gain 8; two clips of 96 and 40 frames with non-zero flow;
+    probabilities, argmax and the final state h_n [layers, H] of each clip."""
+    from model import build_model
+    for tag, hid, layers in (("h512", 512, 1), ("h2048", 2048, 1), ("h1024_l2", 1024, 2), ("h512_l2", 512, 2)):
+        cfg = assembly101_cfg(hidden_dim=hid, num_layers=layers)
+        sd = W.miniroad_state_dict(cfg, seed=20, head_gain=8.0)
+        model = _load(build_model(cfg, "cpu"), sd).eval()
+        save = {}
+        for i, T in enumerate((96, 40)):
+            rgb = W.tsn_features((1, T, 2048), 20, f"g10.{tag}.rgb.{i}")
+            flow = W.tsn_features((1, T, 2048), 20, f"g10.{tag}.flow.{i}")
+            with torch.no_grad():
+                out = model(torch.from_numpy(rgb), torch.from_numpy(flow))["logits"][0].numpy()
+                x = model.layer1(torch.cat((torch.from_numpy(rgb), torch.from_numpy(flow)), 2))
+                _, hn = model.gru(x, torch.zeros(layers, 1, hid))
+            srt = np.sort(out, 1)
+            save[f"probs{i}"] = out.astype(np.float32)
+            save[f"argmax{i}"] = out.argmax(1).astype(np.int32)
+            save[f"margin{i}"] = (srt[:, -1] - srt[:, -2]).astype(np.float32)
+            save[f"h_n{i}"] = hn[:, 0].numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, f"g10_miniroad_eval_{tag}.npz"), **save)
+        print("g10", tag, "min margin", float(min(save["margin0"].min(), save["margin1"].min())))
+
+
+GROUPS = {"g10": g10, "g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -100,16 +100,29 @@ def miniroad_forward(sd, rgb, flow=None, training=False, h0=None, dt=np.float64,
     y = linear(x, w1, p["layer1.0.bias"])                                # rnn.py:40
     e = np.maximum(layernorm(y, p["layer1.1.weight"], p["layer1.1.bias"]), 0.0)  # :41-42
     gi = linear(e, p["gru.weight_ih_l0"], p["gru.bias_ih_l0"])            # GRU input proj
-    h = np.zeros((B, H), dtype=dt) if h0 is None else np.asarray(h0, dtype=dt)  # rnn.py:49,60
-    hs = np.empty((B, T, H), dtype=dt)
-    for t in range(T):                                                    # rnn.py:61
-        h, _ = gru_step(gi[:, t], h, p["gru.weight_hh_l0"], p["gru.bias_hh_l0"])
-        hs[:, t] = h
+    n_layers = sum(1 for k in p if k.startswith("gru.weight_hh_l"))       # nn.GRU(.., num_layers) (rnn.py:32,38): gru.*_l0, _l1, ...
+    h0a = None if h0 is None else np.asarray(h0, dtype=dt)
+    h_last = []
+    gi0 = gi
+    inp = None
+    for l in range(n_layers):
+        if l > 0:                                                         # layer l's input is layer l - 1's h_t (no dropout between layers: nn.GRU default)
+            gi = linear(inp, p[f"gru.weight_ih_l{l}"], p[f"gru.bias_ih_l{l}"])
+        if h0a is None:
+            h = np.zeros((B, H), dtype=dt)                                # rnn.py:49,60
+        else:
+            h = h0a if (n_layers == 1 and h0a.ndim == 2) else h0a[l]
+        hs = np.empty((B, T, H), dtype=dt)
+        for t in range(T):                                                # rnn.py:61
+            h, _ = gru_step(gi[:, t], h, p[f"gru.weight_hh_l{l}"], p[f"gru.bias_hh_l{l}"])
+            hs[:, t] = h
+        h_last.append(h)
+        inp = hs
     logits = linear(np.maximum(hs, 0.0), p["f_classification.0.weight"],
                     p["f_classification.0.bias"])                         # rnn.py:62-64
     out = {"logits": logits if training else softmax(logits)}            # rnn.py:66-70
     if keep:
-        out.update(y=y, e=e, gi=gi, h=hs, raw_logits=logits, h_last=h)
+        out.update(y=y, e=e, gi=gi0, h=hs, raw_logits=logits, h_last=h_last[0] if n_layers == 1 else np.stack(h_last))
     return out
 
 

@@ -21,7 +21,7 @@ E_TIMEOUT = -4
 # every symbol include/prego_amd.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "prego_abi_version", "prego_last_error",
-    "prego_miniroad_create", "prego_miniroad_destroy", "prego_miniroad_last_error", "prego_miniroad_set_weights",
+    "prego_miniroad_create", "prego_miniroad_create_layers", "prego_miniroad_set_gru_layer", "prego_miniroad_destroy", "prego_miniroad_last_error", "prego_miniroad_set_weights",
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
     "prego_miniroad_set_dropout", "prego_oad_loss", "prego_oad_loss_reduce",
@@ -63,6 +63,8 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_abi_version.restype = i32
     lib.prego_last_error.restype = C.c_char_p
     lib.prego_miniroad_create.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32]
+    lib.prego_miniroad_create_layers.argtypes = [C.POINTER(vp), i32, i32, i32, i32, i32, i32, i32]
+    lib.prego_miniroad_set_gru_layer.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     lib.prego_miniroad_destroy.argtypes = [vp]
     lib.prego_miniroad_destroy.restype = None
     lib.prego_miniroad_last_error.argtypes = [vp]

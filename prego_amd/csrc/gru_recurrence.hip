@@ -293,13 +293,18 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   auto publish = [&](int ct, int buf, unsigned tag, bool zero) {
     const int off = buf * buf_stride + ((ucol / KF) * GRU_MAX_TILES + ct) * 1024 + ((((ucol % KF) / EPL) << 4) + l15) * 16 +
                     (ucol % EPL) * (int)sizeof(WT);
-    if constexpr (BF) {
+    if constexpr (BF && OWN_R == 2) {
       f32x2 hv = {zero ? 0.f : hreg[ct][0], zero ? 0.f : hreg[ct][1]};
       hv[0] = __builtin_amdgcn_fmed3f(hv[0], -1.9921875f, 1.9921875f);
       hv[1] = __builtin_amdgcn_fmed3f(hv[1], -1.9921875f, 1.9921875f);
       const unsigned v = (op16<OT>::pack2(hv[0], hv[1]) & 0xBFFFBFFFu) | (tag ? 0x40004000u : 0u);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
+    } else if constexpr (BF) {                 // one 16-bit element per lane (UT = 1: hidden sizes whose weight slice leaves room for one row tile)
+      const float hv = __builtin_amdgcn_fmed3f(zero ? 0.f : hreg[ct][0], -1.9921875f, 1.9921875f);
+      const unsigned short v = (unsigned short)(((unsigned)op16<OT>::cvt(hv) & 0xBFFFu) | (tag ? 0x4000u : 0u));
+      if (local) __builtin_amdgcn_raw_buffer_store_b16(v, rs, off, 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b16(v, rs, off, 0, AUX_SC1);
     } else {
       const unsigned v = tag_f32(zero ? 0.f : hreg[ct][0], tag);
       if (local) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
@@ -577,14 +582,15 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         if (sidx[ct] < na) {
           const size_t o = (size_t)(rbase + sidx[ct]) * HID + ucol;
           if (a.h_relu_out) {
+            // a.out_floor: 0 = relu(h_t) (rnn.py:62, the classifier's operand); -inf = h_t itself (the next layer's input of a stacked GRU)
             if constexpr (BF) {
               bf16_t* p = (bf16_t*)a.h_relu_out + o;
-              if constexpr (OWN_R == 2) *(unsigned*)p = op16<OT>::pack2(fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f));
-              else p[0] = op16<OT>::cvt(fmaxf(hreg[ct][0], 0.f));
+              if constexpr (OWN_R == 2) *(unsigned*)p = op16<OT>::pack2(fmaxf(hreg[ct][0], a.out_floor), fmaxf(hreg[ct][1], a.out_floor));
+              else p[0] = op16<OT>::cvt(fmaxf(hreg[ct][0], a.out_floor));
             } else {
               float* p = (float*)a.h_relu_out + o;
 #pragma unroll
-              for (int e = 0; e < OWN_R; ++e) p[e] = fmaxf(hreg[ct][e], 0.f);
+              for (int e = 0; e < OWN_R; ++e) p[e] = fmaxf(hreg[ct][e], a.out_floor);
             }
           }
           if constexpr (TRAIN) {
@@ -994,7 +1000,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_mt_kernel(GruArgs a) {
         const bool restart = (t + 1 == nstart[ct]);
         publish(ct, tl & 1, (unsigned)((tl >> 1) & 1), restart, more && sidx[ct] < na_n);
         {
-          const unsigned hv = op16<OT>::pack2(fmaxf(hreg[ct][0], 0.f), fmaxf(hreg[ct][1], 0.f));
+          const unsigned hv = op16<OT>::pack2(fmaxf(hreg[ct][0], a.out_floor), fmaxf(hreg[ct][1], a.out_floor));
           const long long o = ((long long)(rbase + sidx[ct]) * HID + ucol) * 2;
           __builtin_amdgcn_raw_buffer_store_b32(hv, rs_hr, (col_live && a.h_relu_out != nullptr) ? (int)o : OOR, 0, 0);
         }
@@ -1068,8 +1074,41 @@ int launch_gru_recurrence_pass(int hid, GruArgs a, hipStream_t s) {
   return 0;
 }
 
+// other hidden sizes (rnn.py:31: any cfg['hidden_dim']): the classic kernel, inference instantiations only.  What decides is the
+// weight slice a workgroup keeps in registers (3 gates x 16 UT rows x H / 4 per wave): 16-bit operands H = 512 (UT = 2: 96 registers) and
+// H = 2048 (UT = 1: 192, 128 workgroups per group = two groups of four XCDs, sc1 hand-off); fp32 operands H = 512 (UT = 1: 96)
+template <int HID>
+static int launch_gru_recurrence_other(bool bf16, int nct, const GruArgs& a, int grid, hipStream_t s) {
+#define LAUNCH_O(WT, UT, NCT)                                                                                    \
+  do {                                                                                                             \
+    const size_t lds = (size_t)2 * 4 * 3 * UT * 64 * 16;                                                           \
+    if (a.gi_bf16) gru_recurrence_kernel<WT, HID, UT, NCT, false, true><<<grid, 256, lds, s>>>(a);                \
+    else gru_recurrence_kernel<WT, HID, UT, NCT, false><<<grid, 256, lds, s>>>(a);                                \
+  } while (0)
+  constexpr int UTB = HID <= 1024 ? 2 : 1;
+  if (bf16) {
+    if (!a.gi_bf16) return -1;                 // 16-bit operands run with 16-bit GI (inference)
+    if (a.f16) { if (nct == 1) LAUNCH_O(f16_t, UTB, 1); else if (nct == 2) LAUNCH_O(f16_t, UTB, 2); else if (nct <= 4) LAUNCH_O(f16_t, UTB, 4); else return -1; }
+    else { if (nct == 1) LAUNCH_O(bf16_t, UTB, 1); else if (nct == 2) LAUNCH_O(bf16_t, UTB, 2); else if (nct <= 4) LAUNCH_O(bf16_t, UTB, 4); else return -1; }
+  } else {
+    if constexpr (HID > 512) return -1;
+    else { if (a.gi_bf16) return -1; if (nct == 1) LAUNCH_O(float, 1, 1); else if (nct == 2) LAUNCH_O(float, 1, 2); else if (nct <= 4) LAUNCH_O(float, 1, 4); else return -1; }
+  }
+#undef LAUNCH_O
+  return 0;
+}
+// workgroups per recurrence group for (operand type, hidden size): H / (16 UT)
+int gru_group_size(bool bf16, int hid) { return hid / (bf16 && hid <= 1024 ? 32 : 16); }
+bool gru_hidden_supported(bool bf16, int hid) { return hid == 1024 || hid == 512 || (bf16 && hid == 2048); }
+
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s) {
-  if (hid != 1024) return -1;
+  if (hid != 1024) {
+    if (!gru_hidden_supported(bf16, hid)) return -1;
+    if (a.keep_r != nullptr || a.h_raw_out != nullptr) return -1;          // training keeps hidden_dim 1024
+    if (!a.armed) gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, gru_hx_bytes(bf16, hid, a.G) / 2 / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);
+    const int grid = a.G * gru_group_size(bf16, hid);
+    return hid == 512 ? launch_gru_recurrence_other<512>(bf16, nct, a, grid, s) : launch_gru_recurrence_other<2048>(bf16, nct, a, grid, s);
+  }
   const int P = bf16 ? 32 : 64;
   const size_t buf_bytes = gru_hx_bytes(bf16, hid, a.G) / 2;
   if (!a.armed) gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, buf_bytes / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);

@@ -86,6 +86,7 @@ struct GruArgs {
   int units_per_chunk, units_last;   // what gi_cnt[c] must reach (last chunk: units_last)
   unsigned gi_row_mask;
   PassHandshake hs;            // pass mode only
+  float out_floor;             // h_relu_out = max(h_t, out_floor): 0 = relu(h_t) (the classifier's operand), -inf = h_t (next GRU layer's input)
 };
 // ---- split pass (ff_pass.hip + the PASS instantiation of gru_recurrence.hip): the feed-forward of a whole pass as one persistent
 // kernel on XCDs xcd_lo .. 7 beside one persistent recurrence launch on XCDs 0 .. xcd_lo - 1
@@ -123,6 +124,8 @@ struct FfPassArgs {
 int launch_ff_pass(const FfPassArgs& a, hipStream_t s);
 // the recurrence of a whole pass as one launch on XCDs 0 .. a.Gd - 1 (GruArgs pass fields); 16-bit operands, 16-bit GI ring, one tile
 int launch_gru_recurrence_pass(int hid, GruArgs a, hipStream_t s);
+int gru_group_size(bool bf16, int hid);            // workgroups per recurrence group
+bool gru_hidden_supported(bool bf16, int hid);     // 1024; 512; 2048 with 16-bit operands
 void launch_gru_arm(bool bf16, int hid, int G, void* hx, unsigned* sync, hipStream_t s);   // must precede it in the stream (see there)
 
 // what a recurrence launch needs re-armed before it starts (gru_recurrence.hip: buffer 0 := tag 1 everywhere, buffer 1 := 0,

@@ -9,6 +9,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <thread>
 #include <cstdarg>
@@ -85,6 +86,10 @@ struct prego_miniroad {
   void* w_c = nullptr;          // [ncls_pad][H] WT zero padded
   float* b_c = nullptr;         // [ncls_pad]
   bool have_weights = false;
+  // nn.GRU(embedding_dim, hidden_dim, num_layers) with num_layers == 2 (rnn.py:32,38): layer 1's operands (gru.*_l1; its input is layer 0's
+  // h_t, so weight_ih_l1 is [3H][H]).  Inference only; hidden state [layers][slots][H]
+  int layers = 1;
+  void* l2_w_ih = nullptr; void* l2_w_hh = nullptr; float* l2_bias2 = nullptr; float* l2_b_hn = nullptr; bool have_layer2 = false;
   // recurrence scratch
   void* hx = nullptr;           // [G][2][64][H] WT
   unsigned* flags = nullptr;    // [G*P] + abort word
@@ -182,11 +187,25 @@ extern "C" const char* prego_last_error(void) { return g_err.c_str(); }
 
 extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
                                      int compute_dtype) {
+  return prego_miniroad_create_layers(out, d_rgb, d_flow, emb, hid, n_classes, 1, compute_dtype);
+}
+extern "C" int prego_miniroad_create_layers(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes, int num_layers,
+                                            int compute_dtype) {
   if (!out) return fail(PREGO_EINVAL, "out is NULL");
   *out = nullptr;
   if (compute_dtype != PREGO_F32 && compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16 && compute_dtype != PREGO_F16X2)
     return fail(PREGO_EINVAL, "compute_dtype %d", compute_dtype);
-  if (hid != 1024) return fail(PREGO_EINVAL, "hidden_dim %d unsupported: the register-resident recurrence is built for 1024", hid);
+  // The recurrence keeps a workgroup's slice of W_hh in registers (3 gates x 16 or 32 rows x H): what fits decides.  16-bit operands:
+  // 512, 1024, 2048; exact-fp32 operands: 512, 1024 (a 16-row slice of H = 2048 is 384 registers per lane); split operands: 1024
+  {
+    const bool op16 = compute_dtype == PREGO_BF16 || compute_dtype == PREGO_F16;
+    const bool ok = compute_dtype == PREGO_F16X2 ? hid == 1024 : gru_hidden_supported(op16, hid);
+    if (!ok) return fail(PREGO_EINVAL, "hidden_dim %d unsupported with compute_dtype %d: 512 / 1024 / 2048 with 16-bit operands, 512 / 1024 with fp32 "
+                                       "operands, 1024 with fp16x2 (the recurrence keeps its W_hh slice in registers)", hid, compute_dtype);
+  }
+  if (num_layers < 1 || num_layers > 2) return fail(PREGO_EINVAL, "num_layers %d: 1 or 2", num_layers);
+  if (num_layers == 2 && compute_dtype == PREGO_F16X2)
+    return fail(PREGO_EINVAL, "num_layers 2 with fp16x2 operands: the split-operand recurrence hands fp32 relu(h) to the classifier only (use fp32)");
   if (emb <= 0 || emb % 512 || emb > 4096) return fail(PREGO_EINVAL, "embedding_dim %d must be a multiple of 512, <= 4096", emb);
   if (d_rgb < 0 || d_flow < 0 || d_rgb + d_flow <= 0 || (d_rgb % 64) || (d_flow % 64))
     return fail(PREGO_EINVAL, "feature sizes %d/%d must be multiples of 64", d_rgb, d_flow);
@@ -202,7 +221,8 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   h->f16 = compute_dtype == PREGO_F16;
   h->x2 = compute_dtype == PREGO_F16X2;      // operand storage 4 bytes per element ([hi | lo] fp16), P = 64, G = 4 like fp32 operands
   h->n_cu = prop.multiProcessorCount;
-  h->P = h->bf16 ? 32 : 64;
+  h->layers = num_layers;
+  h->P = h->x2 ? hid / 16 : gru_group_size(h->bf16, hid);      // 1024: 32 (16-bit) / 64 workgroups per group
   h->G = std::min(h->bf16 ? 8 : 4, h->n_cu / h->P);
   if (h->G < 1) { delete h; return fail(PREGO_EINVAL, "device has %d CUs, the recurrence needs >= %d", prop.multiProcessorCount, h->bf16 ? 32 : 64); }
   const size_t es = h->bf16 ? 2 : 4;
@@ -216,7 +236,11 @@ extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow
   A(&h->hx, h->x2 ? gru_x2_hx_bytes(H, h->G) : gru_hx_bytes(h->bf16, H, h->G));
   if (h->x2) A((void**)&h->x2_scale, 6 * sizeof(float));
   A((void**)&h->flags, ((size_t)h->G * h->P + 16) * sizeof(unsigned));
-  A((void**)&h->h_state, (size_t)max_slots_of(h) * H * 4);
+  A((void**)&h->h_state, (size_t)num_layers * max_slots_of(h) * H * 4);
+  if (num_layers == 2) {
+    A(&h->l2_w_ih, (size_t)3 * H * H * es); A(&h->l2_w_hh, (size_t)3 * H * H * es);
+    A((void**)&h->l2_bias2, 3 * H * 4); A((void**)&h->l2_b_hn, H * 4);
+  }
   A((void**)&h->d_ptrs, (size_t)4 * max_clips_of(h) * sizeof(void*));
   // plan tables pre-sized here so that forward() allocates nothing: 131 072 steps (a 72-minute clip at 30 frames/s; the longest
   // Epic-tent-O video has 31 114 frames) and max_clips clips; only a longer clip than that makes forward() grow them
@@ -276,7 +300,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (!h) return;
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->tile_ctr, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale, h->l2_w_ih, h->l2_w_hh, h->l2_bias2, h->l2_b_hn};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& ev : h->ev_pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
   if (h->pin_ev) { if (h->pin_busy) (void)hipEventSynchronize(h->pin_ev); (void)hipEventDestroy(h->pin_ev); }
@@ -322,6 +346,23 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
   HIPCHK(hipMemcpyAsync(h->b_hn, b_hh + 2 * H, H * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   h->have_weights = true;
+  return PREGO_OK;
+}
+
+extern "C" int prego_miniroad_set_gru_layer(prego_miniroad* h, int layer, const float* w_ih, const float* w_hh, const float* b_ih,
+                                            const float* b_hh, prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (layer != 1 || h->layers != 2) return fail(PREGO_EINVAL, "set_gru_layer: layer %d of a %d-layer handle (layer 0 comes with set_weights)", layer, h->layers);
+  if (!w_ih || !w_hh || !b_ih || !b_hh) return fail(PREGO_EINVAL, "set_gru_layer: NULL tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = h->hid;
+  launch_pad_convert(h->bf16, w_ih, 3 * H, H, H, h->l2_w_ih, 3 * H, H, s, h->f16);
+  launch_pad_convert(h->bf16, w_hh, 3 * H, H, H, h->l2_w_hh, 3 * H, H, s, h->f16);
+  launch_add_vec(b_ih, b_hh, h->l2_bias2, 3 * H, 2 * H, s);
+  HIPCHK(hipMemcpyAsync(h->l2_b_hn, b_hh + 2 * H, H * 4, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipGetLastError());
+  h->have_layer2 = true;
   return PREGO_OK;
 }
 
@@ -894,6 +935,9 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   HandleScope scope_(h);
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "forward before set_weights");
+  if (h->layers == 2 && !h->have_layer2) return fail(PREGO_EINVAL, "forward of a 2-layer handle before set_gru_layer(1)");
+  if ((flags & PREGO_FWD_KEEP) && (h->hid != 1024 || h->layers != 1))
+    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with hidden_dim %d / num_layers %d: the training kernels (kept gates, BPTT) are built for 1024 / 1", h->hid, h->layers);
   if (n_clips <= 0 || !lens) return fail(PREGO_EINVAL, "no clips");
   if (n_clips > max_clips_of(h)) return fail(PREGO_EINVAL, "%d clips > max_clips %d per call", n_clips, max_clips_of(h));
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "rgb pointer array is NULL");
@@ -925,7 +969,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     int r_try = h->split_env > 0 ? h->split_env : 3;       // unset: the candidate with the best estimate (below); 3 until estimated
     const bool with_flow_ = flow != nullptr && h->d_flow > 0 && flow[0] != nullptr;
     // everything but the placement (which a handle's first, chunked, call establishes)
-    const bool shape_ok = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
+    const bool shape_ok = h->split_env != 0 && r_try >= 1 && r_try <= 6 && h->bf16 && h->hid == 1024 && h->layers == 1 && !want_single && !hostfeat && h->G == 8 && !h->no_local &&
                           h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * r_try && frames >= 262144 &&
                           frames < (1ll << 31) - 65536 && (out || argmax) && split_workspace_ok(h, r_try, workspace_bytes) &&
                           (h->d_rgb > 0 ? h->d_rgb : h->d_flow) >= 128 &&
@@ -1090,8 +1134,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                                                              // runs under the recurrence of chunk c, before the head of chunk c)
   // initial state (sorted order)
   const int H = h->hid, E = h->emb;
-  if (h0) launch_permute_rows(h0, h->h_state, h->d_sorted, n_slots, H, 1, s);        // one clip per slot here
-  else HIPCHK(hipMemsetAsync(h->h_state, 0, (size_t)n_slots * H * 4, s));
+  // state of layer l: h_state + l * slot_stride; h0 / h_last of a 2-layer handle are [layers][n_clips][H] (nn.GRU's h_0 / h_n layout)
+  const size_t slot_stride = (size_t)max_slots_of(h) * H;
+  for (int l = 0; l < h->layers; ++l) {
+    if (h0) launch_permute_rows(h0 + (size_t)l * n_clips * H, h->h_state + l * slot_stride, h->d_sorted, n_slots, H, 1, s);        // one clip per slot here
+    else HIPCHK(hipMemsetAsync(h->h_state + l * slot_stride, 0, (size_t)n_slots * H * 4, s));
+  }
 
   const int slots = (n_slots + h->G - 1) / h->G;
   const int nct = (slots + 15) / 16;          // live 16-clip tiles per group (kernels: 1, 2, 4, 8)
@@ -1126,7 +1174,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   bool packed = false;            // X already holds this chunk (packed on the side stream under the previous recurrence)
   bool l1_done = false;           // Y already holds layer1 of this chunk (XCD overlap: the worker GEMM ran under the previous recurrence)
   refresh_placement(h);
-  const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8 && h->placement == 1 && !h->no_local;
+  const bool overlap_ok = h->xcd_overlap && prefetch && i16 && h->bf16 && h->G == 8 && h->placement == 1 && !h->no_local && h->layers == 1 && h->hid == 1024;
   if (overlap_ok) HIPCHK(hipMemsetAsync(h->tile_ctr, 0, 4096 * sizeof(unsigned), s));
   // every exit path after a fork joins the side stream: an error return while the next chunk's pack is still writing X / RM
   // would leave the caller's stream unordered against it (the next forward on this handle could race with that pack)
@@ -1184,6 +1232,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.sync = h->no_local ? nullptr : h->flags;   // flags[0..15] double as the rendezvous words
     ga.armed = (arm_fuse && rows > 0) ? 1 : 0;
     ga.no_mt = h->no_mt ? 1 : 0;
+    ga.out_floor = h->layers == 2 ? -INFINITY : 0.f;      // 2 layers: layer 0 hands h_t itself to layer 1 (below)
     {
       // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
       // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)
@@ -1248,6 +1297,22 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       packed = true;
     }
 
+    if (h->layers == 2) {
+      // second GRU layer (nn.GRU num_layers = 2, rnn.py:38,61): its input is layer 0's h_t - the first launch stored h_t itself
+      // (out_floor = -inf) in HR -, GI and HR are reused in place: gi' = h W_ih_l1^T + b (GI of layer 0 is dead), then the recurrence of
+      // layer 1 over the same steps from its own state, relu(h'_t) -> HR for the classifier
+      ev = ev_begin(h, 0, s);
+      proj(HR, H, h->l2_w_ih, H, h->l2_bias2, GI, 3 * H, rows, 3 * H, H);
+      ev_end(ev, s);
+      if (h->timing) h->gemm_flop += 2.0 * rows * 3.0 * H * H;
+      GruArgs g2 = ga;
+      g2.whh = h->l2_w_hh; g2.b_hn = h->l2_b_hn; g2.h_state = h->h_state + slot_stride; g2.out_floor = 0.f;
+      g2.armed = 0;                 // the exchange buffers / rendezvous words were used by layer 0's launch: re-arm (launcher)
+      g2.Gd = 0;
+      ev = ev_begin(h, 1, s);
+      if (launch_gru_recurrence(h->bf16, H, nct_l, g2, s)) return fail(PREGO_EINVAL, "recurrence (layer 1): unsupported hid=%d nct=%d", H, nct_l);
+      ev_end(ev, s);
+    }
     if (out || argmax) {
       if (launch_head_softmax(h->bf16, HR, h->w_c, h->b_c, plan, base, rows, H, h->ncls,
                               (flags & PREGO_FWD_SOFTMAX) ? 1 : 0, d_out_ptrs, d_arg_ptrs, s, RM + (size_t)(ci & 1) * cap_rows * 8, h->f16))
@@ -1257,7 +1322,8 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     t0 = t1;
     ++ci;
   }
-  if (h_last) launch_permute_rows(h->h_state, h_last, h->d_sorted, n_slots, H, 0, s);
+  if (h_last)
+    for (int l = 0; l < h->layers; ++l) launch_permute_rows(h->h_state + l * slot_stride, h_last + (size_t)l * n_clips * H, h->d_sorted, n_slots, H, 0, s);
   if (hostfeat && (h->feed_upto.empty() || h->feed_upto.back() < h->t_max))
     return fail(PREGO_EINVAL, "feed events cover steps < %d, the call has %d", h->feed_upto.empty() ? 0 : h->feed_upto.back(), h->t_max);
   if (h->meas_armed) { HIPCHK(hipEventRecord(h->ev_meas[1], s)); h->meas_pending = true; h->meas_armed = false; }
@@ -1272,6 +1338,8 @@ extern "C" int prego_miniroad_step(prego_miniroad* h, int n_streams, const float
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "step before set_weights");
   if (!h->bf16) return fail(PREGO_EINVAL, "step: the streaming fast path takes bf16 / fp16 handles (fp32 / fp16x2 operands: use forward() with h0 / h_last)");
+  if (h->hid != 1024 || h->layers != 1)
+    return fail(PREGO_EINVAL, "step: the streaming kernels are built for hidden_dim 1024, one GRU layer (hidden_dim %d, %d layers: use forward() with h0 / h_last)", h->hid, h->layers);
   if (n_streams < 1 || n_streams > 16) return fail(PREGO_EINVAL, "step: %d streams (1..16 per call)", n_streams);
   if (!h_state) return fail(PREGO_EINVAL, "step: h_state is NULL");
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "step: rgb is NULL");

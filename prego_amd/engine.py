@@ -47,7 +47,7 @@ class MiniRoadEngine:
     same speed, 8x less operand rounding, inference only) or 'fp32' (exact-fp32 MFMA, the parity mode)."""
 
     def __init__(self, d_rgb: int, d_flow: int, emb: int, hid: int, n_classes: int, device,
-                 compute_dtype: str = "bf16", lib=None):
+                 compute_dtype: str = "bf16", lib=None, num_layers: int = 1):
         # lib: tests that inject faults run a handle on libprego_amd_debug.so (_lib.load_debug()); everything else runs the product library
         self.lib = lib if lib is not None else _lib.load()
         self.device = torch.device(device)
@@ -60,8 +60,9 @@ class MiniRoadEngine:
         if compute_dtype not in codes:
             raise PregoError(f"compute_dtype {compute_dtype!r}: expected one of {sorted(codes)}")
         with torch.cuda.device(self.device):
-            check(self.lib.prego_miniroad_create(C.byref(h), d_rgb, d_flow, emb, hid, n_classes, codes[compute_dtype]))
+            check(self.lib.prego_miniroad_create_layers(C.byref(h), d_rgb, d_flow, emb, hid, n_classes, int(num_layers), codes[compute_dtype]))
         self.h = h
+        self.num_layers = int(num_layers)
         self.max_clips = self.lib.prego_miniroad_max_clips(self.h)
         self._ws: Optional[torch.Tensor] = None
         # fp16x2 rows are 34 KB (fp32 intermediates, split operands): 32 768 rows measured best there (262.6 against 269.4 ms per pass
@@ -90,6 +91,15 @@ class MiniRoadEngine:
         with torch.cuda.device(self.device):
             check(self.lib.prego_miniroad_set_weights(self.h, *[C.c_void_p(t.data_ptr()) for t in ts],
                                                       C.c_void_p(_stream_ptr(self.device))))
+            for l in range(1, self.num_layers):          # stacked GRU (rnn.py:38): gru.*_l1
+                tl = []
+                for k in (f"gru.weight_ih_l{l}", f"gru.weight_hh_l{l}", f"gru.bias_ih_l{l}", f"gru.bias_hh_l{l}"):
+                    t = sd[k].detach()
+                    if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                        t = t.to(self.device, torch.float32).contiguous()
+                    tl.append(t)
+                check(self.lib.prego_miniroad_set_gru_layer(self.h, l, *[C.c_void_p(t.data_ptr()) for t in tl], C.c_void_p(_stream_ptr(self.device))))
+                ts += tl
         self._keep = ts   # alive until the stream has consumed them
 
     # -- forward ---------------------------------------------------------------------------
@@ -116,19 +126,24 @@ class MiniRoadEngine:
             return ([] if want_out else None), ([] if want_argmax else None), (torch.empty((0, hid), device=self.device) if want_h_last else None)
         outs = [None] * n
         args = [None] * n
-        h_last = torch.empty((n, hid), dtype=torch.float32, device=self.device) if want_h_last else None
+        # GRU state: [n, hid]; a two-layer engine takes / returns nn.GRU's [layers, n, hid]
+        L = self.num_layers
+        st_shape = (lambda m: (m, hid) if L == 1 else (L, m, hid))
+        if h0 is not None and tuple(h0.shape) != st_shape(n):
+            raise PregoError(f"h0 {tuple(h0.shape)}: expected {st_shape(n)}")
+        h_last = torch.empty(st_shape(n), dtype=torch.float32, device=self.device) if want_h_last else None
         lens = [int(r.shape[0]) for r in src_list]
         single = h0 is not None or want_h_last
         for idx in plan_passes(lens, self.max_clips, single, {"fp32": 256, "fp16x2": 128}.get(self.compute_dtype, 512)):
-            sub_h0 = None if h0 is None else h0[idx].contiguous()
-            sub_hl = None if h_last is None else torch.empty((len(idx), hid), dtype=torch.float32, device=self.device)
+            sub_h0 = None if h0 is None else h0[..., idx, :].to(torch.float32).contiguous()
+            sub_hl = None if h_last is None else torch.empty(st_shape(len(idx)), dtype=torch.float32, device=self.device)
             sub_out, sub_arg = [None] * len(idx), [None] * len(idx)
             self._forward_pass(None if rgb is None else [rgb[i] for i in idx], None if flow is None else [flow[i] for i in idx], softmax,
                                want_out, want_argmax, sub_h0, sub_hl, sub_out, sub_arg, 0)
             for k, i in enumerate(idx):
                 outs[i], args[i] = sub_out[k], sub_arg[k]
             if h_last is not None:
-                h_last[idx] = sub_hl
+                h_last[..., idx, :] = sub_hl
         return (outs if want_out else None), (args if want_argmax else None), h_last
 
     # -- link-fed inference (Evaluate: the H2D copy of a batch under its forward) ------------------------------------------
@@ -210,20 +225,25 @@ class MiniRoadEngine:
         """One new frame for each of n <= 16 independent streams: rgb [n, d_rgb] / flow [n, d_flow] (None = zero flow) fp32 cuda
         contiguous, h [n, hid] fp32 cuda = the GRU state, UPDATED IN PLACE (zeros before a stream's first frame).
         Returns (probabilities or logits [n, C], argmax int32 [n]); pass `out` / `argmax` to reuse buffers.  bf16 / fp16 engines run
-        the three / four-launch fast path (prego_miniroad_step); fp32 engines the general forward with h0 / h_last."""
+        the three / four-launch fast path (prego_miniroad_step); fp32 / fp16x2 engines, hidden sizes other than 1024 and two-layer models
+        (h: [layers, n, hid]) the general forward with h0 / h_last."""
         d_rgb, d_flow, emb, hid, ncls = self.dims
         src = rgb if d_rgb > 0 else flow
         if src is None:
             raise PregoError("step: a --no_rgb model needs the flow frame" if d_rgb == 0 else "step: rgb is None")
         n = src.shape[0]
-        for t, d in ((rgb if d_rgb > 0 else None, d_rgb), (flow, d_flow), (h, hid)):
+        general = self.compute_dtype in ("fp32", "fp16x2") or hid != 1024 or self.num_layers != 1     # what the streaming kernels are not built for
+        for t, d in ((rgb if d_rgb > 0 else None, d_rgb), (flow, d_flow)):
             if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.shape != (n, d)):
                 raise PregoError(f"step: expected contiguous fp32 cuda [{n}, {d}], got {tuple(t.shape)} {t.dtype} on {t.device}")
+        h_shape = (n, hid) if self.num_layers == 1 else (self.num_layers, n, hid)
+        if not h.is_cuda or h.dtype != torch.float32 or not h.is_contiguous() or tuple(h.shape) != h_shape:
+            raise PregoError(f"step: expected the GRU state as contiguous fp32 cuda {list(h_shape)}, got {tuple(h.shape)} {h.dtype} on {h.device}")
         if out is None:
             out = torch.empty((n, ncls), dtype=torch.float32, device=self.device)
         if argmax is None:
             argmax = torch.empty((n,), dtype=torch.int32, device=self.device)
-        if self.compute_dtype in ("fp32", "fp16x2"):
+        if general:
             rl = [rgb[i:i + 1] for i in range(n)] if d_rgb > 0 else None
             fl = [flow[i:i + 1] for i in range(n)] if flow is not None else None
             o, a, hl = self.forward_ragged(rl, fl, softmax=softmax, want_out=True, want_argmax=True, h0=h, want_h_last=True)

@@ -32,8 +32,8 @@ class MROAD(nn.Module):
         self.out_dim = cfg["num_classes"]
         self.window_size = cfg["window_size"]
         self.embedding_dim = cfg["embedding_dim"]
-        if self.num_layers != 1:
-            raise PregoError("prego_amd MiniROAD supports num_layers == 1 (both shipped configs)")
+        if self.num_layers not in (1, 2):
+            raise PregoError(f"prego_amd MiniROAD runs nn.GRU with num_layers 1 or 2 (cfg['num_layers'] = {self.num_layers})")
         # parameter containers, reference construction order (rnn.py:38-47)
         self.gru = nn.GRU(self.embedding_dim, self.hidden_dim, self.num_layers, batch_first=True)
         self.layer1 = nn.Sequential(
@@ -72,7 +72,8 @@ class MROAD(nn.Module):
         key = (dev, self._engine_dtype(train))
         ent = self._engines.get(key)
         if ent is None:
-            ent = [MiniRoadEngine(self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim, self.out_dim, dev, key[1]), None]
+            ent = [MiniRoadEngine(self.d_rgb, self.d_flow, self.embedding_dim, self.hidden_dim, self.out_dim, dev, key[1],
+                                  num_layers=self.num_layers), None]
             self._engines[key] = ent
         vers = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if vers != ent[1]:

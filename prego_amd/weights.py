@@ -91,6 +91,11 @@ def miniroad_state_dict(cfg: dict, seed: int = 20, head_gain: float = 1.0) -> di
         "f_classification.0.weight": (head_gain * uniform((c, h), -bh, bh, seed, "f_classification.0.weight")).astype(np.float32),
         "f_classification.0.bias": uniform((c,), -bh, bh, seed, "f_classification.0.bias"),
     }
+    for l in range(1, int(cfg.get("num_layers", 1))):        # stacked GRU (rnn.py:32,38): layer l reads layer l - 1's h_t
+        sd[f"gru.weight_ih_l{l}"] = uniform((3 * h, h), -bh, bh, seed, f"gru.weight_ih_l{l}")
+        sd[f"gru.weight_hh_l{l}"] = uniform((3 * h, h), -bh, bh, seed, f"gru.weight_hh_l{l}")
+        sd[f"gru.bias_ih_l{l}"] = uniform((3 * h,), -bh, bh, seed, f"gru.bias_ih_l{l}")
+        sd[f"gru.bias_hh_l{l}"] = uniform((3 * h,), -bh, bh, seed, f"gru.bias_hh_l{l}")
     return sd
 
 

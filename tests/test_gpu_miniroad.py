@@ -461,3 +461,83 @@ def test_streaming_step_single_stream_models(which):
     m.engine().check()
     ref = O.miniroad_forward(sd, feat, None)["logits"]
     assert np.abs(torch.stack(got, 1).cpu().numpy() - ref).max() < 1e-2
+
+
+# ---- dimensions the shipped yamls do not use (rnn.py:31-38 takes any hidden_dim / num_layers) ---------------------------------------
+G10 = [("h512", 512, 1), ("h2048", 2048, 1), ("h1024_l2", 1024, 2), ("h512_l2", 512, 2)]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("tag,hid,layers", G10)
+def test_g10_other_hidden_sizes_and_two_gru_layers(tag, hid, layers, dtype):
+    """hidden_dim 512 / 2048 and nn.GRU(num_layers=2) against the reference's own outputs (fixture G10, two ragged clips with flow): the
+    probabilities, the argmax (every frame for fp32 operands) and h_n [layers, H]; then the same two clips streamed in two halves through
+    h_last -> h0 ([layers, n, H] for the stacked GRU), which must reproduce the one-shot result bit for bit"""
+    if dtype == "fp32" and hid == 2048:
+        from prego_amd._lib import PregoError
+        with pytest.raises(PregoError, match="hidden_dim 2048 unsupported"):
+            _model(assembly101_cfg(hidden_dim=hid, num_layers=layers), W.miniroad_state_dict(assembly101_cfg(hidden_dim=hid, num_layers=layers), 20), dtype).engine()
+        return
+    g = np.load(os.path.join(G, f"g10_miniroad_eval_{tag}.npz"))
+    cfg = assembly101_cfg(hidden_dim=hid, num_layers=layers)
+    sd = W.miniroad_state_dict(cfg, seed=20, head_gain=8.0)
+    m = _model(cfg, sd, dtype)
+    eng = m.engine()
+    lens = (96, 40)
+    rgb = [torch.from_numpy(W.tsn_features((1, T, 2048), 20, f"g10.{tag}.rgb.{i}")[0]).cuda() for i, T in enumerate(lens)]
+    flow = [torch.from_numpy(W.tsn_features((1, T, 2048), 20, f"g10.{tag}.flow.{i}")[0]).cuda() for i, T in enumerate(lens)]
+    outs, args, hl = eng.forward_ragged(rgb, flow, softmax=True, want_out=True, want_argmax=True, want_h_last=True)
+    eng.check()
+    assert tuple(hl.shape) == ((2, hid) if layers == 1 else (layers, 2, hid))
+    for i in range(2):
+        got = outs[i].cpu().numpy()
+        _check_probs(got, g[f"probs{i}"], dtype, f"g10 {tag} clip {i}")
+        assert np.array_equal(args[i].cpu().numpy(), got.argmax(1))
+        hn = (hl[i][None] if layers == 1 else hl[:, i]).cpu().numpy()
+        assert np.abs(hn - g[f"h_n{i}"]).max() < HL_TOL[dtype], (tag, i)
+    # streaming: first halves, then the rest from the returned state
+    cut = [48, 20]
+    o1, _, h1 = eng.forward_ragged([r[:c] for r, c in zip(rgb, cut)], [f[:c] for f, c in zip(flow, cut)], want_h_last=True)
+    o2, _, h2 = eng.forward_ragged([r[c:] for r, c in zip(rgb, cut)], [f[c:] for f, c in zip(flow, cut)], h0=h1, want_h_last=True)
+    eng.check()
+    for i in range(2):
+        assert torch.equal(torch.cat([o1[i], o2[i]]), outs[i]), (tag, dtype, i)
+    assert torch.equal(h2, hl)
+
+
+def test_other_dimensions_many_clips_and_rejections():
+    """hidden_dim 512 with 300 ragged clips (three clip tiles per group: the multi-tile launch of the classic kernel) and two GRU layers
+    with 150 clips against the numpy oracle on sampled clips; what the kernels are not built for is refused with a message: training,
+    the streaming step and fp16x2 at those dimensions"""
+    from prego_amd._lib import PregoError
+    rng = np.random.RandomState(3)
+    for hid, layers, n in ((512, 1, 300), (1024, 2, 150)):
+        cfg = assembly101_cfg(hidden_dim=hid, num_layers=layers)
+        sd = W.miniroad_state_dict(cfg, seed=20, head_gain=8.0)
+        m = _model(cfg, sd, "fp16")
+        lens = [int(x) for x in rng.randint(5, 60, size=n)]
+        feats = [W.tsn_features((T, 2048), 7, f"odim.{hid}.{layers}.{i}") for i, T in enumerate(lens)]
+        outs, args, _ = m.forward_clips([torch.from_numpy(f).cuda() for f in feats])
+        m.check()
+        for i in (0, n // 2, n - 1, int(np.argmax(lens))):
+            ref = O.miniroad_forward(sd, feats[i][None], None)["logits"][0]
+            _check_probs(outs[i].cpu().numpy(), ref, "fp16", f"hid {hid} layers {layers} clip {i}", exact=False)
+        with pytest.raises(PregoError, match="training"):
+            m.train()
+            m(torch.zeros(2, 8, 2048).cuda(), torch.zeros(2, 8, 2048).cuda())
+        m.eval()
+        # online stepping at these dimensions runs the general forward with h0 / h_last: three frames of clip 0 one by one = its first rows
+        hst = torch.zeros((1, hid) if layers == 1 else (layers, 1, hid), device="cuda")
+        for t in range(3):
+            pr, am = m.step(torch.from_numpy(feats[0][t:t + 1]).cuda(), None, hst)
+            assert torch.equal(pr[0], outs[0][t]) and int(am[0]) == int(args[0][t]), (hid, layers, t)
+        with pytest.raises(PregoError, match="built for hidden_dim 1024"):     # the C entry point itself says what it is built for
+            import ctypes as C
+            from prego_amd._lib import check
+            e = m.engine()
+            check(e.lib.prego_miniroad_step(e.h, 1, C.c_void_p(torch.zeros(1, 2048).cuda().data_ptr()), None,
+                                            C.c_void_p(torch.zeros(2, 1, 2048).cuda().data_ptr()), None, None, 1, None))
+    with pytest.raises(PregoError, match="fp16x2"):
+        _model(assembly101_cfg(num_layers=2), W.miniroad_state_dict(assembly101_cfg(num_layers=2), 20), "fp16x2").engine()
+    with pytest.raises(PregoError, match="hidden_dim 768"):
+        _model(assembly101_cfg(hidden_dim=768), W.miniroad_state_dict(assembly101_cfg(hidden_dim=768), 20), "fp16").engine()

@@ -109,6 +109,23 @@ def test_g4_loss_grads_adamw_small():
                 assert np.abs(sd[k] - g[f"param{step + 1}." + k]).max() < 2e-6, k
 
 
+@pytest.mark.parametrize("tag,hid,layers", [("h512", 512, 1), ("h2048", 2048, 1), ("h1024_l2", 1024, 2), ("h512_l2", 512, 2)])
+def test_g10_other_hidden_sizes_and_two_gru_layers(tag, hid, layers):
+    """rnn.py:31-38 takes any hidden_dim / num_layers: the oracle's stacked-GRU restatement against the reference at 512 / 2048 and 2 layers"""
+    g = _ld(f"g10_miniroad_eval_{tag}.npz")
+    cfg = assembly101_cfg(hidden_dim=hid, num_layers=layers)
+    sd = W.miniroad_state_dict(cfg, seed=20, head_gain=8.0)
+    for i, T in enumerate((96, 40)):
+        rgb = W.tsn_features((1, T, 2048), 20, f"g10.{tag}.rgb.{i}")
+        flow = W.tsn_features((1, T, 2048), 20, f"g10.{tag}.flow.{i}")
+        out = O.miniroad_forward(sd, rgb, flow, keep=True)
+        assert np.abs(out["logits"][0] - g[f"probs{i}"]).max() < 5e-6
+        hn = out["h_last"] if layers == 2 else out["h_last"][None]
+        assert np.abs(hn[:, 0] - g[f"h_n{i}"]).max() < 5e-6
+        ok = g[f"margin{i}"] > 1e-5
+        assert np.array_equal(out["logits"][0].argmax(1)[ok], g[f"argmax{i}"][ok])
+
+
 def test_g4s_oadloss_reduction_sum():
     """OadLoss(reduction='sum') of the reference (criterions/loss.py:30-33) beside 'mean': value and gradient"""
     g = _ld("g4s_oadloss_sum.npz")
