@@ -36,7 +36,13 @@ class Evaluate(nn.Module):
             raise RuntimeError(f"Unknown metrics: {self.metric}")
         self.cfg = cfg
         self.all_class_names = json.load(open(cfg["video_list_path"]))[cfg["data_name"].split("_")[0]]["class_index"]
+        # frames per forward.  The loop is pipelined one batch deep (eval: _flush / _collect): while batch k's features cross the link and
+        # its forward runs, the host waits for batch k - 1's ids and formats their JSON text.  Measured on the 182-video bench set
+        # (2.3 M frames, 16-bit features): ONE batch 226 ms, two batches of 1.2 M frames 238 ms - every forward pays its own fill and tail
+        # (~12 ms) and the text it hides is 6 ms -, so the default keeps an eval set of this size in one forward
         self.max_frames_per_batch = int(cfg.get("eval_frames_per_batch", 4_000_000))
+        if "eval_piece_frames" in cfg:
+            self.PIECE_FRAMES = int(cfg["eval_piece_frames"])
         self.output_dir = cfg.get("eval_output_dir", "output_miniRoad")
         self.last_fps = None
         self._copy_stream = None             # side stream for the H2D feature copies (double buffering against the compute stream)
@@ -73,7 +79,7 @@ class Evaluate(nn.Module):
         return x.contiguous() if (keep is not None and x.dtype == keep) else x.float().contiguous()
 
     @staticmethod
-    def _json_int_lists(output) -> bytes:
+    def _json_int_lists(output, as_parts: bool = False):
         """the reference's output file ({vid: {"pred": [...], "gt": [...]}}, eval.py:59-65) written from the int arrays directly:
         class ids through a table of pre-formatted byte strings (json.dump walks 2 x frames Python ints one at a time: 0.25 s for
         0.8 M frames, five times the forward pass).  Same JSON value; numbers are padded with blanks, which JSON allows."""
@@ -90,7 +96,7 @@ class Evaluate(nn.Module):
             body = lut4[a].tobytes() if hi < 100 else np.take(lut5, a, axis=0).tobytes()
             return b"[" + body[:-1] + b"]"
         parts = [json.dumps(str(vid)).encode() + b': {"pred": ' + arr(v["pred"]) + b', "gt": ' + arr(v["gt"]) + b"}" for vid, v in output.items()]
-        return b"{" + b", ".join(parts) + b"}"
+        return parts if as_parts else b"{" + b", ".join(parts) + b"}"
 
     def _enqueue(self, model, sub, device):
         """H2D of one sub-batch on the copy stream + its forward on the compute stream; nothing here waits for the GPU"""
@@ -120,8 +126,25 @@ class Evaluate(nn.Module):
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
         return probs, args, tgt
 
-    PIECE_FRAMES = 2048          # link-fed eval: frames per H2D piece (8 MB of fp16 rgb); one feed event per ~EVENT_BYTES copied
+    # link-fed eval: frames per H2D piece; one feed event per ~EVENT_BYTES copied.  A copy costs ~10 us of fixed time whatever its size, so
+    # large pieces keep the link busier (182-video set, 16-bit features: 2 048 frames 226 ms to the last id, 4 096: 220, 8 192: 215.5) -
+    # but the recurrence cannot pass a piece's first step before the piece has landed, so whatever a slot's LAST piece covers is run after
+    # the link has gone idle: the tail of every video goes in TAIL_PIECE_FRAMES pieces
+    PIECE_FRAMES = 8192
+    TAIL_PIECE_FRAMES = 2048
     EVENT_BYTES = 64 << 20
+
+    def _pieces_of(self, T):
+        """frame ranges [a, b) one video's features are copied in"""
+        P, Q = self.PIECE_FRAMES, min(self.TAIL_PIECE_FRAMES, self.PIECE_FRAMES)
+        out, a = [], 0
+        while T - a > P + Q:
+            out.append((a, a + P))
+            a += P
+        while a < T:
+            out.append((a, min(a + Q, T)))
+            a += Q
+        return out
 
     def _enqueue_link_fed(self, model, batch, device):
         """ONE forward over the whole batch while its features are still arriving (MROAD.link_fed_eval; pinned host features).
@@ -140,15 +163,14 @@ class Evaluate(nn.Module):
         any_flow = any(b[1] is not None for b in batch)
         row_bytes = sum(int(t.shape[1]) * t.element_size() for t in (batch[0][0],) + ((next(b[1] for b in batch if b[1] is not None),) if any_flow else ()))
         start, n_steps = eng.plan_starts(lens, row_bytes)
-        rgb = [torch.empty(b[0].shape, dtype=b[0].dtype, device=dev) for b in batch]
-        flow = [None if b[1] is None else torch.empty(b[1].shape, dtype=b[1].dtype, device=dev) for b in batch] if any_flow else None
-        P = self.PIECE_FRAMES
-        pieces = sorted((start[i] + a, i, a) for i, T in enumerate(lens) for a in range(0, T, P))
+        pieces = sorted((start[i] + a, i, a, b_) for i, T in enumerate(lens) for a, b_ in self._pieces_of(T))
         upto, events, acc = [], [], 0
-        self._copy_stream.wait_stream(cur)                 # the destination tensors exist in stream order of `cur`
         with torch.cuda.stream(self._copy_stream):
-            for k, (need, i, a) in enumerate(pieces):
-                b = min(a + P, lens[i])
+            # the destination tensors belong to the COPY stream (allocated inside its context): the copies of this batch follow the
+            # previous batch's copies at once - they do not wait for the compute stream, which is still running the previous forward
+            rgb = [torch.empty(b[0].shape, dtype=b[0].dtype, device=dev) for b in batch]
+            flow = [None if b[1] is None else torch.empty(b[1].shape, dtype=b[1].dtype, device=dev) for b in batch] if any_flow else None
+            for k, (need, i, a, b) in enumerate(pieces):
                 rgb[i][a:b].copy_(batch[i][0][a:b], non_blocking=True)
                 acc += (b - a) * int(rgb[i].shape[1]) * rgb[i].element_size()
                 if flow is not None and flow[i] is not None:
@@ -164,9 +186,7 @@ class Evaluate(nn.Module):
             tgt = [b[2].to(dev, non_blocking=True) for b in batch]                   # only needed behind the forward
             ready = torch.cuda.Event()
             ready.record(self._copy_stream)
-        for t in rgb + [f for f in (flow or []) if f is not None]:
-            t.record_stream(self._copy_stream)                 # allocated on `cur`, written on the copy stream
-        for t in tgt:
+        for t in rgb + [f for f in (flow or []) if f is not None] + tgt:
             t.record_stream(cur)                               # allocated on the copy stream (inside its context), read on `cur`
         self._feed_events = events                           # keep the hipEvent_t objects alive until the stream has used them
         eng.set_feed_events(upto, events, row_bytes)
@@ -178,9 +198,10 @@ class Evaluate(nn.Module):
         cur.wait_event(ready)
         return probs, args, tgt
 
-    def _flush(self, model, batch, pred_scores, gt_targets, output, device):
+    def _flush(self, model, batch, device):
+        """enqueue one batch (H2D + forward + argmax ids D2H): nothing here waits for the GPU.  Returns the record _collect finishes."""
         if not batch:
-            return
+            return None
         # Pinned host features + a model that can be fed while it runs: ONE link-fed forward (_enqueue_link_fed).  Otherwise a batch
         # runs as long as its longest video's recurrence and its H2D copy would sit in front of that, so large batches go in two
         # sub-batches ordered by length: the few longest videos first (little to copy, the long critical path), then the bulk of
@@ -217,28 +238,50 @@ class Evaluate(nn.Module):
                     res[i] = (p, a, t)
         want_json = self.cfg["eval"] is not None
         # np.argmax of the one-hot targets (eval.py:55) on the device, where they are anyway for the AP kernel (on the host it reads
-        # frames x classes floats through one core: 25 ms for the bench set); then ONE device -> host copy of the whole batch's
-        # pred and gt ids, after everything has been enqueued (the first wait for the GPU)
-        ids_host = None
+        # frames x classes floats through one core: 25 ms for the bench set); ONE device -> host copy of the whole batch's pred and gt
+        # ids is ENQUEUED here (into pinned memory, behind the forward) and waited for in _collect - one batch later, so that the next
+        # batch's copies and forward are already running while the host waits for these ids and formats their text
+        rec = {"items": [(vid, res[i]) for i, (r, f, target, vid) in enumerate(batch)], "ids": None, "ev": None, "link_fed": link_fed,
+               "src": list(batch), "feed": getattr(self, "_feed_events", None)}       # the loader's tensors / the feed events stay alive until _collect
         if want_json:
             pred_ids = torch.cat([res[i][1] for i in range(len(batch))])
             gt_ids = torch.cat([torch.argmax(res[i][2], dim=1) for i in range(len(batch))]).to(pred_ids.dtype)
-            ids_host = torch.stack([pred_ids, gt_ids]).cpu().numpy()
-        elif link_fed:
+            ids_dev = torch.stack([pred_ids, gt_ids])
+            if ids_dev.is_cuda:
+                ids_host = torch.empty(ids_dev.shape, dtype=ids_dev.dtype, pin_memory=True)
+                ids_host.copy_(ids_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                rec["ids"], rec["ev"], rec["_keep"] = ids_host, ev, ids_dev
+            else:                                  # a stand-in model on a CPU box (the gloo tests of the sharding logic)
+                rec["ids"] = ids_dev
+        batch.clear()
+        return rec
+
+    def _collect(self, rec, pred_scores, gt_targets, output, json_parts):
+        """the host half of a batch, one batch behind its launch: wait for its ids, cut them per video, format the videos' JSON text"""
+        if rec is None:
+            return
+        ids = None
+        if rec["ids"] is not None:
+            if rec["ev"] is not None:
+                rec["ev"].synchronize()
+            ids = rec["ids"].numpy()
+        elif rec["link_fed"]:
             self._copy_stream.synchronize()      # the copies read the loader's pinned tensors: keep them alive until then
         o = 0
-        for i, (r, f, target, vid) in enumerate(batch):
-            p, a, t = res[i]
+        for vid, (p, a, t) in rec["items"]:
             # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
             # once at the end); the reference extends Python lists by one row object per frame (eval.py:46-49)
             pred_scores.append(p)
             gt_targets.append(t)
-            if want_json:
+            if ids is not None:
                 n = int(a.shape[0])
-                output[vid] = {"pred": ids_host[0, o:o + n], "gt": ids_host[1, o:o + n]}      # int arrays; text only at the end
+                output[vid] = {"pred": ids[0, o:o + n], "gt": ids[1, o:o + n]}      # int arrays; text below
+                if json_parts is not None:
+                    json_parts += self._json_int_lists({vid: output[vid]}, as_parts=True)
                 o += n
                 self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
-        batch.clear()
 
     def eval(self, model, dataloader, logger, device):
         model.eval()
@@ -254,7 +297,12 @@ class Evaluate(nn.Module):
             pred_scores, gt_targets = [], []
             per_video = []                       # (loader position, n_frames) to restore the loader's order on rank 0
             t_begin = time.time()
+            t0_ = time.perf_counter()
+            self.phase_log = []                  # (phase, host seconds since the start of this eval): where an end-to-end eval spends its time
+            mark = lambda name: self.phase_log.append((name, time.perf_counter() - t0_))
             batch, frames, pos = [], 0, 0
+            pending = None                       # the batch whose launch is out and whose host half (_collect) is still due
+            json_parts = [] if (self.cfg["eval"] is not None and world == 1) else None      # per-video JSON text, formatted batch by batch
             for rgb_input, flow_input, target, vid, start, end in dataloader:
                 # loader items carry a leading batch dim of test_batch_size == 1 (dataset_builder.py:19)
                 for b in range(rgb_input.shape[0]):
@@ -268,10 +316,22 @@ class Evaluate(nn.Module):
                     per_video.append((pos - 1, int(rgb_input.shape[1])))
                     frames += rgb_input.shape[1]
                 if len(batch) >= max_clips or frames >= self.max_frames_per_batch:
-                    self._flush(model, batch, pred_scores, gt_targets, output, device)
+                    mark("loader")
+                    rec = self._flush(model, batch, device)                 # batch k: enqueued ...
+                    mark("launch")
+                    self._collect(pending, pred_scores, gt_targets, output, json_parts)      # ... while the host finishes batch k - 1
+                    mark("collect")
+                    pending = rec
                     frames = 0
-            self._flush(model, batch, pred_scores, gt_targets, output, device)
+            mark("loader")
+            rec = self._flush(model, batch, device)
+            mark("launch")
+            self._collect(pending, pred_scores, gt_targets, output, json_parts)
+            mark("collect")
+            self._collect(rec, pred_scores, gt_targets, output, json_parts)
+            mark("collect_last")
             model.check()
+            mark("check")
             if world > 1:
                 # the small things go to rank 0 as objects: per-video frame counts and the pred / gt id arrays of the output file
                 # (8 bytes per frame).  The [frames x classes] score and target matrices do NOT travel whole (round 3 pickled 0.8 GB of
@@ -308,12 +368,15 @@ class Evaluate(nn.Module):
                 # and go back to its GPU first
                 finish_ap = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
                                                               self.data_processing, self.metric, defer=True)
+            mark("ap_enqueued")
             if self.cfg["eval"] is not None:
                 os.makedirs(self.output_dir, exist_ok=True)
                 with open(os.path.join(self.output_dir, "output_miniROAD.json"), "wb") as file:
-                    file.write(self._json_int_lists(output))
+                    file.write(b"{" + b", ".join(json_parts) + b"}" if json_parts is not None else self._json_int_lists(output))
+            mark("json_written")
             if finish_ap is not None:
                 result = finish_ap()
+                mark("ap_done")
             else:       # a stand-in model on a CPU box (the gloo tests of the sharding logic), or metric 'cAP' (TVSeries' calibrated variant: host path only)
                 result = perframe_average_precision(pred_all.cpu().numpy(), gt_all.cpu().numpy(), self.all_class_names, self.data_processing, self.metric)
             t_end = time.time()

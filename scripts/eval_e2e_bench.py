@@ -18,6 +18,10 @@ json.dump({"ASSEMBLY101-O": {"class_index": [f"c{i}" for i in range(86)]}}, open
 extra = {}
 if os.environ.get("E2E_SPLIT"):
     extra["eval_split_fraction"] = float(os.environ["E2E_SPLIT"])
+if os.environ.get("E2E_FRAMES_PER_BATCH"):
+    extra["eval_frames_per_batch"] = int(os.environ["E2E_FRAMES_PER_BATCH"])
+if os.environ.get("E2E_PIECE"):
+    extra["eval_piece_frames"] = int(os.environ["E2E_PIECE"])
 half = os.environ.get("E2E_FEATURE_DTYPE") == "fp16"       # the feeder's 16-bit features (cfg['feature_dtype'], prego_amd/data.py)
 cfg = assembly101_cfg(eval="ckpt.pth", video_list_path=vl, eval_output_dir=os.path.join(tmp, "out"), assume_zero_flow=True, **extra)
 sd = W.miniroad_state_dict(cfg, 20, head_gain=8.0)
@@ -32,9 +36,12 @@ for i, T in enumerate(lens):
 frames = sum(lens)
 ev = build_eval(cfg)
 log = logging.getLogger("e2e")
-for rep in range(2):
+for rep in range(int(os.environ.get("E2E_REPS", "2"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     mAP = ev(model, items, log, "cuda:0")
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"Evaluate end to end: {n_clips} videos, {frames} frames: {dt:.2f} s = {frames/dt/1e6:.2f} M frames/s (H2D of pinned features + forward + "
           f"argmax + JSON + device mAP), mAP {mAP:.4f}")
+    if os.environ.get("E2E_PHASES"):
+        prev = 0.0
+        print("   phases (ms since start / delta): " + "  ".join(f"{n} {t*1e3:.1f}/{(t-prev)*1e3:.1f}" for (n, t), prev in zip(ev.phase_log, [0.0] + [t for _, t in ev.phase_log[:-1]])))
