@@ -1033,6 +1033,11 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_mt_kernel(GruArgs a) {
     }
 }
 
+// (Round 5, measured and removed: a BATCHED two-tile step - both tiles of a pair through each phase together: 16 fragment loads in
+// flight, 96 MFMAs behind one wait chain, one LDS reduction + barrier, the two gate chains interleaved in one basic block; bit-identical
+// to this file's kernels.  7.62 us per four-tile step against the pipelined kernel's 7.25 on the same device (synth512: 27.7 vs 28.3 M
+// frames/s): what a tile costs is moving its 32 KB through the CU's vector-memory path in the wave's own time (~850 cycles) and the serial
+// reduce / gate / store phases, not the L2 round trip the batching amortises - and 411-469 registers put the fragments in AGPRs.)
 // Returns 0 on success, -1 for unsupported (hid, nct).
 // a.hx must hold [2][G][GROUP_BYTES] bytes (gru_hx_bytes); both buffers are re-armed here (stream ordered):
 // buffer 0 := tag 1 everywhere (first expected tag there is 0), buffer 1 := tag 0 (first expected tag is 1).
