@@ -16,5 +16,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 tail -3 $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/scripts/split_replay.py "$@" > $OUT/pmc_write.log 2>&1
 tail -3 $OUT/pmc_write.log
+# (d) the matrix pipe: cycles the MFMA unit was busy, MFMA operations issued (x 512 = flops), chip-active cycles; (e) LDS activity
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- python3 $GRAFT_REPO_ROOT/scripts/split_replay.py "$@" > $OUT/pmc_mfma.log 2>&1
+tail -3 $OUT/pmc_mfma.log
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_lds -- python3 $GRAFT_REPO_ROOT/scripts/split_replay.py "$@" > $OUT/pmc_lds.log 2>&1
+tail -3 $OUT/pmc_lds.log
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 find $OUT -name "*.csv" | head -20

@@ -89,3 +89,47 @@ json.dump(t, open(tp, "w"))
 for r in rows:
     if r["algorithmic_bytes_per_launch"] != "":
         print(r)
+
+
+# ---- matrix-pipe and LDS counters of the same replay (collect_split_pmc.sh passes d, e): one row per kernel and counter, per launch
+def pmc_all(name):
+    out = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in newest(glob.glob(os.path.join(src, name, "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            c = out[k][r["Counter_Name"]]
+            c[0] += 1
+            c[1] += float(r["Counter_Value"])
+    return out
+
+
+extra = []
+SIMDS = 256 * 4                 # SIMD_NUM of an MI355X (256 CUs x 4): what rocprofv3's MfmaUtil expression divides by
+for name in ("pmc_mfma", "pmc_lds"):
+    for k, cs in pmc_all(name).items():
+        if not ("ff_pass_kernel" in k or is_pass(k)):
+            continue
+        per = {c: v[1] / v[0] for c, v in cs.items() if v[0]}
+        row = {"kernel": k, "pass": name, **{c: round(v, 1) for c, v in per.items()}}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in per and per.get("GRBM_GUI_ACTIVE"):
+            xcds = 5 if "ff_pass_kernel" in k else 3
+            util = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] * SIMDS) * 100.0
+            row["MfmaUtil_pct_of_chip"] = round(util, 2)
+            row["MfmaUtil_pct_of_its_xcds"] = round(util * 8.0 / xcds, 2)
+            mops = per.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + per.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
+            row["mfma_flop_per_launch"] = mops * 512.0
+            t[("ff_pass" if "ff_pass_kernel" in k else "gru_pass") + "_mfma_util_pct_of_its_xcds"] = row["MfmaUtil_pct_of_its_xcds"]
+        if "SQ_LDS_BANK_CONFLICT" in per and per.get("SQ_LDS_IDX_ACTIVE"):
+            row["lds_bank_conflict_frac_of_active"] = round(per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"], 4)
+        extra.append(row)
+if extra:
+    keys = []
+    for r in extra:
+        for k in r:
+            if k not in keys:
+                keys.append(k)
+    with open(os.path.join(dst, f"{tag}_split_pmc_mfma_lds.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=keys); w.writeheader(); w.writerows(extra)
+    json.dump(t, open(tp, "w"))
+    for r in extra:
+        print(r)
