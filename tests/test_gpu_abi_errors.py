@@ -32,7 +32,9 @@ def _weights(din, emb, hid, ncls):
 def test_create_rejects_unsupported_dimensions():
     lib = _lib.load()
     h = C.c_void_p()
-    for args in [(2048, 2048, 2048, 512, 86, 1),      # hidden_dim != 1024: the register-resident recurrence is built for 1024
+    for args in [(2048, 2048, 2048, 768, 86, 1),      # hidden_dim outside {512, 1024, 2048}: the recurrence keeps its W_hh slice in registers
+                 (2048, 2048, 2048, 2048, 86, 0),     # ... 2048 with exact-fp32 operands: a 16-row slice is 384 registers per lane
+                 (2048, 2048, 2048, 512, 86, 3),      # ... fp16x2 operands: 1024 only
                  (2048, 2048, 1000, 1024, 86, 1),     # embedding_dim not a multiple of 512
                  (2000, 2048, 2048, 1024, 86, 1),     # feature size not a multiple of 64
                  (0, 0, 2048, 1024, 86, 1),           # --no_rgb and --no_flow together: no input at all
@@ -42,6 +44,12 @@ def test_create_rejects_unsupported_dimensions():
         assert rc == EINVAL, args
         lib.prego_last_error.restype = C.c_char_p
         assert lib.prego_last_error()      # a text exists for the handle-free failure
+    for layers, dtype in ((0, 1), (3, 1), (2, 3)):         # num_layers outside {1, 2}; two layers with fp16x2 operands
+        assert lib.prego_miniroad_create_layers(C.byref(h), 2048, 2048, 2048, 1024, 86, layers, dtype) == EINVAL, (layers, dtype)
+    # what round 5 added IS accepted: hidden_dim 512 / 2048 with 16-bit operands, 512 with fp32, two layers
+    for args in [(2048, 2048, 2048, 512, 86, 1, 2), (2048, 2048, 2048, 2048, 86, 1, 1), (2048, 2048, 2048, 512, 86, 1, 0), (2048, 2048, 2048, 1024, 86, 2, 2)]:
+        assert lib.prego_miniroad_create_layers(C.byref(h), *args) == 0, args
+        lib.prego_miniroad_destroy(h)
 
 
 def test_forward_misuse_returns_codes_and_handle_survives():
