@@ -486,6 +486,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         if (more && tfirst[ct] < na_n) load_gi(gin[ct], ct, na_n, rb_n - a.row_base);
 
         // ---- (2) cross-wave (K-quarter) reduction through LDS, double buffered: one barrier per tile
+        // (round 5: rocprofv3 counts SQ_LDS_BANK_CONFLICT = 1/3 of this kernel's active LDS cycles - the gate phase reads 8 bytes per lane
+        // at a 16-byte stride.  Writing every accumulator as two 8-byte planes makes those reads conflict-free and was measured SLOWER:
+        // 2.014 against 1.984 us per step in the split pass, equal in the chunked pass, same device, scripts/probes/ab_lib.sh - twelve
+        // ds_write_b64 instead of six b128 in front of the barrier cost more than the conflicts behind it)
         f32x4* redw = red + parity * RED_STRIDE;
         parity ^= 1;
 #pragma unroll

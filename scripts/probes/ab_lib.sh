@@ -1,6 +1,11 @@
-# A/B two builds on the same device: default library vs prego_amd/lib/alt/libprego_old.so (recurrence stamps, 128 clips)
-for r in 1 2; do
-for v in old default; do
-  if [ $v = default ]; then unset PREGO_AMD_LIB; else export PREGO_AMD_LIB=$PWD/prego_amd/lib/alt/libprego_$v.so; fi
-  echo "== $v"; python scripts/gru_stamps.py 128 bf16 2>&1 | tail -1
-done; done
+#!/bin/bash
+# Runs ON THE GPU BOX: same-device A/B of two builds of the library on the bench workload, alternating: the tree's library against
+# $1 (a .so built from another version of one source, PREGO_AMD_LIB).  usage: bash scripts/probes/ab_lib.sh prego_amd/lib_ab/libX.so [bench args]
+ALT=$GRAFT_REPO_ROOT/$1; shift
+cd $GRAFT_REPO_ROOT
+for r in 1 2 3; do
+  for L in new old; do
+    if [ $L = old ]; then export PREGO_AMD_LIB=$ALT; else unset PREGO_AMD_LIB; fi
+    echo "$L $(python3 bench.py --no-cpu-baseline --no-secondary --no-zero-flow --steps 10 "$@" 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(round(d['ms_per_step'],2),'ms', d['pass'], 'rec us/step', round(d['rooflines']['gru_recurrence']['us_per_timestep'],4))")"
+  done
+done

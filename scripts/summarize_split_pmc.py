@@ -113,7 +113,10 @@ for name in ("pmc_mfma", "pmc_lds"):
         row = {"kernel": k, "pass": name, **{c: round(v, 1) for c, v in per.items()}}
         if "SQ_VALU_MFMA_BUSY_CYCLES" in per and per.get("GRBM_GUI_ACTIVE"):
             xcds = 5 if "ff_pass_kernel" in k else 3
-            util = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] * SIMDS) * 100.0
+            # the CSV holds ONE value per dispatch and counter, summed over the counter's instances: GRBM_GUI_ACTIVE over the 8 XCDs (a
+            # 92.2 ms launch reads 1.70e9 = 8 x 2.30 GHz x 92.2 ms), the SQ counters over all SIMDs.  rocprofv3's MfmaUtil expression is
+            # busy cycles / (max-over-instances active cycles x SIMD_NUM): the per-XCD active cycles are the sum / 8
+            util = per["SQ_VALU_MFMA_BUSY_CYCLES"] / (per["GRBM_GUI_ACTIVE"] / 8.0 * SIMDS) * 100.0
             row["MfmaUtil_pct_of_chip"] = round(util, 2)
             row["MfmaUtil_pct_of_its_xcds"] = round(util * 8.0 / xcds, 2)
             mops = per.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) + per.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
