@@ -344,7 +344,12 @@ int prego_attention_layer_handle_forward(prego_attn_layer* h, int batch, int len
  * keeps x, q, k, v, the attention output (bf16) and the row log-sum-exp in `workspace`; backward reads them from the SAME
  * workspace and overwrites grads[0..7] (fp32, set_weights order: wq, bq, wk, bk, wv, bv, wo, bo) and, if not NULL,
  * dx [batch, len, d_model] (queries = keys = values = x: the three input gradients summed).  bf16 handles only; the
- * attention_dropout of attn.py:39,49 is not modelled (p = 0, the state the reference's modules are in under .eval()). */
+ * attention_dropout of attn.py:39,54 (nn.Dropout on A = softmax(scale * scores), active under module.train()): prego_attention_layer_set_dropout
+ * below, p = 0 by default (the state the reference's modules are in under .eval()). */
+/* FullAttention(attention_dropout = p) in training mode: every forward_train / backward pair that follows drops each attention probability
+ * with probability p and scales the survivors by 1 / (1 - p) (the softmax denominator sums the undropped row), by a stateless hash of
+ * (seed, element) - pass a fresh seed per step; the backward regenerates the mask of its forward.  0 <= p < 1. */
+int prego_attention_layer_set_dropout(prego_attn_layer* h, float p, uint64_t seed);
 size_t prego_attention_layer_train_workspace_bytes(const prego_attn_layer* h, int batch, int len);
 int prego_attention_layer_forward_train(prego_attn_layer* h, int batch, int len, int causal, const float* x, float* out,
                                         void* workspace, size_t workspace_bytes, prego_stream_t stream);

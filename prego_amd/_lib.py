@@ -32,7 +32,7 @@ SYMBOLS = [
     "prego_attention_layer_workspace_bytes", "prego_attention_layer_forward",
     "prego_attention_layer_create", "prego_attention_layer_destroy", "prego_attention_layer_set_weights",
     "prego_attention_layer_handle_workspace_bytes", "prego_attention_layer_handle_forward",
-    "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_vit_adamw_step", "prego_miniroad_step",
+    "prego_attention_layer_set_dropout", "prego_attention_layer_train_workspace_bytes", "prego_attention_layer_forward_train", "prego_attention_layer_backward", "prego_vit_adamw_step", "prego_miniroad_step",
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events", "prego_miniroad_backward_callback",
     "prego_miniroad_plan_starts", "prego_miniroad_set_feed_events", "prego_miniroad_pass_info",
     "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
@@ -130,6 +130,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_attention_layer_handle_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_handle_workspace_bytes.restype = sz
     lib.prego_attention_layer_handle_forward.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]
+    lib.prego_attention_layer_set_dropout.argtypes = [vp, C.c_float, C.c_uint64]
     lib.prego_attention_layer_train_workspace_bytes.argtypes = [vp, i32, i32]
     lib.prego_attention_layer_train_workspace_bytes.restype = sz
     lib.prego_attention_layer_forward_train.argtypes = [vp, i32, i32, i32, vp, vp, vp, sz, vp]

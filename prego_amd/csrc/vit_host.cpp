@@ -629,7 +629,7 @@ extern "C" int prego_debug_attention_fwd(int batch, int n_query, int len, int he
 // wob bf16 [D][D]; act = 5 activation buffers of M*D bf16 (x, q, k, v, attention output)
 static int attention_layer_run(int batch, int len, int d_model, int heads, int causal, const float* x, const void* wqkv,
                                const float* bqkv, const void* wob, const float* bo, float* out, char* act, hipStream_t s, bool f16 = false,
-                               float* lse = nullptr) {
+                               float* lse = nullptr, unsigned drop_thresh = 0, float drop_scale = 1.f, unsigned long long drop_seed = 0) {
   const size_t M = (size_t)batch * len, D = d_model, step = align_up(M * D * 2, 256);
   const int dh = d_model / heads;
   char* xb = act; char* q = act + step; char* k = act + 2 * step; char* vn = act + 3 * step; char* ao = act + 4 * step;
@@ -638,7 +638,7 @@ static int attention_layer_run(int batch, int len, int d_model, int heads, int c
   e.mode = EPI_QKV; e.q = q; e.k = k; e.vn = vn; e.n_tok = len; e.heads = heads; e.dh = dh; e.emb = d_model;
   e.q_scale = 1.0f / sqrtf((float)dh);                                   // attn.py:44 scale = 1/sqrt(E)
   launch_gemm_bf16_nt_epi(xb, d_model, wqkv, d_model, bqkv, nullptr, 0, (int)M, 3 * d_model, d_model, e, s);
-  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s, lse, 0, 1.f, 0, f16)) return -1;
+  if (launch_flash_attention_v2(q, k, vn, ao, batch, len, len, heads, dh, causal ? 1 : 0, s, lse, drop_thresh, drop_scale, drop_seed, f16)) return -1;
   launch_gemm_bf16_nt(ao, d_model, wob, d_model, bo, out, d_model, (int)M, d_model, d_model, s, f16);
   return 0;
 }
@@ -657,7 +657,19 @@ struct prego_attn_layer {
   bool f16 = false;                // IEEE fp16 operands instead of bf16 (prego_attention_layer_set_compute_dtype)
   bool f32 = false;                // fp32 operands (parity mode): wqkv32 [3D][D], wo32 [D][D]
   float* wqkv32 = nullptr; float* wo32 = nullptr;
+  // FullAttention's nn.Dropout(attention_dropout) on A = softmax(scale * scores) (attn.py:39,54), training entry points only: a stateless hash
+  // mask of (seed, element of A), the same in forward_train and backward (prego_attention_layer_set_dropout)
+  float attn_drop_p = 0.f; unsigned long long drop_seed = 0;
 };
+extern "C" int prego_attention_layer_set_dropout(prego_attn_layer* h, float p, uint64_t seed) {
+  if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
+  if (!(p >= 0.f && p < 1.f)) return prego_fail_(PREGO_EINVAL, "attention_dropout p = %f", (double)p);
+  h->attn_drop_p = p;
+  h->drop_seed = seed;
+  return PREGO_OK;
+}
+static inline unsigned al_thr(const prego_attn_layer* h) { return h->attn_drop_p > 0.f ? (unsigned)((double)h->attn_drop_p * 4294967296.0) : 0u; }
+static inline float al_scale(const prego_attn_layer* h) { return h->attn_drop_p > 0.f ? 1.f / (1.f - h->attn_drop_p) : 1.f; }
 extern "C" int prego_attention_layer_set_compute_dtype(prego_attn_layer* h, int compute_dtype) {
   if (!h) return prego_fail_(PREGO_EINVAL, "handle is NULL");
   if (compute_dtype != PREGO_BF16 && compute_dtype != PREGO_F16 && compute_dtype != PREGO_F32)
@@ -750,8 +762,8 @@ extern "C" int prego_attention_layer_handle_forward(prego_attn_layer* h, int bat
 }
 
 // ---- training: forward that keeps q, k, v, the attention output and the row log-sum-exp, and the backward over them --------
-// (attn.py:139-170 under autograd: the projections are nn.Linear, the attention FullAttention.forward attn.py:35-57 in eval
-// dropout state - attention_dropout acts on A only under module.train(), a state this op does not model: p = 0)
+// (attn.py:139-170 under autograd: the projections are nn.Linear, the attention FullAttention.forward attn.py:35-57; attention_dropout
+// (attn.py:39,54: nn.Dropout on A, active under module.train()) is the handle's prego_attention_layer_set_dropout state, p = 0 by default)
 struct AttnTrainWs { size_t act, lse, dyb, dO, dqkv, delta, T1, T2, WT, part, dW, vec, total; int Mp; };
 static AttnTrainWs attn_train_ws(int d_model, int heads, int batch, int len) {
   const size_t M = (size_t)batch * len, D = d_model;
@@ -779,7 +791,7 @@ extern "C" int prego_attention_layer_forward_train(prego_attn_layer* h, int batc
   if (workspace_bytes < w.total) return prego_fail_(PREGO_EWORKSPACE, "training workspace %zu < %zu", workspace_bytes, w.total);
   char* ws = (char*)workspace;
   if (attention_layer_run(batch, len, h->d_model, h->heads, causal, x, h->wqkv, h->bqkv, h->wo, h->bo, out, ws + w.act,
-                          (hipStream_t)stream, false, (float*)(ws + w.lse)))
+                          (hipStream_t)stream, false, (float*)(ws + w.lse), al_thr(h), al_scale(h), h->drop_seed))
     return prego_fail_(PREGO_EINVAL, "attention launch failed");
   HIPCHK(hipGetLastError());
   return PREGO_OK;
@@ -808,7 +820,7 @@ extern "C" int prego_attention_layer_backward(prego_attn_layer* h, int batch, in
       dgrad(ws + w.dyb, D, h->wo, D, M, nullptr, s, ws + w.dO)) return prego_fail_(PREGO_EINVAL, "backward: out_projection GEMM shape");
   // ---- softmax(scale * Q K^T + mask) V (attn.py:41-52)
   if (launch_attention_bwd(q, k, vn, ao, ws + w.dO, (const float*)(ws + w.lse), (float*)(ws + w.delta), ws + w.dqkv, batch, len,
-                           h->heads, dh, causal ? 1 : 0, 1.0f / sqrtf((float)dh), s))
+                           h->heads, dh, causal ? 1 : 0, 1.0f / sqrtf((float)dh), s, al_thr(h), al_scale(h), h->drop_seed))
     return prego_fail_(PREGO_EINVAL, "attention backward launch failed");
   // ---- query / key / value projections (attn.py:160-162): rows of dqkv are [dq | dk | dv]
   if (wgrad(ws + w.dqkv, 3 * D, xb, D, M, Mp, dW, vec, s)) return prego_fail_(PREGO_EINVAL, "backward: qkv GEMM shape");

@@ -289,6 +289,11 @@ class _AttnLayerTrainFn(torch.autograd.Function):
     def forward(ctx, layer, x_in, *params):
         lib, dev = layer.lib, layer.device
         h = layer._train_handle(params)
+        # FullAttention's nn.Dropout(attention_dropout) on A (attn.py:39,54): active in training mode; the mask seed comes from torch's RNG
+        # (one draw per forward, like nn.Dropout consumes the generator), the backward of THIS forward regenerates the same mask
+        p_drop = layer.attention_dropout if layer.training else 0.0
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+        check(lib.prego_attention_layer_set_dropout(h, float(p_drop), seed))
         B, L, D = x_in.shape
         x = x_in.detach().float().contiguous()
         need = lib.prego_attention_layer_train_workspace_bytes(h, B, L)
@@ -300,6 +305,7 @@ class _AttnLayerTrainFn(torch.autograd.Function):
                                                           C.c_void_p(layer._ws_train.data_ptr()), layer._ws_train.numel(), C.c_void_p(_stream_ptr(dev))))
         layer._train_gen += 1      # q, k, v, the attention output and the row log-sum-exp stay in the layer's ONE training workspace
         ctx.layer, ctx.dims, ctx.gen, ctx.need_dx = layer, (B, L, D), layer._train_gen, bool(x_in.requires_grad)
+        ctx.drop = (float(p_drop), seed)
         ctx.shapes = [tuple(p.shape) for p in params]
         return out
 
@@ -314,6 +320,7 @@ class _AttnLayerTrainFn(torch.autograd.Function):
         grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
         dx = torch.empty((B, L, D), dtype=torch.float32, device=dev) if ctx.need_dx else None
         with torch.cuda.device(dev):
+            check(lib.prego_attention_layer_set_dropout(layer._ht, *ctx.drop))          # the mask of the forward this graph belongs to
             check(lib.prego_attention_layer_backward(layer._ht, B, L, 1 if layer.mask_flag else 0, C.c_void_p(dout.data_ptr()),
                                                      None if dx is None else C.c_void_p(dx.data_ptr()), ptr_array([g.data_ptr() for g in grads]),
                                                      len(grads), C.c_void_p(layer._ws_train.data_ptr()), layer._ws_train.numel(),
@@ -329,8 +336,15 @@ class AttentionLayer:
     the row log-sum-exp and backward() returns the gradients of x and of the eight parameters; that path computes with bf16
     operands on its own handle (as ViTEnc's training does), re-ingesting the parameters whenever an optimizer changed them."""
 
-    def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16"):
+    def __init__(self, wq, bq, wk, bk, wv, bv, wo, bo, n_heads: int, mask_flag: bool = True, compute_dtype: str = "fp16",
+                 attention_dropout: float = 0.0):
         self.lib = _lib.load()
+        # FullAttention(attention_dropout=...) (attn.py:36-39; the reference's default is 0.1): acts on the attention probabilities of the
+        # AUTOGRAD path while the layer is in training mode (train() / eval(), as nn.Module); inference calls never drop
+        if not (0.0 <= float(attention_dropout) < 1.0):
+            raise PregoError(f"attention_dropout {attention_dropout}: expected 0 <= p < 1")
+        self.attention_dropout = float(attention_dropout)
+        self.training = True
         if compute_dtype not in ("fp16", "bf16", "fp32"):
             raise PregoError(f"AttentionLayer compute_dtype {compute_dtype!r}: 'fp16', 'bf16' or 'fp32'")
         self.compute_dtype = compute_dtype
@@ -349,6 +363,13 @@ class AttentionLayer:
         self._ws = None
         self.params = (wq, bq, wk, bk, wv, bv, wo, bo)
         self._ht, self._ht_key, self._ws_train, self._train_gen = None, None, None, 0
+
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
 
     def _train_handle(self, params):
         """the bf16 handle of the autograd path, holding the CURRENT values of the parameters"""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): everything profiles/ holds for one round, at the tree that travelled.
 #   bash scripts/collect_round.sh r04          then, in the container:  python scripts/summarize_round.py r04
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O

@@ -215,6 +215,53 @@ def test_g6b_attention_layer_backward(d, B, L, mask):
         out.sum().backward()
 
 
+def test_attention_layer_attention_dropout_in_training_mode():
+    """FullAttention(attention_dropout=p) (attn.py:36-39,54: nn.Dropout on A = softmax(scale * scores)) on the autograd path.  torch's RNG
+    stream cannot be matched, so the mask is held to what defines it: with zero query / key projections A is uniform (1 / L), with a zero
+    value weight every value row is the bias c, with an identity out_projection the layer's output row i, head h is s[i, h] * c where
+    s = (kept probabilities of the row) / (1 - p).  So (1) the kept fraction is 1 - p and s has the binomial mean 1 and variance
+    p / ((1 - p) L), rows and heads draw different masks; (2) the gradient of the value bias is sum_i s[i, h] * dout[i, :]: the BACKWARD
+    regenerated exactly the mask of its forward; (3) a new forward draws a new mask; (4) eval() drops nothing, bit for bit."""
+    from prego_amd.transformer import AttentionLayer
+    d, H, B, L, p = 512, 8, 2, 256, 0.25
+    dh = d // H
+    g = torch.Generator(device="cuda").manual_seed(3)
+    c = torch.rand(d, device="cuda", generator=g) + 0.5
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    params = [z(d, d), z(d), z(d, d), z(d), z(d, d), c.clone(), torch.eye(d, device="cuda"), z(d)]
+    params = [t.requires_grad_(True) for t in params]
+    x = torch.randn(B, L, d, device="cuda", generator=g)
+    dout = torch.rand(B, L, d, device="cuda", generator=g) + 0.5
+    layer = AttentionLayer(*params, n_heads=H, mask_flag=False, attention_dropout=p)
+    torch.manual_seed(11)
+    out = layer(x)
+    (out * dout).sum().backward()
+    s = (out.detach() / c).reshape(B, L, H, dh)
+    assert float((s.std(dim=-1) / s.mean(dim=-1).clamp_min(1e-6)).max()) < 2e-2          # one factor per (row, head): bf16 noise only
+    s = s.mean(-1)                                                                        # [B, L, H]
+    kept = s * (1 - p) * L                                                                # kept keys per row and head
+    assert float((kept - kept.round()).abs().max()) < 0.6                                 # whole keys (bf16 probabilities: 1 / 256 is exact)
+    frac = float(kept.sum() / (B * L * H * L))
+    assert abs(frac - (1 - p)) < 5e-3, frac
+    assert abs(float(s.mean()) - 1.0) < 5e-3
+    var_ref = p / ((1 - p) * L)
+    assert 0.8 * var_ref < float(s.var()) < 1.25 * var_ref, (float(s.var()), var_ref)
+    assert float(s[0, 0].std()) > 0 and float(s[:, :, 0].std()) > 0                       # heads and rows draw their own masks
+    # (2) d loss / d bv[k] = sum over rows of s[row, head(k)] * dout[row, k]
+    ref_gbv = (s.unsqueeze(-1) * dout.reshape(B, L, H, dh)).sum((0, 1)).reshape(d)
+    got_gbv = params[5].grad
+    assert float((got_gbv - ref_gbv).abs().max() / ref_gbv.abs().max()) < 1e-2
+    # (3) another forward: another mask; (4) eval(): none
+    out2 = layer(x)
+    assert not torch.equal(out2.detach(), out.detach())
+    layer.eval()
+    out3 = layer(x)
+    ref = AttentionLayer(*[t.detach() for t in params], n_heads=H, mask_flag=False, compute_dtype="bf16")(x)
+    assert torch.equal(out3.detach(), ref)
+    with pytest.raises(Exception, match="attention_dropout"):
+        AttentionLayer(*[t.detach() for t in params], n_heads=H, attention_dropout=1.0)
+
+
 def test_noncausal_attention_vs_oracle_ragged_length():
     """L = 129 (window + cls token; not a multiple of any tile) without mask, against the numpy oracle"""
     from prego_amd.transformer import attention_layer
