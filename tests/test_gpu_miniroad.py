@@ -506,12 +506,12 @@ def test_g10_other_hidden_sizes_and_two_gru_layers(tag, hid, layers, dtype):
 
 
 def test_other_dimensions_many_clips_and_rejections():
-    """hidden_dim 512 with 300 ragged clips (three clip tiles per group: the multi-tile launch of the classic kernel) and two GRU layers
-    with 150 clips against the numpy oracle on sampled clips; what the kernels are not built for is refused with a message: training,
+    """hidden_dim 512 with 300 ragged clips (three clip tiles per group: the multi-tile launch of the classic kernel), two GRU layers
+    with 150 clips and hidden_dim 2048 with 70 clips against the numpy oracle on sampled clips; what the kernels are not built for is refused with a message: training,
     the streaming step and fp16x2 at those dimensions"""
     from prego_amd._lib import PregoError
     rng = np.random.RandomState(3)
-    for hid, layers, n in ((512, 1, 300), (1024, 2, 150)):
+    for hid, layers, n in ((512, 1, 300), (1024, 2, 150), (2048, 1, 70)):      # 2048: two groups of 128 workgroups, 70 clips = three tiles
         cfg = assembly101_cfg(hidden_dim=hid, num_layers=layers)
         sd = W.miniroad_state_dict(cfg, seed=20, head_gain=8.0)
         m = _model(cfg, sd, "fp16")
