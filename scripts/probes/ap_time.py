@@ -3,10 +3,11 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from prego_amd.metrics import perframe_average_precision_device, perframe_average_precision
-n, C = int(sys.argv[1]) if len(sys.argv) > 1 else 2306143, 86
+n, C = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2306143, 86
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 pr = torch.softmax(torch.randn(n, C, device="cuda", generator=g) * 3, -1)
-pr = (pr * 4096).round() / 4096            # plenty of ties
+if "--distinct" not in sys.argv:
+    pr = (pr * 4096).round() / 4096            # plenty of ties
 lab = torch.randint(0, C, (n,), device="cuda", generator=g)
 gt = torch.zeros(n, C, device="cuda"); gt[torch.arange(n, device="cuda"), lab] = 1
 names = [f"c{i}" for i in range(C)]

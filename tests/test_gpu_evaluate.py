@@ -109,9 +109,10 @@ def test_link_fed_eval_equals_the_copy_then_forward_eval(tmp_path, dtype, with_f
 
 @pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86)])
 def test_device_average_precision_kernel_vs_sklearn(n, C):
-    """prego_perframe_ap (csrc/metrics.hip: segmented radix sort + scan per class) against sklearn's average_precision_score and the
-    host implementation: random scores, heavy ties, a constant column, negative scores (raw logits), -0.0 vs +0.0, a class
-    without positives, tile edges (n = 1, 63, 4097)."""
+    """prego_perframe_ap (csrc/metrics.hip: the positives of every class sorted, every score counted against them) against sklearn's
+    average_precision_score and the host implementation: random scores, heavy ties, a constant column, negative scores (raw logits),
+    -0.0 vs +0.0, a class without positives, tile edges (n = 1, 63, 4097); multi-label targets with more positives than the count
+    kernel's LDS table holds (a class that is positive on half of the frames, one on all of them: the two-level search)."""
     from sklearn.metrics import average_precision_score
     from prego_amd.metrics import average_precision_columns, perframe_average_precision, perframe_average_precision_device
     rng = np.random.default_rng(n + C)
@@ -127,6 +128,10 @@ def test_device_average_precision_kernel_vs_sklearn(n, C):
     gt[np.arange(n), rng.integers(0, C, n)] = 1
     if C > 6:
         gt[:, 6] = 0                                     # class without positives
+    if C > 9:
+        gt[:, 7] = rng.random(n) < 0.5                   # multi-label: 75 000 positives of 150 000 frames
+        gt[:, 8] = 1                                     # every frame positive
+        pr[:, 9] = np.round(pr[:, 9], 2); gt[:, 9] = rng.random(n) < 0.3      # many positives AND heavy ties
     names = [f"c{i}" for i in range(C)]
     dev = perframe_average_precision_device(torch.from_numpy(pr).cuda(), torch.from_numpy(gt).cuda(), names)
     host = perframe_average_precision(pr, gt, names)
