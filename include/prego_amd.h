@@ -222,13 +222,21 @@ int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens,
  * then run over one value per window instead of one per frame. */
 int prego_window_vote(const int32_t* argmax, int64_t n_frames, int window, int n_classes, int32_t* votes, prego_stream_t stream);
 
+/* trainer/eval.py:59-65 writes the per-frame predicted and ground-truth class ids of every video as JSON text.  ids: device int32 [n]
+ * (0 <= id <= 999); text: device uint32 [n], element i = the four bytes "%3d," of ids[i] in memory order (blanks in front of a number
+ * are JSON whitespace), so the host cuts the text per video and turns every list's last comma into its bracket.  bad (nullable):
+ * device int32, set to 1 when an id is out of range (its text is then "  0,": the caller must not use the text). */
+int prego_format_ids(const int32_t* ids, int64_t n, uint32_t* text, int32_t* bad, prego_stream_t stream);
+
 /* utils/metrics.py:25-62 on the device: sklearn.metrics.average_precision_score of every class column of the per-frame score
  * matrix the eval loop collects (trainer/eval.py:48-57; main.py:101 runs it after every epoch).  scores / target: device fp32
  * [n_frames][n_classes] row-major (target != 0 marks a positive).  Thresholds are the distinct score values (ties share one),
  * AP = sum_k (R_k - R_{k-1}) P_k.  ap: device double [n_classes] (NaN for a class without positives); n_pos (nullable): device
  * int64 [n_classes] positives per class; score_sum (nullable): device double [n_classes] column sums of the scores (the "pred:"
  * figure of metrics.py:52).  The caller applies the reference's "ignore class 0" rule (metrics.py:44-48) when averaging.
- * Exact ranks (segmented radix sort), fp64 sum.  Workspace: prego_perframe_ap_workspace_bytes (16 B per score + histograms). */
+ * Exact integer ranks, fp64 sum: only thresholds that hold a positive contribute, so the positives of every class are sorted
+ * (segmented radix sort) and every score is counted against them (csrc/metrics.hip).  Workspace:
+ * prego_perframe_ap_workspace_bytes (16 B per score + histograms). */
 size_t prego_perframe_ap_workspace_bytes(int64_t n_frames, int n_classes);
 int prego_perframe_ap(const float* scores, const float* target, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
                       double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream);

@@ -1867,6 +1867,13 @@ extern "C" int prego_window_vote(const int32_t* argmax, int64_t n_frames, int wi
   return PREGO_OK;
 }
 
+extern "C" int prego_format_ids(const int32_t* ids, int64_t n, uint32_t* text, int32_t* bad, prego_stream_t stream) {
+  if (!ids || !text) return fail(PREGO_EINVAL, "format_ids: NULL argument");
+  if (launch_format_ids(ids, n, text, bad, (hipStream_t)stream)) return fail(PREGO_EINVAL, "format_ids: n %lld", (long long)n);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+
 // ================================================================================================
 // metric: utils/metrics.py:25-62 (per-class average precision of the per-frame scores) on the device
 // ================================================================================================

@@ -4,6 +4,9 @@
 //                 wrote never leaves HBM, only one int32 per window does.
 // One wave per window: a segmented histogram in LDS (integer atomics: exact and order-independent), then a 64-lane argmax over
 // (count, -class).
+//   format_ids    trainer/eval.py:59-65 writes {vid: {"pred": [...], "gt": [...]}} as JSON text: 2 x frames integers.  The ids are on
+//                 the device; every id becomes its four bytes "%3d," here, so the host cuts the text per video instead of formatting
+//                 4.6 M numbers behind the last frame of an eval pass (blanks in front of a number are JSON whitespace).
 #include "common.h"
 #include "kernels.h"
 
@@ -53,5 +56,22 @@ int launch_window_vote(const int* pred, long long n_frames, int window, int n_cl
   long long blocks = (n_win + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   window_vote_kernel<<<(int)blocks, 256, 0, s>>>(pred, n_frames, window, n_classes, votes);
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void format_ids_kernel(const int* __restrict__ ids, long long n, unsigned* __restrict__ text, int* __restrict__ bad) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = ids[i];
+  if (v < 0 || v > 999) { if (bad) *bad = 1; text[i] = 0x2C302020u; return; }      // "  0,": the host does not use a text with the flag set
+  const unsigned h = (unsigned)v / 100u, t = ((unsigned)v / 10u) % 10u, u = (unsigned)v % 10u;
+  const unsigned c0 = h ? '0' + h : ' ';
+  const unsigned c1 = (h || t) ? '0' + t : ' ';
+  text[i] = c0 | (c1 << 8) | (('0' + u) << 16) | ((unsigned)',' << 24);             // little-endian: byte 0 first
+}
+
+int launch_format_ids(const int* ids, long long n, unsigned* text, int* bad, hipStream_t s) {
+  if (n <= 0) return -1;
+  format_ids_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(ids, n, text, bad);
   return 0;
 }

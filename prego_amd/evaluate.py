@@ -46,6 +46,7 @@ class Evaluate(nn.Module):
         self.output_dir = cfg.get("eval_output_dir", "output_miniRoad")
         self.last_fps = None
         self._copy_stream = None             # side stream for the H2D feature copies (double buffering against the compute stream)
+        self._ap_stream = None               # side stream of the metric's kernels (enqueued behind the last forward)
 
     @staticmethod
     def _new_copy_stream(dev):
@@ -250,6 +251,24 @@ class Evaluate(nn.Module):
             if ids_dev.is_cuda:
                 ids_host = torch.empty(ids_dev.shape, dtype=ids_dev.dtype, pin_memory=True)
                 ids_host.copy_(ids_dev, non_blocking=True)
+                if ids_dev.dtype == torch.int32 and len(self.all_class_names) <= 1000:
+                    # the JSON text of the ids as well (prego_format_ids: four bytes "%3d," per id), so that behind the last frame
+                    # the host only cuts it per video: formatting 2 x 2.3 M numbers through a numpy table took 10-15 ms there
+                    from . import _lib
+                    from ._lib import check
+                    import ctypes as C
+                    ids_dev = ids_dev.contiguous()
+                    text_dev = torch.empty(ids_dev.shape, dtype=torch.int32, device=ids_dev.device)
+                    bad_dev = torch.zeros(1, dtype=torch.int32, device=ids_dev.device)
+                    with torch.cuda.device(ids_dev.device):
+                        check(_lib.load().prego_format_ids(C.c_void_p(ids_dev.data_ptr()), ids_dev.numel(), C.c_void_p(text_dev.data_ptr()),
+                                                           C.c_void_p(bad_dev.data_ptr()),
+                                                           C.c_void_p(torch.cuda.current_stream(ids_dev.device).cuda_stream)))
+                    text_host = torch.empty(ids_dev.shape, dtype=torch.int32, pin_memory=True)
+                    bad_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    text_host.copy_(text_dev, non_blocking=True)
+                    bad_host.copy_(bad_dev, non_blocking=True)
+                    rec["text"], rec["bad"], rec["_keep_text"] = text_host, bad_host, (text_dev, bad_dev)
                 ev = torch.cuda.Event()
                 ev.record()
                 rec["ids"], rec["ev"], rec["_keep"] = ids_host, ev, ids_dev
@@ -269,19 +288,36 @@ class Evaluate(nn.Module):
             ids = rec["ids"].numpy()
         elif rec["link_fed"]:
             self._copy_stream.synchronize()      # the copies read the loader's pinned tensors: keep them alive until then
+        text = None
+        if ids is not None and rec.get("text") is not None and int(rec["bad"][0]) == 0:
+            text = rec["text"].numpy().view(np.uint8).reshape(2, -1, 4)      # [pred | gt][frame] = b"%3d," (prego_format_ids)
         o = 0
         for vid, (p, a, t) in rec["items"]:
-            # the [T, C] score and target matrices stay torch tensors on the model's device (one entry per video, concatenated
-            # once at the end); the reference extends Python lists by one row object per frame (eval.py:46-49)
-            pred_scores.append(p)
-            gt_targets.append(t)
             if ids is not None:
                 n = int(a.shape[0])
                 output[vid] = {"pred": ids[0, o:o + n], "gt": ids[1, o:o + n]}      # int arrays; text below
                 if json_parts is not None:
-                    json_parts += self._json_int_lists({vid: output[vid]}, as_parts=True)
+                    if json_parts:
+                        json_parts.append(b", ")
+                    if text is not None and n > 0:
+                        # the video's slice of the device-made text, in place: every list's last comma becomes its bracket
+                        tp, tg = text[0, o:o + n], text[1, o:o + n]
+                        tp[-1, 3] = tg[-1, 3] = 0x5D
+                        json_parts += [json.dumps(str(vid)).encode() + b': {"pred": [', tp, b', "gt": [', tg, b"}"]
+                    else:
+                        json_parts += self._json_int_lists({vid: output[vid]}, as_parts=True)
                 o += n
                 self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
+
+    @staticmethod
+    def _scores(rec, pred_scores, gt_targets):
+        """the [T, C] score and target matrices of a batch's videos, taken at launch time: they stay torch tensors on the model's device
+        (one entry per video, concatenated once at the end; the reference extends Python lists by one row object per frame,
+        eval.py:46-49), so the metric's kernels can be enqueued behind the last forward before the host waits for anything"""
+        if rec is not None:
+            for _vid, (p, _a, t) in rec["items"]:
+                pred_scores.append(p)
+                gt_targets.append(t)
 
     def eval(self, model, dataloader, logger, device):
         model.eval()
@@ -318,6 +354,7 @@ class Evaluate(nn.Module):
                 if len(batch) >= max_clips or frames >= self.max_frames_per_batch:
                     mark("loader")
                     rec = self._flush(model, batch, device)                 # batch k: enqueued ...
+                    self._scores(rec, pred_scores, gt_targets)
                     mark("launch")
                     self._collect(pending, pred_scores, gt_targets, output, json_parts)      # ... while the host finishes batch k - 1
                     mark("collect")
@@ -325,6 +362,27 @@ class Evaluate(nn.Module):
                     frames = 0
             mark("loader")
             rec = self._flush(model, batch, device)
+            self._scores(rec, pred_scores, gt_targets)
+            finish_ap = None
+            if world == 1 and torch.device(device).type == "cuda" and self.metric == "AP" and pred_scores:
+                # the metric in libprego_amd.so (prego_perframe_ap), ENQUEUED here behind the last forward and collected behind the
+                # output file: the GPU ranks the positives while the host waits for the ids and writes the JSON
+                # ... on a stream of its own behind an event, so that model.check() below (which drains the forward's stream to read its
+                # timeout word) does not wait for the metric as well
+                if self._ap_stream is None:
+                    self._ap_stream = torch.cuda.Stream(torch.device(device))
+                fwd_done = torch.cuda.Event()
+                fwd_done.record(torch.cuda.current_stream(torch.device(device)))
+                with torch.cuda.stream(self._ap_stream):
+                    self._ap_stream.wait_event(fwd_done)
+                    pred_all = torch.cat(pred_scores, 0)
+                    gt_all = torch.cat(gt_targets, 0).to(pred_all.device)
+                    ap_fn = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
+                                                              self.data_processing, self.metric, defer=True)
+
+                def finish_ap(_fn=ap_fn, _s=self._ap_stream):
+                    with torch.cuda.stream(_s):           # the result's device -> host copy follows the kernels on THEIR stream
+                        return _fn()
             mark("launch")
             self._collect(pending, pred_scores, gt_targets, output, json_parts)
             mark("collect")
@@ -358,21 +416,22 @@ class Evaluate(nn.Module):
                 if rank == 0:
                     logger.info(f"Processed {num_frames} frames in {t_end - t_begin:.1f} seconds ({self.last_fps:.1f} FPS)")
                 return result["mean_AP"]
-            pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
-            gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
+            if finish_ap is None:
+                pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
+                gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
+                if torch.device(device).type == "cuda" and self.metric == "AP":        # an empty eval set: the empty report
+                    finish_ap = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
+                                                                  self.data_processing, self.metric, defer=True)
             num_frames = int(gt_all.shape[0])
-            finish_ap = None
-            if torch.device(device).type == "cuda" and self.metric == "AP":
-                # sort + scan per class in libprego_amd.so (prego_perframe_ap), ENQUEUED here and collected behind the output file:
-                # the host formats the JSON while the GPU sorts.  After a multi-rank gather the matrices are host tensors on rank 0
-                # and go back to its GPU first
-                finish_ap = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
-                                                              self.data_processing, self.metric, defer=True)
-            mark("ap_enqueued")
             if self.cfg["eval"] is not None:
                 os.makedirs(self.output_dir, exist_ok=True)
                 with open(os.path.join(self.output_dir, "output_miniROAD.json"), "wb") as file:
-                    file.write(b"{" + b", ".join(json_parts) + b"}" if json_parts is not None else self._json_int_lists(output))
+                    if json_parts is not None:          # per-video pieces (bytes and slices of the device-made text), ", " between videos
+                        file.write(b"{")
+                        file.writelines(json_parts)
+                        file.write(b"}")
+                    else:
+                        file.write(self._json_int_lists(output))
             mark("json_written")
             if finish_ap is not None:
                 result = finish_ap()
