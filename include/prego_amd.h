@@ -240,6 +240,17 @@ int prego_format_ids(const int32_t* ids, int64_t n, uint32_t* text, int32_t* bad
 size_t prego_perframe_ap_workspace_bytes(int64_t n_frames, int n_classes);
 int prego_perframe_ap(const float* scores, const float* target, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
                       double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream);
+/* The same metric with the positives given as ONE class id per frame (device int32 [n_frames]; an id outside [0, n_classes) = a
+ * frame without a positive): what a one-hot target matrix says, in 4 bytes per frame instead of 4 x n_classes.  Same results, bit for bit. */
+int prego_perframe_ap_labels(const float* scores, const int32_t* labels, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
+                             double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream);
+/* HOST function (no device work): the reference's loader yields fp32 target rows [n_frames][n_classes] per video (one-hot for both
+ * shipped configs).  targets: n_videos host pointers, n_frames: their row counts; labels: host int32 [sum of n_frames], the videos one
+ * after the other, labels[i] = np.argmax(row i) (eval.py:55, the first maximum); onehot[v] = 1 iff every row of video v holds exactly one
+ * nonzero entry and it is positive - then the labels say everything the matrix does and prego_perframe_ap_labels replaces
+ * prego_perframe_ap (the eval loop sends 4 bytes per frame over the link instead of 4 x n_classes).  Up to 16 threads. */
+int prego_onehot_labels(int n_videos, const float* const* targets, const int64_t* n_frames, int n_classes, int32_t* labels,
+                        int32_t* onehot);
 
 /* torch.optim.AdamW as main.py:62-67 builds it (amsgrad off, maximize off), fused over a tensor list in one launch:
  *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)

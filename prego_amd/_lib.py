@@ -25,7 +25,7 @@ SYMBOLS = [
     "prego_miniroad_max_clips", "prego_miniroad_workspace_bytes", "prego_miniroad_forward",
     "prego_miniroad_check", "prego_miniroad_timing_enable", "prego_miniroad_timing_read",
     "prego_miniroad_set_dropout", "prego_oad_loss", "prego_oad_loss_reduce",
-    "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote", "prego_format_ids",
+    "prego_miniroad_backward_workspace_bytes", "prego_miniroad_backward", "prego_adamw_step", "prego_miniroad_adamw_step", "prego_window_vote", "prego_format_ids", "prego_perframe_ap_labels", "prego_onehot_labels",
     "prego_vit_create", "prego_vit_destroy", "prego_vit_num_tensors", "prego_vit_set_weights",
     "prego_vit_workspace_bytes", "prego_vit_forward",
     "prego_vit_set_dropout", "prego_vit_train_workspace_bytes", "prego_vit_forward_train", "prego_vit_backward",
@@ -99,6 +99,8 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_perframe_ap_workspace_bytes.argtypes = [i64, i32]
     lib.prego_perframe_ap_workspace_bytes.restype = sz
     lib.prego_perframe_ap.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]
+    lib.prego_perframe_ap_labels.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, sz, vp]
+    lib.prego_onehot_labels.argtypes = [i32, C.POINTER(vp), C.POINTER(i64), i32, vp, C.POINTER(C.c_int32)]
     f32 = C.c_float
     lib.prego_adamw_step.argtypes = [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), i64, f32, f32, f32, f32, f32, vp]
     lib.prego_miniroad_adamw_step.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i64, f32, f32, f32, f32, f32, vp]

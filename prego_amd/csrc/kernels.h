@@ -259,7 +259,7 @@ int launch_window_vote(const int* pred, long long n_frames, int window, int n_cl
 // per-frame average precision (metrics.hip): segmented radix sort + scan, one segment per class
 int launch_format_ids(const int* ids, long long n, unsigned* text, int* bad, hipStream_t s);
 size_t perframe_ap_workspace_bytes(long long n_frames, int n_classes);
-int launch_perframe_ap(const float* scores, const float* target, long long n_frames, int n_classes, double* ap, long long* n_pos,
+int launch_perframe_ap(const float* scores, const float* target, const int* labels, long long n_frames, int n_classes, double* ap, long long* n_pos,
                        double* score_sum, void* workspace, hipStream_t s);
 
 // fused multi-tensor AdamW (optim.hip)

@@ -49,9 +49,12 @@ __device__ __forceinline__ float ap_key_score(unsigned k) {
 
 
 // [AP_XF frames] x [<= AP_XC classes] tile: keys written class-major through an LDS transpose, positives appended per class
-__global__ __launch_bounds__(256) void ap_extract_kernel(const float* __restrict__ scores, const float* __restrict__ target, long long n,
-                                                         int C, unsigned* __restrict__ keys, unsigned* __restrict__ pos,
-                                                         unsigned* __restrict__ cursor) {
+// LABELS: the positives are given as one class id per frame (one-hot targets the feeder reduced on the host: 4 bytes per frame over
+// the link instead of 4 x classes); a frame whose id is outside [0, C) has no positive
+template <bool LABELS>
+__global__ __launch_bounds__(256) void ap_extract_kernel(const float* __restrict__ scores, const float* __restrict__ target,
+                                                         const int* __restrict__ labels, long long n, int C, unsigned* __restrict__ keys,
+                                                         unsigned* __restrict__ pos, unsigned* __restrict__ cursor) {
   __shared__ unsigned tile[AP_XC][AP_XF + 1];
   __shared__ unsigned lcnt[AP_XC], lbase[AP_XC];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(256) void ap_extract_kernel(const float* __restrict
     const int f = idx / cb, c = idx - f * cb;
     const size_t g = (size_t)(f0 + f) * C + c0 + c;
     tile[c][f] = ap_desc_key(scores[g]);
-    if (target[g] != 0.f) atomicAdd(&lcnt[c], 1u);
+    const bool positive = LABELS ? labels[f0 + f] == c0 + c : target[g] != 0.f;
+    if (positive) atomicAdd(&lcnt[c], 1u);
   }
   __syncthreads();
   if (tid < cb) {
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(256) void ap_extract_kernel(const float* __restrict
   __syncthreads();
   for (int idx = tid; idx < total; idx += 256) {
     const int f = idx / cb, c = idx - f * cb;
-    if (target[(size_t)(f0 + f) * C + c0 + c] != 0.f)
+    const bool positive = LABELS ? labels[f0 + f] == c0 + c : target[(size_t)(f0 + f) * C + c0 + c] != 0.f;
+    if (positive)
       pos[(size_t)(c0 + c) * n + lbase[c] + atomicAdd(&lcnt[c], 1u)] = tile[c][f];
   }
   for (int c = wave; c < cb; c += 4) {
@@ -422,9 +427,10 @@ size_t perframe_ap_workspace_bytes(long long n, int C) {
   return 4 * (size_t)C * (size_t)n * 4 + (size_t)C * AP_RADIX * ntiles * 4 + (size_t)C * 4 + 8 + (size_t)AP_SPLITS_MAX * C * 8 + 1024;
 }
 
-// Returns 0, or -1 on a bad argument.  ws must hold perframe_ap_workspace_bytes(n, C) bytes.
-int launch_perframe_ap(const float* scores, const float* target, long long n, int C, double* ap, long long* n_pos, double* score_sum,
-                       void* ws, hipStream_t s) {
+// Returns 0, or -1 on a bad argument.  ws must hold perframe_ap_workspace_bytes(n, C) bytes.  Positives: target != 0, or (labels != NULL)
+// the frame's class id.
+int launch_perframe_ap(const float* scores, const float* target, const int* labels, long long n, int C, double* ap, long long* n_pos,
+                       double* score_sum, void* ws, hipStream_t s) {
   if (n <= 0 || C <= 0 || C > 65535 || n >= (1ll << 31)) return -1;    // per-class cursors are 32-bit
   static bool attr = false;
   if (!attr) {
@@ -441,7 +447,9 @@ int launch_perframe_ap(const float* scores, const float* target, long long n, in
   unsigned* cursor = hist + (size_t)C * AP_RADIX * ntiles;
   double* partial = (double*)(((uintptr_t)(cursor + C) + 7) & ~(uintptr_t)7);
   (void)hipMemsetAsync(cursor, 0, (size_t)C * 4, s);
-  ap_extract_kernel<<<dim3((unsigned)((n + AP_XF - 1) / AP_XF), (unsigned)((C + AP_XC - 1) / AP_XC)), 256, 0, s>>>(scores, target, n, C, keys, p0, cursor);
+  const dim3 xg((unsigned)((n + AP_XF - 1) / AP_XF), (unsigned)((C + AP_XC - 1) / AP_XC));
+  if (labels) ap_extract_kernel<true><<<xg, 256, 0, s>>>(scores, nullptr, labels, n, C, keys, p0, cursor);
+  else ap_extract_kernel<false><<<xg, 256, 0, s>>>(scores, target, nullptr, n, C, keys, p0, cursor);
   const int tg = ntiles < AP_TGRID ? ntiles : AP_TGRID;
   for (int p = 0; p < AP_PASSES; ++p) {
     ap32_hist_kernel<<<dim3(tg, C), 64, 0, s>>>(p0, cursor, n, ntiles, 8 * p, hist, p == 0 ? cnt : nullptr);

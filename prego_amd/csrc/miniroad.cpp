@@ -1881,16 +1881,63 @@ extern "C" size_t prego_perframe_ap_workspace_bytes(int64_t n_frames, int n_clas
   if (n_frames <= 0 || n_classes <= 0) return 0;
   return perframe_ap_workspace_bytes(n_frames, n_classes);
 }
-extern "C" int prego_perframe_ap(const float* scores, const float* target, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
-                                 double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream) {
-  if (!scores || !target || !ap || !workspace) return fail(PREGO_EINVAL, "perframe_ap: NULL argument");
+static int perframe_ap_common(const float* scores, const float* target, const int32_t* labels, int64_t n_frames, int n_classes, double* ap,
+                              int64_t* n_pos, double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  if (!scores || (!target && !labels) || !ap || !workspace) return fail(PREGO_EINVAL, "perframe_ap: NULL argument");
   if (n_frames <= 0 || n_frames >= (1ll << 31) || n_classes <= 0 || n_classes > 65535)
     return fail(PREGO_EINVAL, "perframe_ap: n_frames %lld, n_classes %d", (long long)n_frames, n_classes);
   if (workspace_bytes < perframe_ap_workspace_bytes(n_frames, n_classes))
     return fail(PREGO_EWORKSPACE, "perframe_ap: workspace %zu < %zu", workspace_bytes, perframe_ap_workspace_bytes(n_frames, n_classes));
-  if (launch_perframe_ap(scores, target, n_frames, n_classes, ap, (long long*)n_pos, score_sum, workspace, (hipStream_t)stream))
+  if (launch_perframe_ap(scores, target, (const int*)labels, n_frames, n_classes, ap, (long long*)n_pos, score_sum, workspace, (hipStream_t)stream))
     return fail(PREGO_EINVAL, "perframe_ap: bad arguments");
   HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+extern "C" int prego_perframe_ap(const float* scores, const float* target, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
+                                 double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  return perframe_ap_common(scores, target, nullptr, n_frames, n_classes, ap, n_pos, score_sum, workspace, workspace_bytes, stream);
+}
+extern "C" int prego_perframe_ap_labels(const float* scores, const int32_t* labels, int64_t n_frames, int n_classes, double* ap, int64_t* n_pos,
+                                        double* score_sum, void* workspace, size_t workspace_bytes, prego_stream_t stream) {
+  return perframe_ap_common(scores, nullptr, labels, n_frames, n_classes, ap, n_pos, score_sum, workspace, workspace_bytes, stream);
+}
+
+// The feeder's side of that: one-hot target rows (what the reference's dataset yields, dataset.py / eval.py:55 np.argmax(target)) reduced
+// to their class id on the host, in the loader's own memory, by a few threads - while the GPU is busy with the features.  HOST function.
+extern "C" int prego_onehot_labels(int n_videos, const float* const* targets, const int64_t* n_frames, int n_classes, int32_t* labels,
+                                   int32_t* onehot) {
+  if (n_videos < 0 || (n_videos && (!targets || !n_frames || !labels || !onehot)) || n_classes <= 0)
+    return fail(PREGO_EINVAL, "onehot_labels: bad argument");
+  std::vector<int64_t> off((size_t)n_videos + 1, 0);
+  for (int v = 0; v < n_videos; ++v) {
+    if (n_frames[v] < 0 || (n_frames[v] && !targets[v])) return fail(PREGO_EINVAL, "onehot_labels: video %d", v);
+    off[(size_t)v + 1] = off[(size_t)v] + n_frames[v];
+    onehot[v] = 1;
+  }
+  const int64_t total = off[(size_t)n_videos];
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int nt = (int)std::min<int64_t>(std::max<int64_t>(1, total / 16384), std::min(16u, hw ? hw : 1u));
+  auto work = [&](int t) {
+    const int64_t a = total * t / nt, b = total * (t + 1) / nt;
+    int v = (int)(std::upper_bound(off.begin(), off.end(), a) - off.begin()) - 1;
+    for (int64_t i = a; i < b; ++i) {
+      while (i >= off[(size_t)v + 1]) ++v;
+      const float* row = targets[v] + (size_t)(i - off[(size_t)v]) * n_classes;
+      int nz = 0, pos = 0;
+      for (int c = 0; c < n_classes; ++c) { nz += row[c] != 0.f; pos += row[c] > 0.f; }
+      int best = 0;                                            // np.argmax: the first maximum
+      if (nz == 1 && pos == 1) { while (!(row[best] > 0.f)) ++best; }
+      else {
+        __atomic_store_n(&onehot[v], 0, __ATOMIC_RELAXED);
+        for (int c = 1; c < n_classes; ++c) if (row[c] > row[best]) best = c;
+      }
+      labels[i] = best;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  if (total > 0) work(0);
+  for (auto& x : th) x.join();
   return PREGO_OK;
 }
 

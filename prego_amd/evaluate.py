@@ -99,6 +99,47 @@ class Evaluate(nn.Module):
         parts = [json.dumps(str(vid)).encode() + b': {"pred": ' + arr(v["pred"]) + b', "gt": ' + arr(v["gt"]) + b"}" for vid, v in output.items()]
         return parts if as_parts else b"{" + b", ".join(parts) + b"}"
 
+    def _targets_to_device(self, targets, dev):
+        """The loader's target rows [T, C] of a batch's videos -> device tensors, enqueued on the current (copy) stream.  Host fp32
+        one-hot targets (what the reference's dataset yields) travel as ONE class id per frame: `prego_onehot_labels` reduces them in the
+        loader's memory (a few host threads, while the GPU is busy with the features) and says per video whether the ids tell everything
+        the rows do - 4 bytes per frame over the link instead of 4 x classes (0.79 GB for the 182-video eval set: 14 ms of a 200 ms
+        pass).  Such a video's entry is an int32 vector [T]; any other video's rows are copied as they are ([T, C])."""
+        out = [None] * len(targets)
+        host = [i for i, t in enumerate(targets) if t.device.type == "cpu" and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+                and t.shape[1] == len(self.all_class_names)]
+        if dev.type == "cuda" and host and self.cfg.get("eval_label_targets", True):
+            import ctypes as C
+            from . import _lib
+            from ._lib import check
+            nv = len(host)
+            ptrs = (C.c_void_p * nv)(*[targets[i].data_ptr() for i in host])
+            rows = (C.c_int64 * nv)(*[int(targets[i].shape[0]) for i in host])
+            total = sum(int(targets[i].shape[0]) for i in host)
+            labels = torch.empty(max(total, 1), dtype=torch.int32, pin_memory=True)
+            flags = (C.c_int32 * nv)()
+            check(_lib.load().prego_onehot_labels(nv, ptrs, rows, len(self.all_class_names), C.c_void_p(labels.data_ptr()), flags))
+            labels_dev = labels.to(dev, non_blocking=True)
+            self._keep_labels = labels                       # the pinned source of an async copy
+            o = 0
+            for k, i in enumerate(host):
+                n = int(targets[i].shape[0])
+                if flags[k]:
+                    out[i] = labels_dev[o:o + n]
+                o += n
+        for i, t in enumerate(targets):
+            if out[i] is None:
+                out[i] = t.to(dev, non_blocking=True)
+        return out
+
+    def _gt_matrix(self, t):
+        """a video's ground truth as the [T, C] matrix the loader gave (class-id vectors of _targets_to_device expanded again)"""
+        if t.dim() == 2:
+            return t
+        m = torch.zeros((t.shape[0], len(self.all_class_names)), dtype=torch.float32, device=t.device)
+        m[torch.arange(t.shape[0], device=t.device), t.long()] = 1
+        return m
+
     def _enqueue(self, model, sub, device):
         """H2D of one sub-batch on the copy stream + its forward on the compute stream; nothing here waits for the GPU"""
         dev = torch.device(device)
@@ -114,7 +155,7 @@ class Evaluate(nn.Module):
             with torch.cuda.stream(self._copy_stream):
                 rgb = [b[0].to(dev, non_blocking=True) for b in sub]
                 flow = None if flows is None else [None if f is None else f.to(dev, non_blocking=True) for f in flows]
-                tgt = [b[2].to(dev, non_blocking=True) for b in sub]
+                tgt = self._targets_to_device([b[2] for b in sub], dev)
                 ready = torch.cuda.Event()
                 ready.record(self._copy_stream)
             cur.wait_event(ready)
@@ -184,10 +225,7 @@ class Evaluate(nn.Module):
                     events.append(ev)
                     upto.append(2 ** 31 - 1 if last else pieces[k + 1][0])      # every piece needed before that step has been copied
                     acc = 0
-            tgt = [b[2].to(dev, non_blocking=True) for b in batch]                   # only needed behind the forward
-            ready = torch.cuda.Event()
-            ready.record(self._copy_stream)
-        for t in rgb + [f for f in (flow or []) if f is not None] + tgt:
+        for t in rgb + [f for f in (flow or []) if f is not None]:
             t.record_stream(cur)                               # allocated on the copy stream (inside its context), read on `cur`
         self._feed_events = events                           # keep the hipEvent_t objects alive until the stream has used them
         eng.set_feed_events(upto, events, row_bytes)
@@ -196,6 +234,13 @@ class Evaluate(nn.Module):
         except BaseException:
             eng.set_feed_events([], [], 0)                     # a forward that never reached the library must not leave its feed events armed for the next one
             raise
+        # the targets are only needed behind the forward: reduced / copied now that everything else is enqueued, behind the features
+        with torch.cuda.stream(self._copy_stream):
+            tgt = self._targets_to_device([b[2] for b in batch], dev)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        for t in tgt:
+            t.record_stream(cur)
         cur.wait_event(ready)
         return probs, args, tgt
 
@@ -246,7 +291,8 @@ class Evaluate(nn.Module):
                "src": list(batch), "feed": getattr(self, "_feed_events", None)}       # the loader's tensors / the feed events stay alive until _collect
         if want_json:
             pred_ids = torch.cat([res[i][1] for i in range(len(batch))])
-            gt_ids = torch.cat([torch.argmax(res[i][2], dim=1) for i in range(len(batch))]).to(pred_ids.dtype)
+            gt_ids = torch.cat([res[i][2] if res[i][2].dim() == 1 else torch.argmax(res[i][2], dim=1)
+                                for i in range(len(batch))]).to(pred_ids.dtype)
             ids_dev = torch.stack([pred_ids, gt_ids])
             if ids_dev.is_cuda:
                 ids_host = torch.empty(ids_dev.shape, dtype=ids_dev.dtype, pin_memory=True)
@@ -308,6 +354,13 @@ class Evaluate(nn.Module):
                         json_parts += self._json_int_lists({vid: output[vid]}, as_parts=True)
                 o += n
                 self.last_device_argmax[vid] = a          # int32 on the device: input of aggregate_device (utils/aggregate.py)
+
+    def _cat_targets(self, gt_targets, matrix=False):
+        """the eval set's ground truth: one class-id vector [frames] when every video came as class ids (and the caller takes them), else
+        the [frames, C] matrix"""
+        if not matrix and all(t.dim() == 1 for t in gt_targets):
+            return torch.cat(gt_targets, 0)
+        return torch.cat([self._gt_matrix(t) for t in gt_targets], 0)
 
     @staticmethod
     def _scores(rec, pred_scores, gt_targets):
@@ -376,7 +429,7 @@ class Evaluate(nn.Module):
                 with torch.cuda.stream(self._ap_stream):
                     self._ap_stream.wait_event(fwd_done)
                     pred_all = torch.cat(pred_scores, 0)
-                    gt_all = torch.cat(gt_targets, 0).to(pred_all.device)
+                    gt_all = self._cat_targets(gt_targets).to(pred_all.device)
                     ap_fn = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
                                                               self.data_processing, self.metric, defer=True)
 
@@ -402,7 +455,7 @@ class Evaluate(nn.Module):
                         entries += [(p_idx, vid, ent) for (p_idx, _n), (vid, ent) in zip(pv, out.items())]
                     output = {vid: ent for _p, vid, ent in sorted(entries, key=lambda e: e[0])}
                 pred_local = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)), device=device)
-                gt_local = torch.cat(gt_targets, 0).to(pred_local.device) if gt_targets else torch.zeros_like(pred_local)
+                gt_local = self._cat_targets(gt_targets, matrix=True).to(pred_local.device) if gt_targets else torch.zeros_like(pred_local)
                 result = self._sharded_ap(pred_local, gt_local, world, rank)
                 if rank == 0 and self.cfg["eval"] is not None:
                     os.makedirs(self.output_dir, exist_ok=True)
@@ -418,7 +471,7 @@ class Evaluate(nn.Module):
                 return result["mean_AP"]
             if finish_ap is None:
                 pred_all = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)))
-                gt_all = torch.cat(gt_targets, 0).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
+                gt_all = self._cat_targets(gt_targets, matrix=True).to(pred_all.device) if gt_targets else torch.zeros_like(pred_all)
                 if torch.device(device).type == "cuda" and self.metric == "AP":        # an empty eval set: the empty report
                     finish_ap = perframe_average_precision_device(pred_all.to(device), gt_all.to(device), self.all_class_names,
                                                                   self.data_processing, self.metric, defer=True)

@@ -7,9 +7,10 @@ reference always treats as background (metrics.py:44-48).  Two routes to the sam
 
   * `perframe_average_precision`         - numpy on the host, all classes at once (one argsort of the score matrix); the CPU
                                            tests hold it to sklearn.
-  * `perframe_average_precision_device`  - the HIP path: `prego_perframe_ap` (csrc/metrics.hip: segmented radix sort + scan, one
-                                           segment per class), used by `Evaluate` so that the [frames x classes] score matrix of
-                                           an eval pass never leaves the device.  No CPU fallback.
+  * `perframe_average_precision_device`  - the HIP path: `prego_perframe_ap` / `prego_perframe_ap_labels` (csrc/metrics.hip: the
+                                           positives of every class sorted, every score counted against them), used by `Evaluate`
+                                           so that the [frames x classes] score matrix of an eval pass never leaves the device.
+                                           No CPU fallback.
 
 `metric: 'cAP'` (the reference's calibrated variant for TVSeries, metrics.py:10-22; unreachable from the shipped configs) runs on the
 host path only; `Evaluate` moves the matrices to the host for it."""
@@ -106,14 +107,15 @@ def perframe_average_precision(prediction, ground_truth, class_names, postproces
 
 
 def perframe_ap_raw_device(pred, truth):
-    """device counterpart of perframe_ap_raw (metric 'AP'): fp32 CUDA matrices [frames, classes] -> three host vectors"""
+    """device counterpart of perframe_ap_raw (metric 'AP'): fp32 CUDA matrices [frames, classes] (truth: or class ids [frames]) -> three host vectors"""
     ncls = int(pred.shape[1])
     fin = perframe_average_precision_device(pred, truth, [str(i) for i in range(ncls)], None, "AP", defer=True, raw=True)
     return fin()
 
 
 def perframe_average_precision_device(prediction, ground_truth, class_names, postprocessing=None, metrics="AP", defer=False, raw=False):
-    """Device path: prediction / ground_truth fp32 CUDA tensors [frames, classes]; the sort and the scan run in
+    """Device path: prediction / ground_truth fp32 CUDA tensors [frames, classes] - or ground_truth = an integer CUDA tensor [frames],
+    one class id per frame (what one-hot targets say; an id outside the classes = no positive) -; the sort and the scan run in
     libprego_amd.so (`prego_perframe_ap`), one small device -> host transfer brings back AP, positives and score mass.
     defer=True: the kernels are only ENQUEUED and a function is returned that waits for them and builds the report (Evaluate writes
     its output file while the GPU sorts)."""
@@ -129,8 +131,9 @@ def perframe_average_precision_device(prediction, ground_truth, class_names, pos
         raise PregoError("perframe_average_precision_device needs CUDA tensors; there is no CPU fallback "
                          "(host arrays: perframe_average_precision)")
     pred = prediction.detach().to(torch.float32).contiguous()
-    truth = ground_truth.detach().to(torch.float32).contiguous()
-    if pred.dim() != 2 or pred.shape != truth.shape or pred.shape[1] != len(class_names):
+    by_label = ground_truth.dim() == 1 and not ground_truth.dtype.is_floating_point      # one class id per frame (prego_perframe_ap_labels)
+    truth = ground_truth.detach().to(torch.int32 if by_label else torch.float32).contiguous()
+    if pred.dim() != 2 or pred.shape[1] != len(class_names) or (truth.shape != pred.shape[:1] if by_label else truth.shape != pred.shape):
         raise PregoError(f"perframe_average_precision_device: shapes {tuple(pred.shape)} / {tuple(truth.shape)} for {len(class_names)} classes")
     n, ncls = pred.shape
     if n == 0:                                          # an empty eval set: same empty report as the host path
@@ -142,9 +145,10 @@ def perframe_average_precision_device(prediction, ground_truth, class_names, pos
     ws = torch.empty(lib.prego_perframe_ap_workspace_bytes(n, ncls), dtype=torch.uint8, device=dev)
     out = torch.empty((3, ncls), dtype=torch.float64, device=dev)          # AP | positives (int64 bits) | score sums
     with torch.cuda.device(dev):
-        check(lib.prego_perframe_ap(C.c_void_p(pred.data_ptr()), C.c_void_p(truth.data_ptr()), n, ncls, C.c_void_p(out[0].data_ptr()),
-                                    C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
-                                    C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        fn = lib.prego_perframe_ap_labels if by_label else lib.prego_perframe_ap
+        check(fn(C.c_void_p(pred.data_ptr()), C.c_void_p(truth.data_ptr()), n, ncls, C.c_void_p(out[0].data_ptr()),
+                 C.c_void_p(out[1].data_ptr()), C.c_void_p(out[2].data_ptr()), C.c_void_p(ws.data_ptr()), ws.numel(),
+                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     def finish(_keep=(pred, truth, ws)):
         host = out.cpu().numpy()
         if raw:

@@ -107,6 +107,61 @@ def test_link_fed_eval_equals_the_copy_then_forward_eval(tmp_path, dtype, with_f
     assert all(len(res[True][1][f"v{i}"]["pred"]) == T for i, T in enumerate(lens))
 
 
+def test_one_hot_targets_travel_as_class_ids(tmp_path):
+    """The loader's one-hot target rows are reduced to one class id per frame on the host (prego_onehot_labels) and the metric takes the
+    ids (prego_perframe_ap_labels): output file and mAP bit for bit those of the matrix path (cfg eval_label_targets = False) - also when
+    one video is NOT one-hot (two positives in some rows, an all-zero row: that video's rows travel as they are and the whole set is
+    scored through the matrix entry point)."""
+    from prego_amd.registry import build_model, build_eval
+    import prego_amd.model, prego_amd.evaluate  # noqa: F401
+    vl = os.path.join(tmp_path, "video_list.json")
+    json.dump({"EPIC-TENT-O": {"class_index": [f"c{i}" for i in range(12)]}}, open(vl, "w"))
+    lens = [900, 1, 2500, 333, 64]
+    for multi in (False, True):
+        items = []
+        for i, T in enumerate(lens):
+            rgb = torch.from_numpy(W.tsn_features((T, 2048), 21, f"oh.rgb.{i}"))[None].pin_memory()
+            tgt = torch.zeros(1, T, 12)
+            tgt[0, torch.arange(T), (torch.arange(T) // 41 + i) % 12] = 1
+            if multi and i == 2:
+                tgt[0, 100:200, 7] = 1                                   # a second positive
+                tgt[0, 300] = 0                                          # a row without any
+            items.append((rgb, torch.zeros(1, 1, 2048).expand(1, T, 2048), tgt.pin_memory(), (f"v{i}",), torch.tensor([0]), torch.tensor([T])))
+        res = {}
+        for by_id in (True, False):
+            out_dir = tmp_path / f"out_{int(multi)}_{int(by_id)}"
+            cfg = epic_tent_cfg(eval="dummy.pth", video_list_path=vl, compute_dtype="fp16", eval_output_dir=str(out_dir), eval_label_targets=by_id)
+            model = build_model(cfg, "cuda:0")
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in W.miniroad_state_dict(cfg, 20, head_gain=8.0).items()})
+            ev = build_eval(cfg)
+            seen = []
+            orig = ev._cat_targets
+            ev._cat_targets = lambda ts, matrix=False: (seen.append([t.dim() for t in ts]), orig(ts, matrix))[1]
+            mAP = ev(model, items, logging.getLogger("t"), "cuda:0")
+            assert seen and seen[0] == ([1 if (by_id and not (multi and i == 2)) else 2 for i in range(len(lens))])
+            res[by_id] = (mAP, json.load(open(out_dir / "output_miniROAD.json")))
+        assert res[True][1] == res[False][1]
+        assert res[True][0] == res[False][0]
+        gt2 = np.argmax(items[2][2][0].numpy(), 1)
+        assert res[True][1]["v2"]["gt"] == gt2.tolist()
+
+
+def test_device_average_precision_by_class_id_equals_the_matrix_entry():
+    from prego_amd.metrics import perframe_average_precision_device
+    rng = np.random.default_rng(5)
+    n, C = 70_000, 23
+    pr = torch.from_numpy(np.round(rng.random((n, C)), 3).astype(np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, C + 2, n).astype(np.int32)).cuda()          # ids C, C + 1: frames without a positive
+    gt = torch.zeros(n, C, device="cuda")
+    ok = lab < C
+    gt[torch.arange(n, device="cuda")[ok], lab[ok].long()] = 1
+    names = [f"c{i}" for i in range(C)]
+    a = perframe_average_precision_device(pr, gt, names, raw=True)
+    b = perframe_average_precision_device(pr, lab, names, raw=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+
+
 @pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86)])
 def test_device_average_precision_kernel_vs_sklearn(n, C):
     """prego_perframe_ap (csrc/metrics.hip: the positives of every class sorted, every score counted against them) against sklearn's

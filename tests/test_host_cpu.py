@@ -326,3 +326,37 @@ def test_build_provenance_record_matches_the_tree():
     info = B.build_info()
     assert info["sources_match_tree"] is True and info["arch"] == "gfx950" and info["build_mode"] in (
         "built on this host", "prebuilt elsewhere, shipped with the tree")
+
+
+def test_onehot_labels_host_reducer():
+    """prego_onehot_labels (a HOST function of the library, no device work): np.argmax of every target row, and per video whether the
+    ids say everything the rows do (exactly one nonzero entry per row, positive)."""
+    import ctypes as C
+    import numpy as np
+    from prego_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    ncls = 86
+    vids = []
+    for T in (1, 0, 40_000, 777):
+        t = np.zeros((T, ncls), np.float32)
+        t[np.arange(T), rng.integers(0, ncls, T)] = 1
+        vids.append(t)
+    soft = rng.random((500, ncls)).astype(np.float32)                     # not one-hot: plain argmax
+    neg = np.zeros((300, ncls), np.float32); neg[np.arange(300), 5] = -1   # one nonzero per row, but negative: argmax is column 0
+    two = vids[2][:1000].copy(); two[17, 3] = 1; two[17, 9] = 1
+    zero = vids[2][:1000].copy(); zero[400] = 0
+    vids += [soft, neg, two, zero]
+    nv = len(vids)
+    ptrs = (C.c_void_p * nv)(*[v.ctypes.data for v in vids])
+    rows = (C.c_int64 * nv)(*[v.shape[0] for v in vids])
+    total = sum(v.shape[0] for v in vids)
+    labels = np.full(total, -7, np.int32)
+    flags = (C.c_int32 * nv)()
+    assert lib.prego_onehot_labels(nv, ptrs, rows, ncls, C.c_void_p(labels.ctypes.data), flags) == 0
+    assert list(flags) == [1, 1, 1, 1, 0, 0, 0, 0]
+    o = 0
+    for v in vids:
+        assert np.array_equal(labels[o:o + v.shape[0]], np.argmax(v, 1).astype(np.int32) if v.shape[0] else np.zeros(0, np.int32))
+        o += v.shape[0]
+    assert lib.prego_onehot_labels(1, None, rows, ncls, C.c_void_p(labels.ctypes.data), flags) != 0
