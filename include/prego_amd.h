@@ -34,9 +34,11 @@ extern "C" {
  * 4: round 4 (PREGO_F16X2 split-operand mode; the prego_debug_* / _debug_stamps entry points left this header and the product library:
  *    prego_amd_debug.h / libprego_amd_debug.so).
  * 5: round 4, later (prego_miniroad_pass_info; the split pass behind prego_miniroad_forward).
- * 6: round 5 (no new entry point; behaviour: a forward() that runs the split pass returns once its two launches have met - see
- *    prego_miniroad_forward -, a pass that cannot run side by side is re-run chunked inside the same call instead of being reported as
- *    PREGO_ETIMEOUT by prego_miniroad_check; tuning environment knobs are read by the debug library only). */
+ * 6: round 5.  Behaviour: a forward() that runs the split pass returns once its two launches have met - see prego_miniroad_forward -,
+ *    a pass that cannot run side by side is re-run chunked inside the same call instead of being reported as PREGO_ETIMEOUT by
+ *    prego_miniroad_check; tuning environment knobs are read by the debug library only.  Added (existing signatures unchanged):
+ *    prego_miniroad_create_layers / _set_gru_layer (num_layers 2), prego_oad_loss_reduce (reduction 'sum'),
+ *    prego_attention_layer_set_dropout, prego_perframe_ap_labels, prego_onehot_labels (host), prego_format_ids. */
 #define PREGO_ABI_VERSION 6
 
 enum {

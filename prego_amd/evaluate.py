@@ -108,7 +108,7 @@ class Evaluate(nn.Module):
         out = [None] * len(targets)
         host = [i for i, t in enumerate(targets) if t.device.type == "cpu" and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
                 and t.shape[1] == len(self.all_class_names)]
-        if dev.type == "cuda" and host and self.cfg.get("eval_label_targets", True):
+        if host and self.cfg.get("eval_label_targets", True):
             import ctypes as C
             from . import _lib
             from ._lib import check
@@ -116,7 +116,7 @@ class Evaluate(nn.Module):
             ptrs = (C.c_void_p * nv)(*[targets[i].data_ptr() for i in host])
             rows = (C.c_int64 * nv)(*[int(targets[i].shape[0]) for i in host])
             total = sum(int(targets[i].shape[0]) for i in host)
-            labels = torch.empty(max(total, 1), dtype=torch.int32, pin_memory=True)
+            labels = torch.empty(max(total, 1), dtype=torch.int32, pin_memory=dev.type == "cuda")
             flags = (C.c_int32 * nv)()
             check(_lib.load().prego_onehot_labels(nv, ptrs, rows, len(self.all_class_names), C.c_void_p(labels.data_ptr()), flags))
             labels_dev = labels.to(dev, non_blocking=True)
@@ -164,7 +164,7 @@ class Evaluate(nn.Module):
         else:
             rgb = [b[0].to(device) for b in sub]
             flow = None if flows is None else [None if f is None else f.to(device) for f in flows]
-            tgt = [b[2].to(device) for b in sub]
+            tgt = self._targets_to_device([b[2] for b in sub], dev)
         probs, args, _ = model.forward_clips(rgb, flow, want_probs=True, want_argmax=True)
         return probs, args, tgt
 
@@ -455,7 +455,7 @@ class Evaluate(nn.Module):
                         entries += [(p_idx, vid, ent) for (p_idx, _n), (vid, ent) in zip(pv, out.items())]
                     output = {vid: ent for _p, vid, ent in sorted(entries, key=lambda e: e[0])}
                 pred_local = torch.cat(pred_scores, 0) if pred_scores else torch.zeros((0, len(self.all_class_names)), device=device)
-                gt_local = self._cat_targets(gt_targets, matrix=True).to(pred_local.device) if gt_targets else torch.zeros_like(pred_local)
+                gt_local = self._cat_targets(gt_targets).to(pred_local.device) if gt_targets else torch.zeros_like(pred_local)
                 result = self._sharded_ap(pred_local, gt_local, world, rank)
                 if rank == 0 and self.cfg["eval"] is not None:
                     os.makedirs(self.output_dir, exist_ok=True)
@@ -518,7 +518,25 @@ class Evaluate(nn.Module):
             dist.all_to_all_single(recv, send, output_split_sizes=[n * mine for n in ns],
                                    input_split_sizes=[int(m.shape[0]) * (cb[q + 1] - cb[q]) for q in range(world)])
             return recv.reshape(sum(ns), mine) if mine else recv.reshape(sum(ns), 0)
-        p_cols, g_cols = exchange(pred), exchange(gt)
+        p_cols = exchange(pred)
+        by_id = torch.tensor([int(gt.dim() == 1)], dtype=torch.int64, device=pred.device)
+        dist.all_reduce(by_id, op=dist.ReduceOp.MIN)                 # class ids only if EVERY rank holds ids (a rank without videos: a matrix of no rows)
+        if int(by_id.item()):
+            # one-hot ground truth held as one class id per frame (_targets_to_device): every rank gets every frame's id (4 bytes per
+            # frame, padded to the longest rank) instead of its columns of the target matrix; an id outside my columns = no positive there
+            width_n = max(ns) if ns else 0
+            buf = torch.full((max(width_n, 1),), -1, dtype=torch.int32, device=pred.device)
+            buf[:gt.shape[0]] = gt.to(torch.int32)
+            bufs = [torch.empty_like(buf) for _ in range(world)]
+            dist.all_gather(bufs, buf)
+            ids = torch.cat([bufs[q][:ns[q]] for q in range(world)]) - cb[rank]
+            g_cols = ids
+            if not (p_cols.is_cuda and self.metric == "AP"):
+                g_cols = torch.zeros((sum(ns), mine), dtype=torch.float32, device=pred.device)
+                ok = (ids >= 0) & (ids < mine)
+                g_cols[torch.arange(sum(ns), device=pred.device)[ok], ids[ok].long()] = 1
+        else:
+            g_cols = exchange(self._gt_matrix(gt))
         if mine == 0:
             raw = (np.zeros(0), np.zeros(0, np.int64), np.zeros(0))
         elif p_cols.is_cuda and self.metric == "AP":
