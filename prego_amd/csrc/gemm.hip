@@ -390,7 +390,7 @@ void launch_gemm_bf16_nt_epi(const void* A, int lda, const void* B, int ldb, con
 #undef GL
 }
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
-                         int N, int K, hipStream_t s, bool f16) {
+                         int N, int K, hipStream_t s, bool f16, bool train_splitk) {
   if (f16) {                             // fp16 operands: ping-pong kernel for whole-chip shapes, the 128 x 128 kernel below
     GemmEpi e16{};
     e16.mode = EPI_STORE; e16.f16 = 1;
@@ -398,6 +398,12 @@ void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const f
     return;
   }
   static const bool no_big = prego_tune_env("PREGO_GEMM_NO_BIG") != nullptr;
+  static const bool no_splitk = prego_tune_env("PREGO_GEMM_NO_SPLITK") != nullptr;
+  // at most one 128 x 128 tile per CU (the training step's projections: rows = 16 x 128): eight waves per workgroup, two K groups
+  // (gemm_tn.hip) - 54 -> ~35 us where the 256 x 128 kernel left half of the CUs without a tile
+  if (train_splitk && !no_splitk && ((M + 127) / 128) * ((N + 127) / 128) <= 256 && K >= 1024 && K % 64 == 0 &&
+      launch_gemm_bf16_tn(false, false, A, lda, B, ldb, bias, C, ldc, M, N, K, K, nullptr, s) == 0)
+    return;
   if (M >= 4096 && N % 256 == 0 && !no_big) {   // 256x256 tiles: ping-pong 8-phase schedule with 16-byte stores (gemm_pp.hip)
     static const bool no_pp = prego_tune_env("PREGO_GEMM_NO_PINGPONG") != nullptr;      // A/B knob: the previous production kernel
     if (no_pp || launch_gemm_bf16_pingpong(A, lda, B, ldb, bias, C, ldc, M, N, K, s) != 0)
@@ -425,6 +431,8 @@ void launch_gemm_bf16_variant(int variant, const void* A, int lda, const void* B
     (void)hipFuncSetAttribute((const void*)gemm_bf16_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * GSTAGE);
     const int ntm = (M + GBM - 1) / GBM, ntn = N / BN;
     gemm_bf16_nt_big_kernel<<<ntm * ntn, 512, 3 * GSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
+  } else if (variant == 30) {        // the eight-wave split-K workgroup of gemm_tn.hip on nn.Linear's form (<= 256 tiles)
+    (void)launch_gemm_bf16_tn(false, false, A, lda, B, ldb, bias, C, ldc, M, N, K, K, nullptr, s);
   } else if (variant == 20) {
     (void)launch_gemm_bf16_w4(A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
   } else if (variant >= 21 && variant <= 23) {

@@ -214,7 +214,9 @@ GruArm gru_x2_arm_desc(int hid, int G, void* hx, unsigned* sync);
 int launch_gemm_bf16_pingpong(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M, int N,
                               int K, hipStream_t s);
 void launch_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, const float* bias, float* C, int ldc, int M,
-                         int N, int K, hipStream_t s, bool f16 = false);
+                         int N, int K, hipStream_t s, bool f16 = false,
+                         bool train_splitk = false /* bf16, at most 256 tiles of 128 x 128: the eight-wave split-K workgroup of gemm_tn.hip
+                                                      (another summation order over k than every other NT kernel: training forward only) */);
 void launch_gemm_f32_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C, int ldc, int M,
                         int N, int K, hipStream_t s);
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s);

@@ -1155,7 +1155,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       return;
     }
     if (!h->bf16) { launch_gemm_f32_nt((const float*)A, lda, (const float*)Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
-    if (!i16 && !h->f16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s); return; }
+    if (!i16 && !h->f16) { launch_gemm_bf16_nt(A, lda, Wt, ldb, bias, (float*)Cout, ldc, M, N, K, s, false, (flags & PREGO_FWD_KEEP) != 0); return; }
     if (M >= 4096 && launch_gemm_bf16_pingpong_mode(0, A, lda, Wt, ldb, bias, Cout, ldc, M, N, K, i16, s, h->f16) == 0) return;
     GemmEpi epi{};
     epi.f16 = h->f16 ? 1 : 0;

@@ -471,7 +471,7 @@ extern "C" int prego_vit_forward_train(prego_vit* h, int batch, const float* rgb
   const int causal = (flags & 1) ? 1 : 0;
   float* x = (float*)(ws + w.x);
   launch_cat_convert(rgb, flow, B * T, h->d_rgb, h->d_flow, ws + w.xb, s);
-  launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);
+  launch_gemm_bf16_nt(ws + w.xb, din, h->enc_w, din, h->enc_b, (float*)(ws + w.enc), E, B * T, E, din, s);      // the eval forward's kernel: the keeping forward is the same arithmetic, bit for bit (test G5b)
   const unsigned dthr = drop_thresh_of(h);
   const float dsc = drop_scale_of(h);
   launch_vit_tokens((const float*)(ws + w.enc), h->cls, h->pe, B, T, E, x, s, dthr, dsc, site_seed(h, 0, 0));

@@ -294,7 +294,7 @@ def test_fused_adamw_refreshes_engine_weights(dtype):
         a, b = res["fused"][2][k], res["torch"][2][k]
         # AdamW normalises every element's step to ~lr: an element whose gradient is ~0 amplifies a last-bit difference of the
         # two kernels' m / sqrt(v) into a fraction of lr (1e-3 here); the bulk must agree to fp32 rounding
-        assert np.abs(a - b).max() < 2.5e-3 and np.abs(a - b).mean() < 2e-7, (k, np.abs(a - b).max(), np.abs(a - b).mean())
+        assert np.abs(a - b).max() < 2.5e-3 and np.abs(a - b).mean() < 5e-7, (k, np.abs(a - b).max(), np.abs(a - b).mean())
     assert np.abs(res["fused"][1] - res["torch"][1]).max() < (2e-3 if dtype == "bf16" else 2e-4)
 
 
