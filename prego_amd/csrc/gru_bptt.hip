@@ -9,10 +9,17 @@
 // Decomposition = the forward kernel's: G groups x P workgroups, a workgroup owns 16*UT output units j (columns of dh) and
 // holds its slice of W_hh^T ([j][3H], K = 3H = 3072) as MFMA A-fragments in VGPRs, wave q the K-quarter q (192 VGPRs).
 // Per step a workgroup needs the whole dGH_{t+1} of its group's clips (3 x the forward's h): an all-gather through a
-// double-buffered exchange buffer in fragment-major layout.  Gradients are not bounded, so the forward's tag-in-the-data
-// validity trick does not apply: the hand-off is one EPOCH WORD per producer workgroup.  Producers drain their publish
-// stores (s_waitcnt vmcnt(0)) and then store their epoch; a consumer's wave 0 polls the group's P epoch words with one load
-// instruction (one lane per producer) and then everybody gathers.  (An atomic step counter polled by one lane cost 4 us.)  As in the forward kernel the
+// FIVE-buffered exchange buffer in fragment-major layout.  Gradients are not bounded, so the forward's tag-bit-in-the-data validity
+// trick does not apply as it stands; since round 5 the data still IS its own flag: a word of all ones (a bf16 pair / an fp32 value no
+// publish ever writes: such a NaN is stored with its lowest bit cleared) means "not yet published".  A consumer re-loads its
+// fragments until no live word is all ones; a producer, at the TOP of step t, resets what it published at step t+3 (buffer
+// (t+3) % 5, which it will write again at step t-2).  Why five buffers and three steps: (WAR) at the top of its step t a workgroup
+// has gathered everyone's step t+2 data, so everyone has finished the gate math of step t+2 and with it the gather of step t+3 -
+// nobody reads that buffer's old contents any more; (RAW) a consumer polls for step t-2 data once it has finished step t-2, which
+// took everyone's step t-1 data, and a workgroup's step t-1 (and step t) publish was issued after its step-t reset had been
+// acknowledged (the wave waited for loads it issued behind the reset stores: vmcnt retires in order) - so stale step t+3 data can
+// never be taken for step t-2 data.  (Rounds 3-4: one EPOCH WORD per producer behind a drain of the publish stores + a barrier, and
+// a poll of the group's epoch words before the gather - two more dependent L2 round trips per step: 3.05 us per step, now 2.2.)  As in the forward kernel the
 // launch first VERIFIES placement (every workgroup of a group reports its XCC id): a group that sits on one XCD hands off
 // with plain stores + L1-bypassing nt loads through that XCD's L2, any other placement with sc1 stores + sc1 loads (the
 // agent-scope release/acquire FENCES this replaced wrote back and invalidated the whole L2 every step: 30 us per step).
@@ -24,6 +31,7 @@
 
 #define BPTT_SPIN_LIMIT (1u << 22)
 #define BPTT_MAX_TILES 4
+#define BPTT_BUFS 5            // exchange buffers (header comment)
 
 template <typename WT, int HID, int UT, int NCT>
 __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
@@ -105,10 +113,12 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
   }
   const int buf_stride = a.G * GROUP_BYTES;
   char* hx_base = (char*)a.hx + (size_t)g * GROUP_BYTES;
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hx_base, 0, buf_stride + GROUP_BYTES, 0x00020000);
-  // epoch words of the group's workgroups: a.sync[64 + g*64 + w]
-  __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc((void*)(a.sync + 64 + g * 64), 0, 64 * 4, 0x00020000);
-  unsigned arrived = 0;                       // publishes this workgroup has announced
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)hx_base, 0, (BPTT_BUFS - 1) * buf_stride + GROUP_BYTES, 0x00020000);
+  // byte offset of my element (clip l15 of tile ct, k = gate * H + my unit) inside a buffer
+  auto elem_off = [&](int ct, int gate) -> int {
+    const int k = gate * HID + ucol;
+    return ((k / KF) * BPTT_MAX_TILES + ct) * 1024 + ((((k % KF) / EPL) << 4) + l15) * 16 + (k % EPL) * (int)sizeof(WT);
+  };
 
   // plan tables through the scalar path (constant address space), one step ahead: vector loads here put a vmcnt(0) and an
   // L2 round trip at the top of every step
@@ -126,8 +136,24 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
     const int t2 = t >= 2 ? t - 2 : 0;
     const int na_2 = nact_c[t2], ro_2 = rowoff_c[t2];                       // look-ahead for step t-2
     na_prev = na_cur; na_cur = na_nx; ro_cur = ro_nx; na_nx = na_2; ro_nx = ro_2;
-    const int rbuf = (t + 1) & 1;             // where step t+1 published
     if (tfirst[0] >= na) continue;            // nothing of this group alive yet (clips are sorted longest first)
+    const int pbuf = t % BPTT_BUFS;           // where this step publishes
+    const int rbuf = (t + 1) % BPTT_BUFS;     // where step t+1 published
+    // ---- reset what I published at step t+3 (header comment): FIRST in the step, so that waiting for any later load of this wave
+    // proves these stores acknowledged before this step's publish is issued
+    if (t + 3 < a.t_max) {
+      const int zbuf = (t + 3) % BPTT_BUFS;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        if (sidx[ct] < na) {
+#pragma unroll
+          for (int gate = 0; gate < 3; ++gate) {
+            if (local) __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rs, zbuf * buf_stride + elem_off(ct, gate), 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(0xFFFFFFFFu, rs, zbuf * buf_stride + elem_off(ct, gate), 0, AUX_SC1);
+          }
+        }
+      }
+    }
 
     // ---- this step's inputs (HBM) go out BEFORE the wait for the other workgroups: their latency runs under the spin,
     // the gather and the MFMAs instead of in front of the gate math
@@ -143,27 +169,6 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
         in_n[ct][e] = a.N[eo + e]; in_g[ct][e] = a.GHN[eo + e]; in_hp[ct][e] = a.Hraw[ep + e];
       }
     }
-    // ---- wait until every workgroup of the group has published step t+1: wave 0 polls the group's P epoch words (one per
-    // producer workgroup, one lane each, ONE load instruction per poll) through the same path as the data
-    const bool need = tfirst[0] < na_next;
-    if (need) {
-      if (q == 0) {
-        unsigned spins = 0;
-        for (;;) {
-          unsigned ep = 0xFFFFFFFFu;
-          if (lane < P) {
-            const int foff = lane * 4;
-            ep = local ? __builtin_amdgcn_raw_buffer_load_b32(rs_f, foff, 0, AUX_NT) : __builtin_amdgcn_raw_buffer_load_b32(rs_f, foff, 0, AUX_SC1);
-          }
-          if (__all(ep >= arrived)) break;
-          if (++spins > BPTT_SPIN_LIMIT) { if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-          if ((spins & 255u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        }
-      }
-      __syncthreads();
-      if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    }
-
     float dpr[NCT][OWN_R], dpz[NCT][OWN_R], dpn[NCT][OWN_R], dpnr[NCT][OWN_R];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
@@ -180,14 +185,31 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
         // a lane's 16 bytes belong to ONE clip column (lane & 15): columns that were not alive at step t+1 published nothing
         // and are not fetched (an offset past num_records returns zeros without a memory access)
         const int lane_off = sidx[ct] < na_next ? lane * 16 : 0x7FFF0000;
-        if (local) {
+        // the data is its own flag: (re)load ALL of the wave's fragments until no live word is all ones (a round = one L2 round trip
+        // with every fragment in flight; no per-fragment bookkeeping - the forward kernel's lesson)
+        const bool col_live = sidx[ct] < na_next;
+        unsigned spins = 0;
+        for (;;) {
+          if (local) {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_NT);
-        } else {
+            for (int ks = 0; ks < NKS; ++ks)
+              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_NT);
+          } else {
 #pragma unroll
-          for (int ks = 0; ks < NKS; ++ks)
-            hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_SC1);
+            for (int ks = 0; ks < NKS; ++ks)
+              hb[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs, rbuf * buf_stride + ((q * NKS + ks) * BPTT_MAX_TILES + ct) * 1024 + lane_off, 0, AUX_SC1);
+          }
+          unsigned mx = 0u;
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned m01 = hb[ks][0] > hb[ks][1] ? hb[ks][0] : hb[ks][1];
+            const unsigned m23 = hb[ks][2] > hb[ks][3] ? hb[ks][2] : hb[ks][3];
+            const unsigned m = m01 > m23 ? m01 : m23;
+            mx = mx > m ? mx : m;
+          }
+          if (__all(!col_live || mx != 0xFFFFFFFFu)) break;
+          if (++spins > BPTT_SPIN_LIMIT / 64) { if (lane == 0) __hip_atomic_store(a.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          if ((spins & 63u) == 0u && __hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
 #pragma unroll
         for (int ut = 0; ut < UT; ++ut) redw[(q * UT + ut) * 64 + lane] = acc[ut];
         __syncthreads();
+        if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // a gather gave up (here or elsewhere)
 #pragma unroll
         for (int e = 0; e < OWN_R; ++e) {
           float p[4];
@@ -240,9 +263,7 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
         if (t > 0) {
 #pragma unroll
           for (int gate = 0; gate < 3; ++gate) {
-            const int k = gate * HID + ucol;
-            const int off = (t & 1) * buf_stride + ((k / KF) * BPTT_MAX_TILES + ct) * 1024 + ((((k % KF) / EPL) << 4) + l15) * 16 +
-                            (k % EPL) * (int)sizeof(WT);
+            const int off = pbuf * buf_stride + elem_off(ct, gate);
             const float v0 = gate == 0 ? dpr[ct][0] : (gate == 1 ? dpz[ct][0] : dpnr[ct][0]);
             unsigned pv;
             if constexpr (BF) {
@@ -251,24 +272,14 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
             } else {
               pv = __float_as_uint(v0);
             }
+            if (pv == 0xFFFFFFFFu) pv = 0xFFFFFFFEu;                  // all ones means "not yet published": such a NaN travels with its lowest bit cleared
             if (local) __builtin_amdgcn_raw_buffer_store_b32(pv, rs, off, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b32(pv, rs, off, 0, AUX_SC1);
           }
         }
       }
     }
-    // ---- announce this step's publish: only the publish stores (and older loads) are outstanding here, so the drain is short;
-    // one counter increment per workgroup
-    if (t > 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's publish stores have reached the L2 (local) / memory (sc1)
-      __syncthreads();
-      ++arrived;
-      if (tid == 0) {                                             // my epoch word: "this workgroup has published `arrived` steps"
-        if (local) __builtin_amdgcn_raw_buffer_store_b32(arrived, rs_f, w * 4, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(arrived, rs_f, w * 4, 0, AUX_SC1);
-      }
-    }
-    // ---- the step's results for the weight-gradient GEMMs, fire and forget (behind the hand-off, not in front of it) ------------
+    // ---- the step's results for the weight-gradient GEMMs, fire and forget (behind the publish, not in front of it) -------------
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       if (tfirst[ct] < na && sidx[ct] < na) {
@@ -290,14 +301,15 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
   }
 }
 
-size_t gru_bptt_hx_bytes(bool bf16, int hid, int G) { return (size_t)2 * G * (3 * hid / (bf16 ? 32 : 16)) * BPTT_MAX_TILES * 1024; }
+size_t gru_bptt_hx_bytes(bool bf16, int hid, int G) { return (size_t)BPTT_BUFS * G * (3 * hid / (bf16 ? 32 : 16)) * BPTT_MAX_TILES * 1024; }
 
 // returns 0 on success, -1 for an unsupported shape (the caller falls back to the step-by-step loop)
 int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
   if (hid != 1024 || nct > BPTT_MAX_TILES) return -1;
   const int P = bf16 ? 32 : 64;
   const int grid = a.G * P;
-  (void)hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), s);      // [0,64): placement words; [64 + 64 g + w]: epoch words
+  (void)hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), s);      // [0,64): placement words
+  (void)hipMemsetAsync(a.hx, 0xFF, gru_bptt_hx_bytes(bf16, hid, a.G), s);      // every word "not yet published"
 #define LAUNCHB(WT, UT, NCT)                                                                       \
   do {                                                                                             \
     const size_t lds = (size_t)2 * 4 * UT * 64 * 16;                                               \
