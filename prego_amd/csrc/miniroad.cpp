@@ -1615,17 +1615,19 @@ extern "C" int prego_oad_loss_reduce(int n_clips, const int32_t* lens, const flo
   void** d = (void**)sc.dev;
   hipStream_t s = (hipStream_t)stream;
   const void** tab = (const void**)sc.pin;
+  // the four tables packed one behind the other (n_clips entries each): ONE host -> device copy per call (four copies of 128 bytes
+  // were four 5 us blit launches in front of the loss kernel of every training step)
+  const size_t n = (size_t)n_clips;
   for (int i = 0; i < n_clips; ++i) {
     if (lens[i] <= 0 || !logits[i] || !target[i]) return fail(PREGO_EINVAL, "loss: clip %d", i);
-    tab[0 * MC + i] = logits[i]; tab[1 * MC + i] = target[i]; tab[2 * MC + i] = dlogits ? dlogits[i] : nullptr;
+    tab[0 * n + i] = logits[i]; tab[1 * n + i] = target[i]; tab[2 * n + i] = dlogits ? dlogits[i] : nullptr;
   }
-  std::memcpy(&tab[3 * MC], lens, (size_t)n_clips * 4);        // 4th table doubles as the lens array
-  for (int k = 0; k < 4; ++k)                                  // only the used prefix of each table travels
-    HIPCHK(hipMemcpyAsync(d + k * MC, tab + k * MC, (size_t)n_clips * sizeof(void*), hipMemcpyHostToDevice, s));
+  std::memcpy(&tab[3 * n], lens, n * 4);                       // 4th table doubles as the lens array
+  HIPCHK(hipMemcpyAsync(d, tab, 4 * n * sizeof(void*), hipMemcpyHostToDevice, s));
   HIPCHK(hipEventRecord(sc.ev, s));
   sc.busy = true;
-  launch_oad_loss((const float* const*)d, (const float* const*)(d + MC), (const int*)(d + 3 * MC), n_clips, n_classes,
-                  loss_out, dlogits ? (float* const*)(d + 2 * MC) : nullptr, grad_scale, s, reduction == 1);
+  launch_oad_loss((const float* const*)d, (const float* const*)(d + n), (const int*)(d + 3 * n), n_clips, n_classes,
+                  loss_out, dlogits ? (float* const*)(d + 2 * n) : nullptr, grad_scale, s, reduction == 1);
   HIPCHK(hipGetLastError());
   return PREGO_OK;
 }
