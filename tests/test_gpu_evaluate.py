@@ -235,3 +235,26 @@ def test_evaluate_runs_the_transformer_entry_per_frame(tmp_path):
         gts.append(item[2][0].numpy())
     want = perframe_average_precision(np.concatenate(scores), np.concatenate(gts), [f"c{i}" for i in range(12)])["mean_AP"]
     assert abs(mAP - want) < 1e-12
+
+
+def test_format_ids_text_is_the_json_of_the_ids():
+    """prego_format_ids: four bytes "%3d," per id in memory order; ids outside 0..999 set the flag (the caller then formats on the host)"""
+    import ctypes as C
+    from prego_amd import _lib
+    lib = _lib.load()
+    ids = torch.tensor([0, 7, 10, 85, 99, 100, 101, 999, 512, 3], dtype=torch.int32, device="cuda")
+    text = torch.empty(ids.numel(), dtype=torch.int32, device="cuda")
+    bad = torch.zeros(1, dtype=torch.int32, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.prego_format_ids(C.c_void_p(ids.data_ptr()), ids.numel(), C.c_void_p(text.data_ptr()), C.c_void_p(bad.data_ptr()), s) == 0
+    raw = text.cpu().numpy().tobytes()
+    assert raw == b"".join(b"%3d," % int(v) for v in ids.tolist()) and int(bad.item()) == 0
+    assert json.loads(b"[" + raw[:-1] + b"]") == ids.tolist()
+    ids[4] = 1000
+    assert lib.prego_format_ids(C.c_void_p(ids.data_ptr()), ids.numel(), C.c_void_p(text.data_ptr()), C.c_void_p(bad.data_ptr()), s) == 0
+    assert int(bad.item()) == 1
+    ids[4] = -1
+    bad.zero_()
+    assert lib.prego_format_ids(C.c_void_p(ids.data_ptr()), ids.numel(), C.c_void_p(text.data_ptr()), C.c_void_p(bad.data_ptr()), s) == 0
+    assert int(bad.item()) == 1
+    assert lib.prego_format_ids(None, 4, C.c_void_p(text.data_ptr()), None, s) != 0
