@@ -162,7 +162,7 @@ def test_device_average_precision_by_class_id_equals_the_matrix_entry():
         assert np.array_equal(x, y, equal_nan=True)
 
 
-@pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86)])
+@pytest.mark.parametrize("n,C", [(1, 3), (63, 5), (4097, 12), (150_000, 86), (9_001, 130)])      # 130 classes: two column blocks in ap_extract
 def test_device_average_precision_kernel_vs_sklearn(n, C):
     """prego_perframe_ap (csrc/metrics.hip: the positives of every class sorted, every score counted against them) against sklearn's
     average_precision_score and the host implementation: random scores, heavy ties, a constant column, negative scores (raw logits),
