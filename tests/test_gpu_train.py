@@ -193,6 +193,39 @@ def test_train_one_epoch_registry_loop_reduces_loss():
     assert torch.allclose(p.sum(-1), torch.ones_like(p[..., 0]), atol=1e-4)
 
 
+@pytest.mark.parametrize("zero_flow", [True, False])
+def test_train_one_epoch_prefetch_equals_the_blocking_copies(zero_flow):
+    """train_one_epoch copies batch k + 1 on a side stream while step k runs (trainer._device_batches; pinned loader tensors): epoch
+    losses and final weights equal, bit for bit, those of the reference's three blocking .to(device) per step - with the flow half
+    read (rgb + flow) and with a model told it is zero (flow_input then never travels)."""
+    from prego_amd.registry import build_trainer
+    import prego_amd.trainer as TR
+    cfg = assembly101_cfg(dropout=0.0, compute_dtype="bf16", assume_zero_flow=zero_flow)
+    sd = W.miniroad_state_dict(cfg, 20)
+    B, T = 4, 16
+    batches = []
+    for i in range(5):
+        rgb = torch.from_numpy(W.tsn_features((B, T, 2048), 40 + i, "pf.rgb")).pin_memory()
+        flow = torch.zeros_like(rgb).pin_memory() if zero_flow else torch.from_numpy(W.tsn_features((B, T, 2048), 40 + i, "pf.flow")).pin_memory()
+        tgt = torch.from_numpy(_targets(B, T, 86, 40 + i, "pf.tgt")).pin_memory()
+        batches.append((rgb, flow, tgt, ["v"] * B, torch.zeros(B), torch.full((B,), T)))
+    res = {}
+    try:
+        for pre in (True, False):
+            TR.PREFETCH = pre
+            model, crit = _build(cfg, sd)
+            opt = torch.optim.AdamW([{"params": model.parameters(), "initial_lr": 1e-3}], lr=1e-3, weight_decay=cfg["weight_decay"])
+            tr = build_trainer(cfg)
+            losses = [tr(batches, model, crit, opt, None, e, "cuda:0", None, scheduler=None) for e in (1, 2)]
+            model.engine().check()
+            res[pre] = (losses, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()})
+    finally:
+        TR.PREFETCH = True
+    assert res[True][0] == res[False][0]
+    for k in res[True][1]:
+        assert np.array_equal(res[True][1][k], res[False][1][k]), k
+
+
 def test_empty_clip_list_is_a_noop():
     cfg = assembly101_cfg()
     sd = W.miniroad_state_dict(cfg, 20)
