@@ -165,8 +165,10 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
     if hasattr(sampler, "set_epoch"):          # data-parallel runs: a different permutation every epoch
         sampler.set_epoch(epoch)
     step_weight = getattr(sampler, "step_weight", None)       # data.EpochWindowSampler: global batch / real windows of a step (1.0 but for a short last batch)
+    loss_host = None
     for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(_device_batches(trainloader, model, device)):
         w = float(step_weight(it)) if step_weight is not None else 1.0
+        loss_value = None
         model.train()
         if scaler is not None:
             # --amp (train.py:10-18): the reference's loss-scaling protocol runs unchanged - scaled loss, scaled gradients through
@@ -189,9 +191,22 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
             _arm_early_allreduce(model, w)
             loss.backward()
             _allreduce_grads(model, w)         # enqueued behind the backward's events, BEFORE the host waits for anything
-            _check_engine(model)               # synchronises; only gates optimizer.step()
-            optimizer.step()
-        epoch_loss += loss.item() * w
+            # train.py:26's loss.item(): the value travels to pinned host memory in front of the check's synchronisation and is read
+            # behind it - optimizer.step() is then enqueued with nothing waiting for it, and the host walks into the next step while the
+            # AdamW kernel runs (a second synchronisation behind optimizer.step() cost its launch + 0.09 ms of idle host per step)
+            if loss.is_cuda and getattr(model, "_engine", None) is not None:
+                if loss_host is None:
+                    loss_host = torch.empty((), dtype=loss.dtype, pin_memory=True)
+                loss_host.copy_(loss.detach(), non_blocking=True)
+                _check_engine(model)           # synchronises; only gates optimizer.step()
+                optimizer.step()
+                loss_value = loss_host.item()
+        if loss_value is None:
+            if scaler is None:
+                _check_engine(model)
+                optimizer.step()
+            loss_value = loss.item()
+        epoch_loss += loss_value * w
         if writer is not None:
-            writer.add_scalar("Train Loss", loss.item() * w, it + epoch * len(trainloader))
+            writer.add_scalar("Train Loss", loss_value * w, it + epoch * len(trainloader))
     return epoch_loss
