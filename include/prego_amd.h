@@ -262,7 +262,9 @@ int prego_adamw_step(int n_tensors, float* const* params, const float* const* gr
                      float weight_decay, prego_stream_t stream);
 /* The same step for MiniROAD's ten tensors (prego_miniroad_set_weights' order, reference state_dict shapes) that ALSO rewrites the
  * handle's converted operand copies from the updated values in the same pass: the training loop (train.py:24 optimizer.step())
- * needs no prego_miniroad_set_weights after it. */
+ * needs no prego_miniroad_set_weights after it.  The launch is GUARDED by the handle's timeout word on the device: while a recurrence /
+ * BPTT timeout of this handle is pending (set by the kernel that gave up, cleared by prego_miniroad_check, which reports it), the step
+ * changes nothing - a training loop may enqueue it without synchronising first and still never applies garbage gradients. */
 int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                               float weight_decay, prego_stream_t stream);

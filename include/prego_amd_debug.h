@@ -39,6 +39,9 @@ int prego_debug_gemm_worker(const void* A, const void* B, const float* bias, flo
  * skip = eligible calls still to be kept chunked by the back-off, split_env = the handle's PREGO_SPLIT_PASS state (-1 auto, 0 never, R). */
 int prego_debug_split_fault(prego_miniroad* h, int mode);
 int prego_debug_split_state(const prego_miniroad* h, int64_t* fallbacks, int32_t* fails, int64_t* skip, int32_t* split_env);
+/* unit-test hook: sets the handle's timeout word on the device (stream-ordered), as a recurrence / BPTT kernel that gave up would:
+ * prego_miniroad_check then reports PREGO_ETIMEOUT and clears it; until then prego_miniroad_adamw_step changes nothing. */
+int prego_debug_set_abort(prego_miniroad* h, unsigned value, prego_stream_t stream);
 
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */

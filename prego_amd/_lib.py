@@ -40,7 +40,7 @@ SYMBOLS = [
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
 DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
                  "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
-                 "prego_debug_split_fault", "prego_debug_split_state"]
+                 "prego_debug_split_fault", "prego_debug_split_state", "prego_debug_set_abort"]
 
 
 class PregoError(RuntimeError):
@@ -150,6 +150,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
         lib.prego_debug_gemm_bf16.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, vp]
         lib.prego_debug_split_fault.argtypes = [vp, i32]
         lib.prego_debug_split_state.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
+        lib.prego_debug_set_abort.argtypes = [vp, C.c_uint32, vp]
     return lib
 
 

@@ -267,7 +267,7 @@ int launch_perframe_ap(const float* scores, const float* target, const int* labe
 // fused multi-tensor AdamW (optim.hip)
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,
-                 float wd, hipStream_t s);
+                 float wd, hipStream_t s, const unsigned* guard = nullptr /* device word: non-zero = change nothing */);
 
 // Transformer path (attention.hip, vit.hip)
 // attention forward (attention.hip): query on the lane, V row-major [B,h,N,dh], Nq queries against N keys

@@ -1558,6 +1558,12 @@ extern "C" int prego_debug_split_fault(prego_miniroad* h, int mode) {
   h->dbg_fault = mode;
   return PREGO_OK;
 }
+// unit-test hook: set the handle's timeout word as a kernel that gave up would (stream-ordered)
+extern "C" int prego_debug_set_abort(prego_miniroad* h, unsigned value, prego_stream_t stream) {
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  HIPCHK(hipMemsetD32Async((hipDeviceptr_t)h->abort_word, (int)value, 1, (hipStream_t)stream));
+  return PREGO_OK;
+}
 extern "C" int prego_debug_split_state(const prego_miniroad* h, int64_t* fallbacks, int32_t* fails, int64_t* skip, int32_t* split_env) {
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (fallbacks) *fallbacks = h->split_fallbacks;
@@ -1985,8 +1991,10 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
   void* cb[6] = {h->b1, h->ln_g, h->ln_b, nullptr, nullptr, h->b_c};
   const long long nb[6] = {numel[1], numel[2], numel[3], numel[6], numel[7], numel[9]};
   for (int i = 0; i < 10; ++i) if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return fail(PREGO_EINVAL, "adamw: tensor %d is NULL", i);
-  if (launch_adamw(4, pw, gw, mw, vw, cw, nw, h->bf16, step, lr, beta1, beta2, eps, weight_decay, s) ||
-      launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s))
+  // guarded by the handle's timeout word: after a forward / backward that gave up, the step changes nothing (the add / copy below then
+  // rebuild the same derived vectors from the unchanged biases)
+  if (launch_adamw(4, pw, gw, mw, vw, cw, nw, h->bf16, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word) ||
+      launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word))
     return fail(PREGO_EINVAL, "adamw: bad step %lld", (long long)step);
   launch_add_vec(params[6], params[7], h->bias2, (int)(3 * H), (int)(2 * H), s);      // r,z rows: b_ih + b_hh ; n rows: b_ih
   HIPCHK(hipMemcpyAsync(h->b_hn, params[7] + 2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));

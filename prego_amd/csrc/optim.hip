@@ -23,8 +23,12 @@ struct AdamDesc {
 };
 struct AdamTable { AdamDesc d[ADAM_MAX_TENSORS]; int n; };
 
+// guard (nullable): a device word; while it is non-zero the launch changes nothing.  prego_miniroad_adamw_step passes the handle's
+// timeout word: a step whose recurrence / BPTT gave up (garbage gradients) then leaves parameters, moments and operand copies as they
+// were, whether or not the host has looked at the word yet - the training loop needs no synchronisation in front of optimizer.step()
 __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt) {
+                                                    float bc2_sqrt, const unsigned* __restrict__ guard) {
+  if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
   int ti = 0;
   for (int i = 1; i < tab.n; ++i) if ((int)blockIdx.x >= tab.d[i].block0) ti = i;      // <= 24 scalar compares
   const AdamDesc d = tab.d[ti];
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float lr, flo
 // copies[i] nullable; copy_bf16: element type of every non-NULL copy.  Returns 0, or -1 on a bad argument.
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,
-                 float wd, hipStream_t s) {
+                 float wd, hipStream_t s, const unsigned* guard) {
   if (n_tensors <= 0 || step <= 0) return -1;
   const float bc1 = 1.0f - (float)pow((double)b1, (double)step);
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
@@ -94,7 +98,7 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
       tab.d[i] = AdamDesc{params[k], grads[k], exp_avg[k], exp_avg_sq[k], cp, numel[k], blocks, (short)(copy_bf16 ? 1 : 0), vec};
       blocks += (int)((numel[k] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK);
     }
-    adamw_kernel<<<blocks, 256, 0, s>>>(tab, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+    adamw_kernel<<<blocks, 256, 0, s>>>(tab, lr, b1, b2, eps, wd, bc1, bc2_sqrt, guard);
   }
   return 0;
 }

@@ -24,6 +24,17 @@ class FusedAdamW(torch.optim.Optimizer):
         # the "Transformer" entry (ViTEnc): same idea through prego_vit_adamw_step
         self._vit = model if model is not None and hasattr(model, "_handle") and hasattr(model, "pre_head_ln") else None
 
+    def is_guarded_for(self, model) -> bool:
+        """True when step() runs `prego_miniroad_adamw_step` for exactly this model's ten tensors: that launch is a no-op on the DEVICE
+        while the engine's timeout word is set (a forward / backward that gave up), so a training loop may call step() without
+        synchronising first (prego_amd/trainer.py)."""
+        if self._model is None or self._model is not model or len(self.param_groups) != 1:
+            return False
+        named = dict(model.named_parameters())
+        want = {id(named[k]) for k in _PARAM_ORDER if k in named}
+        have = {id(p) for p in self.param_groups[0]["params"]}
+        return len(want) == len(_PARAM_ORDER) and want == have and all(p.is_cuda for p in self.param_groups[0]["params"])
+
     def _state(self, p):
         st = self.state[p]
         if not st:

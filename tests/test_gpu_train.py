@@ -226,6 +226,87 @@ def test_train_one_epoch_prefetch_equals_the_blocking_copies(zero_flow):
         assert np.array_equal(res[True][1][k], res[False][1][k]), k
 
 
+def test_guarded_training_loop_equals_the_per_step_loop():
+    """With a FusedAdamW bound to the model, train_one_epoch runs without a host synchronisation per step (the optimizer launch is
+    guarded by the engine's timeout word on the device; losses summed at the end as train.py:26 sums them): epoch losses and weights
+    equal, bit for bit, the per-step loss.item() loop's."""
+    from prego_amd.optim import FusedAdamW
+    from prego_amd.registry import build_trainer
+    import prego_amd.trainer as TR
+    cfg = assembly101_cfg(dropout=0.0, compute_dtype="bf16")
+    sd = W.miniroad_state_dict(cfg, 20)
+    B, T = 4, 16
+    batches = []
+    for i in range(TR.CHECK_EVERY + 3):          # crosses one in-epoch check
+        rgb = torch.from_numpy(W.tsn_features((B, T, 2048), 50 + i % 5, "gl.rgb")).pin_memory()
+        flow = torch.from_numpy(W.tsn_features((B, T, 2048), 50 + i % 5, "gl.flow")).pin_memory()
+        tgt = torch.from_numpy(_targets(B, T, 86, 50 + i % 5, "gl.tgt")).pin_memory()
+        batches.append((rgb, flow, tgt, ["v"] * B, torch.zeros(B), torch.full((B,), T)))
+    res = {}
+    try:
+        for guarded in (True, False):
+            TR.GUARDED_LOOP = guarded
+            model, crit = _build(cfg, sd)
+            opt = FusedAdamW([{"params": list(model.parameters())}], lr=1e-3, weight_decay=cfg["weight_decay"], model=model)
+            assert opt.is_guarded_for(model)
+            tr = build_trainer(cfg)
+            losses = [tr(batches, model, crit, opt, None, e, "cuda:0", None, scheduler=None) for e in (1, 2)]
+            res[guarded] = (losses, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()})
+    finally:
+        TR.GUARDED_LOOP = True
+    assert res[True][0] == res[False][0] and res[True][0][1] < res[True][0][0]
+    for k in res[True][1]:
+        assert np.array_equal(res[True][1][k], res[False][1][k]), k
+
+
+def test_fused_adamw_step_is_a_noop_while_the_timeout_word_is_set():
+    """prego_miniroad_adamw_step is guarded by the handle's timeout word ON THE DEVICE: after a forward / backward that gave up (the
+    debug library sets the word as such a kernel would) the step leaves parameters, moments and the handle's operand copies as they
+    were; prego_miniroad_check reports PREGO_ETIMEOUT and clears the word; the next step updates again."""
+    import ctypes as C
+    from prego_amd import _lib
+    from prego_amd._lib import PregoError, ptr_array
+    from prego_amd.config import FEATURE_SIZES
+    from prego_amd.engine import MiniRoadEngine, _PARAM_ORDER
+    dbg = _lib.load_debug()
+    cfg = assembly101_cfg(compute_dtype="bf16")
+    sd = W.miniroad_state_dict(cfg, 20)
+    eng = MiniRoadEngine(FEATURE_SIZES[cfg["rgb_type"]], FEATURE_SIZES[cfg["flow_type"]], cfg["embedding_dim"], cfg["hidden_dim"],
+                         cfg["num_classes"], "cuda:0", "bf16", lib=dbg)
+    params = {k: torch.from_numpy(sd[k]).cuda() for k in _PARAM_ORDER}
+    eng.set_weights(params)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    grads = {k: torch.randn(v.shape, device="cuda", generator=g) * 1e-2 for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step(n):
+        rc = dbg.prego_miniroad_adamw_step(eng.h, ptr_array([params[k].data_ptr() for k in _PARAM_ORDER]),
+                                           ptr_array([grads[k].data_ptr() for k in _PARAM_ORDER]), ptr_array([m[k].data_ptr() for k in _PARAM_ORDER]),
+                                           ptr_array([v2[k].data_ptr() for k in _PARAM_ORDER]), n, 1e-3, 0.9, 0.999, 1e-8, 0.05, s)
+        assert rc == 0, dbg.prego_last_error()
+    rgb = torch.from_numpy(W.tsn_features((300, 2048), 20, "ga.rgb")).cuda()
+    fwd = lambda: eng.forward_ragged([rgb], None, softmax=True)[0][0].clone()
+    before = {k: p.clone() for k, p in params.items()}
+    out0 = fwd()
+    assert dbg.prego_debug_set_abort(eng.h, 1, s) == 0
+    step(1)
+    torch.cuda.synchronize()
+    for k in params:
+        assert torch.equal(params[k], before[k]), k
+        assert not m[k].any() and not v2[k].any(), k
+    with pytest.raises(PregoError):
+        eng.check()                                   # reports the timeout, clears the word
+    eng.check()
+    assert torch.equal(fwd(), out0)                   # the handle's operand copies were not touched either
+    step(1)
+    torch.cuda.synchronize()
+    assert all(not torch.equal(params[k], before[k]) for k in params)
+    assert not torch.equal(fwd(), out0)               # ... and follow the update now
+    eng.check()
+
+
 def test_empty_clip_list_is_a_noop():
     cfg = assembly101_cfg()
     sd = W.miniroad_state_dict(cfg, 20)
