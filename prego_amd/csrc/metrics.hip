@@ -432,11 +432,8 @@ size_t perframe_ap_workspace_bytes(long long n, int C) {
 int launch_perframe_ap(const float* scores, const float* target, const int* labels, long long n, int C, double* ap, long long* n_pos,
                        double* score_sum, void* ws, hipStream_t s) {
   if (n <= 0 || C <= 0 || C > 65535 || n >= (1ll << 31)) return -1;    // per-class cursors are 32-bit
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)ap_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AP_TAB * 4 + 128);
-    attr = true;
-  }
+  static DeviceOnce once;
+  once.run([] { (void)hipFuncSetAttribute((const void*)ap_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, AP_TAB * 4 + 128); });
   const int ntiles = (int)((n + AP_TILE - 1) / AP_TILE);
   const size_t cn = (size_t)C * (size_t)n;
   unsigned* keys = (unsigned*)ws;
