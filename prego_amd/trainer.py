@@ -107,7 +107,8 @@ def _allreduce_grads(model, weight: float = 1.0):
 
 def _check_engine(model):
     """A recurrence / BPTT spin timeout only sets the handle's abort word and makes the kernels return early, so the
-    logits and gradients of that step are garbage: surface it (PregoError, PREGO_ETIMEOUT) BEFORE optimizer.step().
+    logits and gradients of that step are garbage: surface it (PregoError, PREGO_ETIMEOUT) BEFORE optimizer.step() - or, in the guarded
+    loop (_guarded_epoch), behind a step the device skipped for the same reason.
     `engine().check()` synchronises the stream - the reference loop syncs here anyway (`loss.item()`, train.py:26)."""
     eng = getattr(model, "_engine", None)
     if eng is not None:
