@@ -222,8 +222,10 @@ def train_one_epoch(trainloader, model, criterion, optimizer, scaler, epoch, dev
     # timeout check runs every CHECK_EVERY steps and at the end of the epoch (a step that gave up leaves the weights as they were; so do
     # the steps behind it, the word stays set until the check reports it).  With a tensorboard writer, --amp or any other optimizer the
     # loop below keeps the reference's per-step loss.item().
-    guarded = bool(GUARDED_LOOP and scaler is None and writer is None and getattr(optimizer, "is_guarded_for", None) is not None
-                   and torch.device(device).type == "cuda" and optimizer.is_guarded_for(model))
+    guarded = bool(GUARDED_LOOP and scaler is None and writer is None and torch.device(device).type == "cuda" and
+                   ((getattr(optimizer, "is_guarded_for", None) is not None and optimizer.is_guarded_for(model))
+                    # the `Transformer` entry (ViTEnc) has no persistent kernel that could give up: nothing to check, any optimizer
+                    or (hasattr(model, "pre_head_ln") and getattr(model, "_engine", None) is None)))
     if guarded:
         return _guarded_epoch(trainloader, model, criterion, optimizer, device, step_weight)
     for it, (rgb_input, flow_input, target, vid, start, end) in enumerate(_device_batches(trainloader, model, device)):

@@ -19,6 +19,41 @@ from prego_amd.config import assembly101_cfg  # noqa: E402
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def test_vit_train_one_epoch_deferred_losses_equal_the_per_step_loop():
+    """TRAINER["OAD"] on the `Transformer` entry: the loop without a host synchronisation per step (losses summed at the end of the
+    epoch as train.py:26 sums them; ViTEnc has no kernel that could time out) gives the per-step loss.item() loop's epoch losses and
+    weights, bit for bit - with the fused AdamW and with torch's."""
+    from prego_amd.optim import FusedAdamW
+    from prego_amd.registry import build_criterion, build_model, build_trainer
+    import prego_amd.loss, prego_amd.transformer, prego_amd.trainer as TR  # noqa: F401
+    cfg = _vit_cfg(num_layers=1)
+    sd = W.vit_state_dict(cfg, 20)
+    batches = []
+    for i in range(4):
+        rgb = torch.from_numpy(W.tsn_features((3, 128, 2048), 30 + i, "vl.rgb")).pin_memory()
+        flow = torch.from_numpy(W.tsn_features((3, 128, 2048), 30 + i, "vl.flow")).pin_memory()
+        tgt = torch.from_numpy(_targets(3, 128, 86, 30 + i, "vl.tgt")).pin_memory()
+        batches.append((rgb, flow, tgt, ["v"] * 3, torch.zeros(3), torch.full((3,), 128)))
+    for fused in (True, False):
+        res = {}
+        try:
+            for deferred in (True, False):
+                TR.GUARDED_LOOP = deferred
+                model = build_model(cfg, "cuda:0")
+                model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+                crit = build_criterion(cfg, "cuda:0")
+                opt = FusedAdamW([{"params": list(model.parameters())}], lr=1e-3, weight_decay=0.05, model=model) if fused else \
+                    torch.optim.AdamW([{"params": list(model.parameters())}], lr=1e-3, weight_decay=0.05)
+                tr = build_trainer(cfg)
+                losses = [tr(batches, model, crit, opt, None, e, "cuda:0", None, scheduler=None) for e in (1, 2)]
+                res[deferred] = (losses, {k: p.detach().cpu().numpy() for k, p in model.named_parameters()})
+        finally:
+            TR.GUARDED_LOOP = True
+        assert res[True][0] == res[False][0] and np.isfinite(res[True][0]).all(), (fused, res[True][0], res[False][0])
+        for k in res[True][1]:
+            assert np.array_equal(res[True][1][k], res[False][1][k]), (fused, k)
+
+
 def _vit_cfg(**over):
     # compute_dtype bf16: the training tests compare eval-mode and training-mode forwards of the SAME (bf16) handle bit for bit
     cfg = dict(model="Transformer", window_size=128, patch_dim=1, num_heads=8, attn_dropout_rate=0.0, dropout=0.0, compute_dtype="bf16")
