@@ -13,10 +13,12 @@
  *  - calls only enqueue work on the caller's stream; nothing waits for the END of device work except prego_miniroad_check().  One
  *    documented wait for a START: a prego_miniroad_forward() that runs the split pass returns once the stream has reached its two
  *    persistent launches and they have confirmed each other resident (normally at once; behind earlier work of the stream otherwise).
- *  - the caller owns inputs, outputs and the workspace; they must stay valid until the stream reaches the
- *    end of the call.  The handle owns converted weight copies, the plan tables (pre-sized at create for clips of up to
- *    131 072 frames: forward() allocates nothing below that) and a pinned staging buffer for the per-call pointer tables
- *    (host pointer arrays passed to a call may be freed as soon as the call returns).
+ *  - the caller owns inputs, outputs, the workspace and the resident buffer (prego_miniroad_set_resident); they must stay valid until
+ *    the stream reaches the end of the call.  The handle owns converted weight copies, the plan tables (pre-sized at create for clips
+ *    of up to 131 072 frames: forward() allocates nothing below that; a longer clip or more clips than any call before grows them
+ *    once, behind a stream synchronisation) and a pinned staging buffer for the per-call pointer tables (host pointer arrays passed
+ *    to a call may be freed as soon as the call returns).  Nothing else is allocated by a hot call: every per-call buffer whose size
+ *    depends on the call is the caller's, sized by a query (workspace_bytes, resident_bytes, backward_workspace_bytes).
  *  - one handle per (device, stream); different handles are independent and re-entrant.
  */
 #ifndef PREGO_AMD_H
@@ -38,8 +40,12 @@ extern "C" {
  *    a pass that cannot run side by side is re-run chunked inside the same call instead of being reported as PREGO_ETIMEOUT by
  *    prego_miniroad_check; tuning environment knobs are read by the debug library only.  Added (existing signatures unchanged):
  *    prego_miniroad_create_layers / _set_gru_layer (num_layers 2), prego_oad_loss_reduce (reduction 'sum'),
- *    prego_attention_layer_set_dropout, prego_perframe_ap_labels, prego_onehot_labels (host), prego_format_ids. */
-#define PREGO_ABI_VERSION 6
+ *    prego_attention_layer_set_dropout, prego_perframe_ap_labels, prego_onehot_labels (host), prego_format_ids.
+ * 7: round 6.  prego_miniroad_forward no longer allocates or synchronises for the whole-call relu(h) buffer: the caller sizes it with
+ *    prego_miniroad_resident_bytes and hands it over with prego_miniroad_set_resident (without one, every call runs the chunked pass
+ *    with the per-chunk classifier - same results).  Added: prego_miniroad_resident_bytes / _set_resident, prego_miniroad_guard_publish /
+ *    _set_peer_guard (data-parallel training: a timeout on one rank stops the optimizer step of every rank).  Existing signatures unchanged. */
+#define PREGO_ABI_VERSION 7
 
 enum {
   PREGO_OK = 0,
@@ -115,6 +121,18 @@ int prego_miniroad_max_clips(const prego_miniroad* h);
  * flags: PREGO_FWD_KEEP adds the activations backward() needs (whole batch resident). */
 size_t prego_miniroad_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens,
                                       int64_t rows_per_chunk, int flags);
+
+/* Whole-call resident buffer (ABI 7).  Long inference calls run the classifier ONCE behind the pass instead of once per chunk, and the
+ * split pass (two persistent launches, prego_miniroad_pass_info) keeps its row map and counters beside it: both need relu(h) of every
+ * frame of the call resident - 2 KB per frame with 16-bit operands, 4 KB with fp32 / fp16x2 operands (4.7 GB for a 2.3 M-frame eval
+ * set).  resident_bytes: the size that lets a call of these clips and flags use those passes (0 = such a call never would: training
+ * calls, num_layers 2, fewer than 65 536 frames, more than 24 GB).  set_resident: a device buffer (256-byte aligned) the handle may use
+ * for this in every following forward() until it is replaced (NULL, 0 removes it); it is caller-owned, read and written only between the
+ * start and the end of a forward() call in stream order, and holds nothing between calls.  A call whose size exceeds the registered
+ * buffer simply runs the chunked pass with the per-chunk classifier: same result bits, ~20 % slower on the eval-set workload.
+ * forward() itself never allocates device memory for it and never waits for the stream because of it. */
+size_t prego_miniroad_resident_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens, int flags);
+int prego_miniroad_set_resident(prego_miniroad* h, void* device_buffer, size_t bytes);
 
 /* MROAD.forward (rnn.py:51-71) for a ragged batch, and the device half of Evaluate.eval (trainer/eval.py:36-56).
  *   lens[i]            frames of clip i (host array)
@@ -268,6 +286,15 @@ int prego_adamw_step(int n_tensors, float* const* params, const float* const* gr
 int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, int64_t step, float lr, float beta1, float beta2, float eps,
                               float weight_decay, prego_stream_t stream);
+/* The same guard across data-parallel ranks (ABI 7; train.py:20-24 under clip sharding).  A rank whose kernels gave up still takes part
+ * in the gradient all-reduce, so its garbage reaches every rank: the guard has to be collective.
+ *   guard_publish: enqueue dst[0] = (this handle's timeout word is set) ? 1.0f : 0.0f.  dst is one fp32 element of the gradient bucket
+ *                  the ranks sum (the caller reserves it; call it after prego_miniroad_backward, before that bucket's all-reduce).
+ *   set_peer_guard: the address of that element (after the reduction it is non-zero iff ANY rank gave up), NULL = none.  While it
+ *                  holds a non-zero value prego_miniroad_adamw_step changes nothing AND raises this handle's own timeout word, so the
+ *                  following steps are skipped as well and prego_miniroad_check reports PREGO_ETIMEOUT on every rank at the same step. */
+int prego_miniroad_guard_publish(prego_miniroad* h, float* dst, prego_stream_t stream);
+int prego_miniroad_set_peer_guard(prego_miniroad* h, const float* reduced_word);
 
 /* ---- "Transformer" (ViTEnc): step_recognition/model/transformer_models/ViT.py:25-143 ------------------------------ */
 typedef struct prego_vit prego_vit;

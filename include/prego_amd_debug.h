@@ -42,6 +42,10 @@ int prego_debug_split_state(const prego_miniroad* h, int64_t* fallbacks, int32_t
 /* unit-test hook: sets the handle's timeout word on the device (stream-ordered), as a recurrence / BPTT kernel that gave up would:
  * prego_miniroad_check then reports PREGO_ETIMEOUT and clears it; until then prego_miniroad_adamw_step changes nothing. */
 int prego_debug_set_abort(prego_miniroad* h, unsigned value, prego_stream_t stream);
+/* unit-test hook: how many hipMalloc calls / host-side stream or event waits the MiniROAD host code of this library has made so far in
+ * this process (prego_miniroad_check's own synchronisation counts).  A test calls it around a hot call to hold "forward() allocates
+ * nothing and waits for nothing" to zero (include/prego_amd.h, conventions). */
+int prego_debug_alloc_count(int64_t* device_mallocs, int64_t* host_waits);
 
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */

@@ -36,11 +36,12 @@ SYMBOLS = [
     "prego_perframe_ap_workspace_bytes", "prego_perframe_ap", "prego_vit_frames_workspace_bytes", "prego_vit_forward_frames", "prego_miniroad_backward_events", "prego_miniroad_backward_callback",
     "prego_miniroad_plan_starts", "prego_miniroad_set_feed_events", "prego_miniroad_pass_info",
     "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
+    "prego_miniroad_resident_bytes", "prego_miniroad_set_resident", "prego_miniroad_guard_publish", "prego_miniroad_set_peer_guard",
 ]
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
 DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
                  "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
-                 "prego_debug_split_fault", "prego_debug_split_state", "prego_debug_set_abort"]
+                 "prego_debug_split_fault", "prego_debug_split_state", "prego_debug_set_abort", "prego_debug_alloc_count"]
 
 
 class PregoError(RuntimeError):
@@ -73,6 +74,11 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_miniroad_max_clips.argtypes = [vp]
     lib.prego_miniroad_workspace_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32), i64, i32]
     lib.prego_miniroad_workspace_bytes.restype = sz
+    lib.prego_miniroad_resident_bytes.argtypes = [vp, i32, C.POINTER(C.c_int32), i32]
+    lib.prego_miniroad_resident_bytes.restype = sz
+    lib.prego_miniroad_set_resident.argtypes = [vp, vp, sz]
+    lib.prego_miniroad_guard_publish.argtypes = [vp, vp, vp]
+    lib.prego_miniroad_set_peer_guard.argtypes = [vp, vp]
     lib.prego_miniroad_forward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp),
                                            C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp, sz, vp]
     lib.prego_miniroad_step.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp]
@@ -151,6 +157,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
         lib.prego_debug_split_fault.argtypes = [vp, i32]
         lib.prego_debug_split_state.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
         lib.prego_debug_set_abort.argtypes = [vp, C.c_uint32, vp]
+        lib.prego_debug_alloc_count.argtypes = [C.POINTER(i64), C.POINTER(i64)]
     return lib
 
 

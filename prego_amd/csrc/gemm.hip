@@ -433,10 +433,6 @@ void launch_gemm_bf16_variant(int variant, const void* A, int lda, const void* B
     gemm_bf16_nt_big_kernel<<<ntm * ntn, 512, 3 * GSTAGE, s>>>((const bf16_t*)A, (const bf16_t*)B, bias, C, M, N, K, lda, ldb, ldc);
   } else if (variant == 30) {        // the eight-wave split-K workgroup of gemm_tn.hip on nn.Linear's form (<= 256 tiles)
     (void)launch_gemm_bf16_tn(false, false, A, lda, B, ldb, bias, C, ldc, M, N, K, K, nullptr, s);
-  } else if (variant == 20) {
-    (void)launch_gemm_bf16_w4(A, lda, B, ldb, bias, C, ldc, M, N, K, false, s);
-  } else if (variant >= 21 && variant <= 23) {
-    launch_gemm_bf16_w4_diag(variant - 20, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
   } else {
     launch_gemm_bf16_experimental(variant, A, lda, B, ldb, bias, C, ldc, M, N, K, s);
   }

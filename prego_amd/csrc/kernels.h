@@ -190,10 +190,6 @@ void launch_f32_to_bf16(const float* src, void* dst, size_t n, hipStream_t s);
 void launch_pad_convert(bool bf16, const float* src, int rows_src, int cols_src, int ld_src, void* dst, int rows_dst,
                         int cols_dst, hipStream_t s, bool f16 = false);
 // 256x256x64 ping-pong (8-phase) kernel, csrc/gemm_pp.hip; -1 = shape not supported (N % 256, K % 64, K >= 128)
-// round-5 experiment (gemm_w4.hip): 256 x 256 x 64 tiles on four waves with 128 x 128 wave tiles; fp32 or 16-bit C; -1 = shape not taken
-int launch_gemm_bf16_w4(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N, int K, bool out16,
-                        hipStream_t s, bool f16 = false);
-void launch_gemm_bf16_w4_diag(int diag, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N, int K, hipStream_t s);
 int launch_gemm_bf16_pingpong_mode(int mode, const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc,
                                    int M, int N, int K, bool out_bf16, hipStream_t s, bool f16 = false);
 int launch_gemm_bf16_pingpong_epi(const void* A, int lda, const void* B, int ldb, const float* bias, void* C, int ldc, int M, int N,
@@ -267,7 +263,8 @@ int launch_perframe_ap(const float* scores, const float* target, const int* labe
 // fused multi-tensor AdamW (optim.hip)
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,
-                 float wd, hipStream_t s, const unsigned* guard = nullptr /* device word: non-zero = change nothing */);
+                 float wd, hipStream_t s, unsigned* guard = nullptr /* device word: non-zero = change nothing */,
+                 const float* peer = nullptr /* device float: non-zero = change nothing and raise *guard (data-parallel runs) */);
 
 // Transformer path (attention.hip, vit.hip)
 // attention forward (attention.hip): query on the lane, V row-major [B,h,N,dh], Nq queries against N keys

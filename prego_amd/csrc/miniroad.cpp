@@ -145,7 +145,8 @@ struct prego_miniroad {
   int placement = -1; unsigned* pin_place = nullptr; hipEvent_t ev_place = nullptr; bool place_pending = false;
   int prefetch_grid = 0;        // workgroup cap of the prefetching pack launch (0 = unthrottled)
   // split pass: recurrence on XCDs 0 .. split_r - 1 and the feed-forward of the whole pass on the others, two persistent
-  // launches.  split_buf: handle-owned [relu(h) rows of the pass | row map | counters], grown outside the steady state
+  // launches.  Their whole-call buffer [relu(h) rows of the pass | row map | counters] is the CALLER's resident buffer (res_buf,
+  // prego_miniroad_set_resident): forward() allocates nothing and synchronises nothing for it (round 6)
   int split_r = 0; int plan_force_slots = 0;
   int split_env = -1;           // PREGO_SPLIT_PASS at create: -1 unset = decide per call (cost model), 0 = never, R = whenever a call is eligible
   double plan_cost_us = 0;      // recurrence cost estimate of the cached plan (kStepCost tables)
@@ -154,14 +155,14 @@ struct prego_miniroad {
   // split pass runs its GEMM tiles 35 % slower on some, where it then loses to the chunked pass): measured / estimated, per kind
   hipEvent_t ev_meas[2] = {nullptr, nullptr}; bool meas_pending = false, meas_armed = false; int meas_mode = 0; double meas_est = 0;
   double ratio_chunked = 1.0, ratio_split = 1.0; bool have_ratio_chunked = false, have_ratio_split = false, split_warm = false;
-  char* split_buf = nullptr; size_t split_bytes = 0;
+  char* res_buf = nullptr; size_t res_bytes = 0;       // caller-owned (prego_miniroad_set_resident); NULL = per-chunk head, chunked pass
+  const float* peer_guard = nullptr;                   // caller-owned device word (prego_miniroad_set_peer_guard); NULL = none
   // start handshake of a split pass (kernels.h: PassHandshake): the pinned word the two launches report their GO / FAIL decision in, the
   // pass counter, and the back-off after a FAIL (the call itself is re-run as a chunked pass: no call is ever lost)
   unsigned* pin_hs = nullptr; unsigned hs_seq = 0; int split_fails = 0; long long split_skip = 0; long long split_fallbacks = 0;
   int dbg_fault = 0;            // debug library only (prego_debug_split_fault): what the NEXT split pass does differently, one shot
   // chunked pass with the classifier ONCE behind the pass (as the split pass runs it): relu(h) of every packed row of the call stays
-  // resident here (handle-owned, grown outside the steady state, capped at 24 GB) instead of one head launch per chunk
-  char* head_buf = nullptr; size_t head_bytes = 0; bool head_defer_off = false;
+  // in the caller's resident buffer (capped at 24 GB) instead of one head launch per chunk
   hipEvent_t ev_split[4] = {nullptr, nullptr, nullptr, nullptr};   // timing of the two launches (timing_enable)
   double split_rec_ms = 0, split_ff_ms = 0; long long split_passes = 0, split_steps = 0; bool split_ev_pending = false;
   std::string err;              // last error of THIS handle (prego_miniroad_last_error)
@@ -186,6 +187,21 @@ static int max_slots_of(const prego_miniroad* h) { return h->G * 16 * (h->x2 ? 2
 static int max_clips_of(const prego_miniroad*) { return PREGO_MAX_CLIPS; }
 
 extern "C" int prego_abi_version(void) { return PREGO_ABI_VERSION; }
+#ifdef PREGO_DEBUG_ABI
+// unit-test hook (prego_debug_alloc_count): every device allocation and every stream / event wait this file makes is counted, so a test
+// can hold "a hot call allocates nothing and waits for nothing" to zero
+#include <atomic>
+static std::atomic<long long> g_dbg_mallocs{0}, g_dbg_syncs{0};
+#define hipMalloc(p, n) (++g_dbg_mallocs, (hipMalloc)(p, n))
+#define hipStreamSynchronize(s) (++g_dbg_syncs, (hipStreamSynchronize)(s))
+#define hipEventSynchronize(e) (++g_dbg_syncs, (hipEventSynchronize)(e))
+extern "C" int prego_debug_alloc_count(int64_t* device_mallocs, int64_t* host_waits) {
+  if (device_mallocs) *device_mallocs = g_dbg_mallocs.load();
+  if (host_waits) *host_waits = g_dbg_syncs.load();
+  return PREGO_OK;
+}
+#endif
+
 extern "C" const char* prego_last_error(void) { return g_err.c_str(); }
 
 extern "C" int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes,
@@ -311,8 +327,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->side) { PREGO_TEARDOWN(hipStreamSynchronize(h->side)); PREGO_TEARDOWN(hipStreamDestroy(h->side)); }
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->tile_ctr, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale, h->l2_w_ih, h->l2_w_hh, h->l2_bias2, h->l2_b_hn,
-                  h->split_buf, h->head_buf};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale, h->l2_w_ih, h->l2_w_hh, h->l2_bias2, h->l2_b_hn};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; ++i)
     if (ptrs[i]) {
 #ifdef PREGO_DEBUG_ABI
@@ -708,6 +723,51 @@ extern "C" size_t prego_miniroad_workspace_bytes(const prego_miniroad* h, int n_
   return (size_t)rows * rb.total + 12 * 256;
 }
 
+// Whole-call resident buffer (round 6; SURVEY 8b: "no allocation of caller-visible memory, workspace sized by a query and passed in").
+// A pass that runs the classifier once per call keeps relu(h) of every packed row (2 KB per frame with 16-bit operands, 4 KB with fp32 /
+// fp16x2), the split pass also its row map and counters.  Until round 5 forward() grew a handle-owned hipMalloc for it (behind a stream
+// synchronisation); now the caller sizes it here and hands it over with prego_miniroad_set_resident.
+static size_t split_buf_need(const prego_miniroad* h, long long total);
+extern "C" size_t prego_miniroad_resident_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens, int flags) {
+  if (!h || n_clips <= 0 || !lens) return 0;
+  if ((flags & PREGO_FWD_KEEP) || h->layers != 1) return 0;
+  long long total = 0;
+  for (int i = 0; i < n_clips; ++i) total += lens[i] > 0 ? lens[i] : 0;
+  if (total < 65536) return 0;                      // fewer than four chunks of the smallest useful size: the per-chunk head runs
+  const RowBytes rb = row_bytes(h, true, flags);
+  size_t need = align_up((size_t)total * rb.hr, 256);
+  if (h->bf16 && h->hid == 1024) need = std::max(need, split_buf_need(h, total));
+  return need <= ((size_t)24 << 30) + ((size_t)1 << 30) ? need : 0;
+}
+
+extern "C" int prego_miniroad_set_resident(prego_miniroad* h, void* device_buffer, size_t bytes) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if ((device_buffer == nullptr) != (bytes == 0)) return fail(PREGO_EINVAL, "set_resident: buffer %p with %zu bytes", device_buffer, bytes);
+  if ((uintptr_t)device_buffer & 255) return fail(PREGO_EINVAL, "set_resident: the buffer must be 256-byte aligned");
+  h->res_buf = (char*)device_buffer; h->res_bytes = bytes;
+  return PREGO_OK;
+}
+
+// Data-parallel guard (round 6, advisor): a rank whose recurrence / BPTT gave up must stop EVERY rank's optimizer step, not only its own.
+// publish: dst[0] = 1.0f if this handle's timeout word is set, else 0.0f - enqueued; dst is an element of the gradient bucket the ranks
+// all-reduce (sum).  peer guard: the address of that element; prego_miniroad_adamw_step then changes nothing while it holds a non-zero
+// value and raises this handle's own word (code 0x200), so prego_miniroad_check reports the step on every rank.
+void launch_guard_publish(const unsigned* abort_word, float* dst, hipStream_t s);
+extern "C" int prego_miniroad_guard_publish(prego_miniroad* h, float* dst, prego_stream_t stream) {
+  HandleScope scope_(h);
+  if (!h || !dst) return fail(PREGO_EINVAL, "guard_publish: NULL argument");
+  launch_guard_publish(h->abort_word, dst, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
+extern "C" int prego_miniroad_set_peer_guard(prego_miniroad* h, const float* reduced_word) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  h->peer_guard = reduced_word;
+  return PREGO_OK;
+}
+
 static EventPair* ev_begin(prego_miniroad* h, int kind, hipStream_t s) {
   if (!h->timing) return nullptr;
   if (h->ev_used == h->ev_pool.size()) {
@@ -760,27 +820,14 @@ static SplitRings split_rings(const prego_miniroad* h, int R) {
 }
 static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_bytes) { return workspace_bytes >= split_rings(h, R).total; }
 
-// handle-owned buffer of a split pass: relu(h) rows | row map | counters.  Grown outside the steady state; false = the device has no room
-// (the caller then keeps the chunked pass)
+// whole-call buffer of a split pass: relu(h) rows | row map | counters.  It lives in the caller's resident buffer
+// (prego_miniroad_resident_bytes / _set_resident); a buffer that is too small keeps the call on the chunked pass
 static size_t split_buf_need(const prego_miniroad* h, long long total) {
   const long long n_units = (total + 255) / 256;
   const long long n_chunks = (n_units + (1 << kSplitChunkUnitShift) - 1) >> kSplitChunkUnitShift;
   return align_up((size_t)total * h->hid * 2, 256) + align_up((size_t)total * 8, 256) + align_up(((size_t)4 * n_units + 2 * (size_t)n_chunks + 32) * 4, 256);
 }
-static bool split_reserve(prego_miniroad* h, long long total, hipStream_t s, bool* grew) {
-  const size_t need = split_buf_need(h, total);
-  *grew = false;
-  if (need <= h->split_bytes) return true;
-  if (hipStreamSynchronize(s) != hipSuccess) return false;
-  if (h->split_buf) (void)hipFree(h->split_buf);
-  h->split_buf = nullptr; h->split_bytes = 0;
-  // a handle that goes on to split passes gives its chunked pass's whole-call relu(h) buffer back first (the two are the same size)
-  if (h->head_buf) { (void)hipFree(h->head_buf); h->head_buf = nullptr; h->head_bytes = 0; }
-  if (hipMalloc((void**)&h->split_buf, need + need / 8) != hipSuccess) { (void)hipGetLastError(); h->split_buf = nullptr; return false; }
-  h->split_bytes = need + need / 8;
-  *grew = true;
-  return true;
-}
+static bool split_resident_ok(const prego_miniroad* h, long long total) { return h->res_buf && split_buf_need(h, total) <= h->res_bytes; }
 
 // Split passes of DIFFERENT handles on one device must not interleave: handle A's feed-forward launch resident on XCDs R .. 7 with handle
 // B's recurrence launch resident on XCDs 0 .. R - 1 wait for each other's partner, which can never be dispatched (bounded, but both calls
@@ -810,10 +857,8 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   const size_t hr_bytes = align_up((size_t)total * H * 2, 256), rm_bytes = align_up((size_t)total * 8, 256);
   const size_t n_ctr = (size_t)4 * n_units + 2 * (size_t)n_chunks + 32;
   if (!h->split_warm) { h->meas_armed = false; h->split_warm = true; }       // a handle's first split pass loads kernels: not a measurement
-  bool grew = false;
-  if (!split_reserve(h, total, s, &grew)) return fail(PREGO_EHIP, "split pass: no device memory for %zu B of relu(h) rows", split_buf_need(h, total));
-  if (grew) h->meas_armed = false;                  // the allocation sat inside the timed window
-  char* HR = h->split_buf;
+  if (!split_resident_ok(h, total)) return fail(PREGO_EWORKSPACE, "split pass: resident buffer %zu B < %zu B", h->res_bytes, split_buf_need(h, total));
+  char* HR = h->res_buf;
   char* RM = HR + hr_bytes;
   unsigned* ctr = (unsigned*)(RM + rm_bytes);
   unsigned* tick = ctr; unsigned* hs_word = ctr + 8; unsigned* ff_here = ctr + 16; unsigned* pack_done = ctr + 32; unsigned* l1_cnt = pack_done + n_units; unsigned* ln_done = l1_cnt + n_units;
@@ -994,7 +1039,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
                           h->side != nullptr && side_queue_differs(h, s) && n_clips >= 16 * r_try && frames >= 262144 &&
                           frames < (1ll << 31) - 65536 && (out || argmax) && split_workspace_ok(h, r_try, workspace_bytes) &&
                           (h->d_rgb > 0 ? h->d_rgb : h->d_flow) >= 128 &&
-                          (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30);
+                          (size_t)frames * (h->hid * 2 + 8) <= ((size_t)24 << 30) && split_resident_ok(h, frames);
     // a call of this class is worth one wait for the placement word of an earlier launch (the handle's second call otherwise races it)
     if (shape_ok && h->placement < 0 && h->place_pending) { (void)hipEventSynchronize(h->ev_place); refresh_placement(h); }
     bool backing_off = false;                       // a failed start handshake keeps the next eligible calls chunked
@@ -1060,13 +1105,6 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       }
     }
   }
-  if (split_r > 0) {                                 // the pass keeps relu(h) of every frame: make room now, or stay chunked for good
-    long long frames_ = 0;
-    for (int i = 0; i < n_clips; ++i) frames_ += lens[i];
-    bool grew_ = false;
-    if (!split_reserve(h, frames_, s, &grew_)) { split_r = 0; h->split_env = 0; h->meas_armed = false; }
-    else if (grew_) h->meas_armed = false;
-  }
   h->split_r = split_r;
   int rc = build_plan(h, n_clips, lens, want_single, host_row_bytes, split_r > 0 ? 16 * split_r : 0);
   if (rc) return rc;
@@ -1127,24 +1165,16 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   float* HRAW = rb.hraw ? (float*)carve((size_t)cap_rows * rb.hraw) : nullptr;
   // The classifier once per pass.  A pass of many chunks pays the head kernel's launch, its fill and its scatter per chunk (split
   // operands: 71 launches of the fp32 head = 10.3 ms of a 280 ms pass; 16-bit operands: 47 x ~123 us): with relu(h) of the whole call
-  // resident - 4 KB (fp32 / fp16x2) or 2 KB per frame in a handle-owned buffer - ONE launch behind the last chunk does the same work at
-  // its HBM rate.  Inference calls of one GRU layer whose rows span four or more chunks; a link-fed call keeps the per-chunk head (its
-  // last chunk ends with the link, and a whole-pass head behind it would be pure tail); no room on the device = per-chunk head.
+  // resident - 4 KB (fp32 / fp16x2) or 2 KB per frame in the CALLER's resident buffer (prego_miniroad_set_resident) - ONE launch behind
+  // the last chunk does the same work at its HBM rate.  Inference calls of one GRU layer whose rows span four or more chunks; a link-fed
+  // call keeps the per-chunk head (its last chunk ends with the link, and a whole-pass head behind it would be pure tail); no resident
+  // buffer, or one that is too small = per-chunk head.  Nothing is allocated and nothing is waited for here.
   bool defer_head = false;
   char* HRall = nullptr;
-  if (!(flags & PREGO_FWD_KEEP) && !hostfeat && h->layers == 1 && (out || argmax) && !h->head_defer_off && (long long)total_rows >= 4 * cap_rows &&
+  if (!(flags & PREGO_FWD_KEEP) && !hostfeat && h->layers == 1 && (out || argmax) && (long long)total_rows >= 4 * cap_rows &&
       (size_t)total_rows * rb.hr <= ((size_t)24 << 30)) {
     const size_t need = align_up((size_t)total_rows * rb.hr, 256);
-    if (need > h->head_bytes) {
-      if (hipStreamSynchronize(s) == hipSuccess) {
-        if (h->head_buf) (void)hipFree(h->head_buf);
-        h->head_buf = nullptr; h->head_bytes = 0;
-        if (hipMalloc((void**)&h->head_buf, need + need / 8) == hipSuccess) h->head_bytes = need + need / 8;
-        else { (void)hipGetLastError(); h->head_buf = nullptr; h->head_defer_off = true; }      // no room: this handle keeps the per-chunk head
-      }
-      h->meas_armed = false;                   // the allocation sat inside a timed window
-    }
-    if (h->head_buf && need <= h->head_bytes) { defer_head = true; HRall = h->head_buf; }
+    if (h->res_buf && need <= h->res_bytes) { defer_head = true; HRall = h->res_buf; }
   }
   const bool i16 = inter16(h, flags);
   // projection with fp32 or bf16 output: ping-pong kernel for whole-chip shapes, the 128x128 kernel with a bf16-store epilogue below
@@ -1426,6 +1456,9 @@ extern "C" int prego_miniroad_check(prego_miniroad* h, prego_stream_t stream) {
     (void)hipMemset(h->abort_word, 0, sizeof ab);
     // codes: 1 = the recurrence's gather / rendezvous; 3 = the recurrence of a split pass
     // waiting for its input projection; 0x100 + k = wait k of the feed-forward launch of a split pass (ff_pass.hip)
+    if (ab == 0x200u)       // prego_miniroad_set_peer_guard: raised by the guarded AdamW step, not by a kernel of this handle
+      return fail(PREGO_ETIMEOUT, "data-parallel training: a recurrence / BPTT kernel of ANOTHER rank timed out; every rank skipped the optimizer "
+                  "steps from that one on (weights unchanged since the last good step) [code 0x200]");
     if (ab >= 2) {
       // a wait INSIDE a split pass ran out although its start handshake had seen both launches resident (launches that cannot run side by
       // side never get this far: they leave at the handshake and the call is re-run chunked, prego_miniroad_forward).  A stuck workgroup or a
@@ -1993,8 +2026,8 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
   for (int i = 0; i < 10; ++i) if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]) return fail(PREGO_EINVAL, "adamw: tensor %d is NULL", i);
   // guarded by the handle's timeout word: after a forward / backward that gave up, the step changes nothing (the add / copy below then
   // rebuild the same derived vectors from the unchanged biases)
-  if (launch_adamw(4, pw, gw, mw, vw, cw, nw, h->bf16, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word) ||
-      launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word))
+  if (launch_adamw(4, pw, gw, mw, vw, cw, nw, h->bf16, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word, h->peer_guard) ||
+      launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word, h->peer_guard))
     return fail(PREGO_EINVAL, "adamw: bad step %lld", (long long)step);
   launch_add_vec(params[6], params[7], h->bias2, (int)(3 * H), (int)(2 * H), s);      // r,z rows: b_ih + b_hh ; n rows: b_ih
   HIPCHK(hipMemcpyAsync(h->b_hn, params[7] + 2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));

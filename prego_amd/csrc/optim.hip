@@ -27,8 +27,14 @@ struct AdamTable { AdamDesc d[ADAM_MAX_TENSORS]; int n; };
 // timeout word: a step whose recurrence / BPTT gave up (garbage gradients) then leaves parameters, moments and operand copies as they
 // were, whether or not the host has looked at the word yet - the training loop needs no synchronisation in front of optimizer.step()
 __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, const unsigned* __restrict__ guard) {
+                                                    float bc2_sqrt, unsigned* __restrict__ guard, const float* __restrict__ peer) {
   if (guard && __hip_atomic_load(guard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  // peer (nullable): the ranks' timeout flags summed by the gradient all-reduce (prego_miniroad_guard_publish).  Non-zero (or NaN) = some
+  // rank's step gave up: every rank skips the step and raises its own word, so that every rank's check() reports it at the same step
+  if (peer && !(*peer == 0.0f)) {
+    if (guard && blockIdx.x == 0 && threadIdx.x == 0) atomicCAS(guard, 0u, 0x200u);
+    return;
+  }
   int ti = 0;
   for (int i = 1; i < tab.n; ++i) if ((int)blockIdx.x >= tab.d[i].block0) ti = i;      // <= 24 scalar compares
   const AdamDesc d = tab.d[ti];
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamTable tab, float lr, flo
 // copies[i] nullable; copy_bf16: element type of every non-NULL copy.  Returns 0, or -1 on a bad argument.
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,
-                 float wd, hipStream_t s, const unsigned* guard) {
+                 float wd, hipStream_t s, unsigned* guard, const float* peer) {
   if (n_tensors <= 0 || step <= 0) return -1;
   const float bc1 = 1.0f - (float)pow((double)b1, (double)step);
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, (double)step));
@@ -98,7 +104,12 @@ int launch_adamw(int n_tensors, float* const* params, const float* const* grads,
       tab.d[i] = AdamDesc{params[k], grads[k], exp_avg[k], exp_avg_sq[k], cp, numel[k], blocks, (short)(copy_bf16 ? 1 : 0), vec};
       blocks += (int)((numel[k] + ADAM_ELEMS_PER_BLOCK - 1) / ADAM_ELEMS_PER_BLOCK);
     }
-    adamw_kernel<<<blocks, 256, 0, s>>>(tab, lr, b1, b2, eps, wd, bc1, bc2_sqrt, guard);
+    adamw_kernel<<<blocks, 256, 0, s>>>(tab, lr, b1, b2, eps, wd, bc1, bc2_sqrt, guard, peer);
   }
   return 0;
 }
+
+__global__ void guard_publish_kernel(const unsigned* __restrict__ abort_word, float* __restrict__ dst) {
+  dst[0] = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.0f : 0.0f;
+}
+void launch_guard_publish(const unsigned* abort_word, float* dst, hipStream_t s) { guard_publish_kernel<<<1, 1, 0, s>>>(abort_word, dst); }

@@ -65,6 +65,7 @@ class MiniRoadEngine:
         self.num_layers = int(num_layers)
         self.max_clips = self.lib.prego_miniroad_max_clips(self.h)
         self._ws: Optional[torch.Tensor] = None
+        self._res: Optional[torch.Tensor] = None          # whole-call relu(h) buffer (prego_miniroad_set_resident): torch's allocator owns it
         # fp16x2 rows are 34 KB (fp32 intermediates, split operands): 32 768 rows measured best there (262.6 against 269.4 ms per pass
         # at 49 152; scripts/probes/chunk_sweep3.sh); the 16-bit modes are flat between 32 768 and 49 152 (120.2 / 120.4 ms)
         self.rows_per_chunk = 32768 if compute_dtype == "fp16x2" else 49152
@@ -109,6 +110,19 @@ class MiniRoadEngine:
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def _resident(self, n_clips, lens_arr, flags):
+        """The whole-call buffer a long inference call needs for the once-per-pass classifier / the split pass (include/prego_amd.h,
+        ABI 7): sized by the library's query, allocated HERE by torch's caching allocator (stream-ordered: no hipMalloc and no
+        synchronisation inside prego_miniroad_forward), grown with 1/8 of slack and kept for the following calls."""
+        need = self.lib.prego_miniroad_resident_bytes(self.h, n_clips, lens_arr, flags)
+        if need and (self._res is None or self._res.numel() < need):
+            try:
+                res = torch.empty(need + need // 8, dtype=torch.uint8, device=self.device)
+            except torch.OutOfMemoryError:
+                return            # no room beside the caller's tensors: the call runs the chunked pass with the per-chunk classifier
+            check(self.lib.prego_miniroad_set_resident(self.h, C.c_void_p(res.data_ptr()), res.numel()))
+            self._res = res       # the old buffer goes back to the allocator of the same stream: work already enqueued on it finishes first
 
     def forward_ragged(self, rgb: Sequence[torch.Tensor], flow: Optional[Sequence[Optional[torch.Tensor]]],
                        softmax: bool = True, want_out: bool = True, want_argmax: bool = False,
@@ -190,6 +204,8 @@ class MiniRoadEngine:
         lens_arr = (C.c_int32 * n)(*lens)
         flags = (_lib.FWD_SOFTMAX if softmax else 0) | (_lib.FWD_IN16 if dt != torch.float32 else 0)
         ws = self._workspace(n, lens_arr, flags)
+        if h0 is None and h_last is None:
+            self._resident(n, lens_arr, flags)
         rgb_p = None if rgb is None else ptr_array([r.data_ptr() for r in rgb])
         flow_p = None if flow is None else ptr_array([None if f is None else f.data_ptr() for f in flow])
         out_p = arg_p = None
@@ -326,7 +342,10 @@ class MiniRoadEngine:
         # all-reduces the bucket in place (no gather / scatter copies around the collective)
         sizes = [int(torch.Size(shapes[k]).numel()) for k in _PARAM_ORDER]
         offs, total = [], 0
-        for n in sizes:
+        guard_off = None
+        for k, n in zip(_PARAM_ORDER, sizes):
+            if k == "gru.weight_ih_l0":             # end of the layer1 / LayerNorm bucket (the LAST one the backward finishes): one slot of
+                guard_off, total = total, total + 64    # 64 floats whose first element carries this rank's timeout flag through the all-reduce
             offs.append(total)
             total += (n + 63) // 64 * 64            # 256-byte aligned views
         self._grad_flat = torch.empty(total, dtype=torch.float32, device=self.device)   # every gradient tensor is overwritten by backward
@@ -334,7 +353,8 @@ class MiniRoadEngine:
         # buckets of the flat tensor in the order the backward finishes them (csrc/miniroad.cpp: head, GRU, then LayerNorm / layer1):
         # the first two are announced by events recorded inside the backward, the last one is final when backward returns
         o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
-        self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]
+        self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]       # bucket 2 ends with the guard slot
+        self._guard_off = guard_off
         self._grad_offsets = {k: (o, n) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}     # where each tensor lives in the flat bucket
         self._grad_events = None
         self._early_done = set()
@@ -355,6 +375,15 @@ class MiniRoadEngine:
                 self.h, B, lens_arr, dl_p, *[C.c_void_p(grads[k].data_ptr()) for k in _PARAM_ORDER],
                 C.c_void_p(self._ws_train.data_ptr()), self._ws_train.numel(),
                 C.c_void_p(self._ws_bwd.data_ptr()), self._ws_bwd.numel(), C.c_void_p(_stream_ptr(self.device))))
+            if self._grad_events is not None:
+                # data parallel: this rank's timeout flag rides in the last sub-bucket (summed over the ranks), and the fused AdamW step
+                # of EVERY rank is a no-op while the sum is non-zero (prego_miniroad_guard_publish / _set_peer_guard; advisor, round 5: a
+                # rank that gave up used to feed garbage into the other ranks' steps for up to CHECK_EVERY steps)
+                gp = self._grad_flat.data_ptr() + 4 * guard_off
+                check(self.lib.prego_miniroad_guard_publish(self.h, C.c_void_p(gp), C.c_void_p(_stream_ptr(self.device))))
+                check(self.lib.prego_miniroad_set_peer_guard(self.h, C.c_void_p(gp)))
+            else:
+                check(self.lib.prego_miniroad_set_peer_guard(self.h, None))
         if self._cb_error is not None:
             e, self._cb_error = self._cb_error, None
             raise e

@@ -107,6 +107,8 @@ class FusedAdamW(torch.optim.Optimizer):
                         *hyper, C.c_void_p(_stream_ptr(dev))))
                     # the engine's operand copies are now those of the NEW values: bump the parameter versions (raw-pointer
                     # update) and record them as ingested, so model.engine() does not re-ingest
+                    # the data-parallel peer guard (engine.backward) pointed into THIS step's gradient bucket: one step, one flag
+                    check(lib.prego_miniroad_set_peer_guard(eng.h, None))
                     torch._C._increment_version(ps)
                     m._mark_ingested(train=True)
                 else:

@@ -109,10 +109,24 @@ def _check_engine(model):
     """A recurrence / BPTT spin timeout only sets the handle's abort word and makes the kernels return early, so the
     logits and gradients of that step are garbage: surface it (PregoError, PREGO_ETIMEOUT) BEFORE optimizer.step() - or, in the guarded
     loop (_guarded_epoch), behind a step the device skipped for the same reason.
-    `engine().check()` synchronises the stream - the reference loop syncs here anyway (`loss.item()`, train.py:26)."""
+    `engine().check()` synchronises the stream - the reference loop syncs here anyway (`loss.item()`, train.py:26).
+
+    Data-parallel runs: the check is COLLECTIVE.  Every rank's timeout flag travels in the last gradient sub-bucket (engine.backward:
+    guard slot, summed by the all-reduce), so after the reduction every rank knows whether ANY rank gave up: the fused AdamW step is a
+    no-op on all of them (prego_miniroad_set_peer_guard) and every rank raises here at the same step - the failing rank through its own
+    word, the others through the reduced flag - instead of one rank leaving and the rest hanging in the next collective with
+    garbage-averaged weights (advisor, round 5)."""
     eng = getattr(model, "_engine", None)
-    if eng is not None:
-        eng.check()
+    if eng is None:
+        return
+    eng.check()
+    off = getattr(eng, "_guard_off", None)
+    flat = getattr(eng, "_grad_flat", None)
+    if off is not None and flat is not None and getattr(eng, "_grad_events", None) is not None:
+        if float(flat[off]) != 0.0:        # the stream is synchronised: the reduced flag of this step (or of the step that tripped the guard)
+            from ._lib import PregoError
+            raise PregoError("data-parallel training: a recurrence / BPTT kernel of another rank timed out (PREGO_ETIMEOUT); "
+                             "no rank applied that step")
 
 
 PREFETCH = True        # train_one_epoch copies batch k + 1 to the device while step k runs (False: the reference's three blocking .to(device))

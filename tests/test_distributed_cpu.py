@@ -326,6 +326,87 @@ def test_train_one_epoch_bucketed_allreduce_matches_global_batch(kind):
             assert (a - b).abs().max().item() <= 1e-2 * step + 1e-7, ((a - b).abs().max().item(), step)
 
 
+class _GuardMROAD(_BucketMROAD):
+    """+ the engine's guard slot (engine.backward, ABI 7): one extra element at the end of the last sub-bucket that carries the rank's
+    "my kernels gave up" flag through the all-reduce; check() raises on the rank that gave up (its own timeout word)"""
+
+    def __init__(self, gave_up):
+        super().__init__()
+        e = self._engine
+        n = e._grad_flat.numel()
+        flat = torch.zeros(n + 4)
+        lo = e._grad_bounds[1]
+        e._grad_bounds = [(e._grad_bounds[0][0] + 4, n + 4), (0, lo[1] + 4)]      # [0, mid) + the slot | the rest, shifted
+        e._guard_off = lo[1]
+        e._grad_events = [None, None]
+        e._grad_flat = flat
+        ps = list(self.parameters())
+        offs, o = [], 0
+        for p in ps:
+            if o == lo[1]:
+                o += 4
+            offs.append(o)
+            o += p.numel()
+        for p in ps:
+            p._post_accumulate_grad_hooks.clear()
+        for p, o in zip(ps, offs):
+            def hook(param, o=o):
+                v = flat[o:o + param.numel()].view_as(param)
+                v.copy_(param.grad)
+                param.grad = v
+                flat[e._guard_off] = 1.0 if gave_up else 0.0          # what prego_miniroad_guard_publish enqueues behind the backward
+            p.register_post_accumulate_grad_hook(hook)
+
+        def check():
+            if gave_up:
+                from prego_amd._lib import PregoError
+                raise PregoError("GRU recurrence kernel timed out")
+        e.check = check
+
+
+def _guard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from prego_amd import distributed as D
+    from prego_amd._lib import PregoError
+    from prego_amd.trainer import train_one_epoch
+    D.init_from_env("gloo")
+    rgb, flow, tgt = _train_batches()
+    per = rgb.shape[0] // world
+    sl = slice(rank * per, (rank + 1) * per)
+    loader = [(rgb[sl], flow[sl], tgt[sl], ("v",) * per, torch.zeros(per), torch.zeros(per))] * 2
+    model = _GuardMROAD(gave_up=(rank == 1))
+    before = [p.detach().clone() for p in model.parameters()]
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    try:
+        train_one_epoch(loader, model, _oad_loss_torch, opt, None, 1, "cpu")
+        res = "no error"
+    except PregoError as e:
+        res = str(e)
+    moved = any(not torch.equal(a, b.detach()) for a, b in zip(before, model.parameters()))
+    q.put((rank, res, moved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_timeout_on_one_rank_raises_on_every_rank_before_any_step():
+    """advisor, round 5: a rank whose recurrence / BPTT gave up used to raise ALONE (the others applied garbage-averaged gradients
+    and hung in the next collective).  The flag now rides in the gradient bucket: rank 1 gives up, BOTH ranks raise PregoError at that
+    step's check - rank 1 through its own word, rank 0 through the reduced flag - and neither has moved a weight."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (res, moved)) for r, res, moved in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "timed out" in got[1][0] and not got[1][1]
+    assert "another rank" in got[0][0] and not got[0][1], got[0]
+
+
 def test_epoch_window_sampler_partitions_and_reshuffles():
     from prego_amd.data import EpochWindowSampler
 

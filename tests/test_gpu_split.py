@@ -280,3 +280,57 @@ def test_three_failed_handshakes_keep_the_handle_chunked(weights):
     assert state()["env"] == 0
     _, a, info = _run(eng, rgb, None, softmax=True, want_out=False, want_argmax=True)
     assert info["mode"] == 0
+
+
+def test_forward_allocates_nothing_for_the_whole_call_buffer(weights):
+    """ABI 7 ("no allocation of caller-visible memory, workspace sized by a query and passed in; no hidden sync"): relu(h) of
+    the whole call - what the once-per-pass classifier and the split pass need - is the CALLER's buffer (prego_miniroad_resident_bytes /
+    _set_resident; the engine allocates it through torch).  On the debug library, which counts every hipMalloc of the MiniROAD host code:
+    a second, LARGER call and a repeat perform no device allocation inside prego_miniroad_forward, the passes still run split, and a
+    handle whose buffer is too small for a call runs the chunked pass with the per-chunk classifier - the same bits."""
+    import ctypes as C
+    cfg, sd = weights
+    lens_a = _lens(64, 3900, 4400, 41)
+    lens_b = [T + 700 for T in lens_a]                          # the larger call
+    assert sum(lens_a) >= 262144
+    rgb_b = [_feat((T, 2048), 2100 + i, torch.float16) for i, T in enumerate(lens_b)]
+    rgb_a = [r[:T] for r, T in zip(rgb_b, lens_a)]
+    _, e0 = _engine(sd, cfg, "fp16", "0")
+    ref_a, _, _ = _run(e0, rgb_a, None, softmax=True, want_out=True, want_argmax=False)
+    ref_b, _, _ = _run(e0, rgb_b, None, softmax=True, want_out=True, want_argmax=False)
+    eng, dbg, _ = _debug_engine(sd, cfg, "fp16", "3")
+
+    def counts():
+        m, w = C.c_int64(), C.c_int64()
+        assert dbg.prego_debug_alloc_count(C.byref(m), C.byref(w)) == 0
+        return m.value, w.value
+    _run(eng, rgb_a, None, softmax=True, want_out=True, want_argmax=False)           # placement (chunked), resident buffer of call A registered
+    need_a = dbg.prego_miniroad_resident_bytes(eng.h, len(lens_a), (C.c_int32 * len(lens_a))(*lens_a), 1 | 4)
+    need_b = dbg.prego_miniroad_resident_bytes(eng.h, len(lens_b), (C.c_int32 * len(lens_b))(*lens_b), 1 | 4)
+    assert need_a >= sum(lens_a) * 2048 and need_b > need_a and eng._res.numel() >= need_a
+    o, _, info = _run(eng, rgb_a, None, softmax=True, want_out=True, want_argmax=False)
+    assert info["mode"] == 3
+    m0, w0 = counts()
+    torch.cuda.synchronize()
+    o, _, info = _run(eng, rgb_b, None, softmax=True, want_out=True, want_argmax=False)     # larger: the ENGINE grows the buffer (torch), not the library
+    m1, w1 = counts()
+    assert info["mode"] == 3 and eng._res.numel() >= need_b
+    assert m1 == m0, f"prego_miniroad_forward allocated device memory {m1 - m0} times on a larger call"
+    assert all(torch.equal(x, y) for x, y in zip(o, ref_b))
+    o, _, info = _run(eng, rgb_b, None, softmax=True, want_out=True, want_argmax=False)
+    m2, w2 = counts()
+    assert m2 == m1 and info["mode"] == 3
+    assert w2 - w1 <= 1, f"a steady-state forward + check waited {w2 - w1} times on the host (check()'s own synchronisation is the one)"
+    # a buffer that is too small: chunked pass, per-chunk classifier, same bits; none at all: likewise
+    small = torch.empty(need_a // 2 // 256 * 256, dtype=torch.uint8, device="cuda")
+    for buf in (small, None):
+        assert dbg.prego_miniroad_set_resident(eng.h, None if buf is None else C.c_void_p(buf.data_ptr()), 0 if buf is None else buf.numel()) == 0
+        eng._res = torch.empty(1 << 40, dtype=torch.uint8, device="meta")            # the engine believes it is large enough: it will not re-register
+        o, _, info = _run(eng, rgb_a, None, softmax=True, want_out=True, want_argmax=False)
+        assert info["mode"] == 0
+        assert all(torch.equal(x, y) for x, y in zip(o, ref_a))
+    assert counts()[0] == m2
+    # misuse
+    assert dbg.prego_miniroad_set_resident(eng.h, C.c_void_p(small.data_ptr() + 64), 1024) < 0          # not 256-byte aligned
+    assert dbg.prego_miniroad_set_resident(eng.h, None, 1024) < 0
+    eng._res = None

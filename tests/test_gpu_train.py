@@ -307,6 +307,75 @@ def test_fused_adamw_step_is_a_noop_while_the_timeout_word_is_set():
     eng.check()
 
 
+def test_adamw_step_peer_guard_stops_every_rank():
+    """Data-parallel guard (ABI 7; advisor, round 5): a rank whose kernels gave up still takes part in the gradient all-reduce, so the
+    guard must be collective.  prego_miniroad_guard_publish writes this handle's flag (1.0 / 0.0) into an element of the gradient bucket;
+    with prego_miniroad_set_peer_guard pointing at the (summed) element, a non-zero value makes prego_miniroad_adamw_step a no-op on a
+    HEALTHY handle too, raises that handle's own word - so the following steps are skipped as well - and check() names the other rank."""
+    import ctypes as C
+    from prego_amd import _lib
+    from prego_amd._lib import PregoError, ptr_array
+    from prego_amd.config import FEATURE_SIZES
+    from prego_amd.engine import MiniRoadEngine, _PARAM_ORDER
+    dbg = _lib.load_debug()
+    cfg = assembly101_cfg(compute_dtype="bf16")
+    sd = W.miniroad_state_dict(cfg, 20)
+    eng = MiniRoadEngine(FEATURE_SIZES[cfg["rgb_type"]], FEATURE_SIZES[cfg["flow_type"]], cfg["embedding_dim"], cfg["hidden_dim"],
+                         cfg["num_classes"], "cuda:0", "bf16", lib=dbg)
+    params = {k: torch.from_numpy(sd[k]).cuda() for k in _PARAM_ORDER}
+    eng.set_weights(params)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    grads = {k: torch.randn(v.shape, device="cuda", generator=g) * 1e-2 for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in params.items()}
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step(n):
+        rc = dbg.prego_miniroad_adamw_step(eng.h, ptr_array([params[k].data_ptr() for k in _PARAM_ORDER]),
+                                           ptr_array([grads[k].data_ptr() for k in _PARAM_ORDER]), ptr_array([m[k].data_ptr() for k in _PARAM_ORDER]),
+                                           ptr_array([v2[k].data_ptr() for k in _PARAM_ORDER]), n, 1e-3, 0.9, 0.999, 1e-8, 0.05, s)
+        assert rc == 0, dbg.prego_last_error()
+    flag = torch.full((64,), 7.0, device="cuda")
+    # publish: 0.0 on a healthy handle, 1.0 while the word is set
+    assert dbg.prego_miniroad_guard_publish(eng.h, C.c_void_p(flag.data_ptr()), s) == 0
+    assert flag[0].item() == 0.0 and flag[1].item() == 7.0
+    assert dbg.prego_debug_set_abort(eng.h, 1, s) == 0
+    assert dbg.prego_miniroad_guard_publish(eng.h, C.c_void_p(flag.data_ptr()), s) == 0
+    assert flag[0].item() == 1.0
+    with pytest.raises(PregoError):
+        eng.check()
+    eng.check()
+    # the reduced flag of "some other rank gave up" on a healthy handle: (1 + 0) / world, whatever the scaling
+    before = {k: p.clone() for k, p in params.items()}
+    flag[0] = 0.5
+    assert dbg.prego_miniroad_set_peer_guard(eng.h, C.c_void_p(flag.data_ptr())) == 0
+    step(1)
+    flag[0] = 0.0                                      # the next step's flag is clean - but this handle's own word is raised by now
+    step(1)
+    torch.cuda.synchronize()
+    for k in params:
+        assert torch.equal(params[k], before[k]), k
+        assert not m[k].any() and not v2[k].any(), k
+    with pytest.raises(PregoError, match="ANOTHER rank"):
+        eng.check()
+    eng.check()
+    step(1)                                            # flag 0.0, word cleared: the step applies
+    torch.cuda.synchronize()
+    assert all(not torch.equal(params[k], before[k]) for k in params)
+    flag[0] = float("nan")                             # a NaN that leaked into the bucket counts as "gave up"
+    mid = {k: p.clone() for k, p in params.items()}
+    step(2)
+    torch.cuda.synchronize()
+    assert all(torch.equal(params[k], mid[k]) for k in params)
+    with pytest.raises(PregoError):
+        eng.check()
+    assert dbg.prego_miniroad_set_peer_guard(eng.h, None) == 0
+    step(2)
+    torch.cuda.synchronize()
+    assert all(not torch.equal(params[k], mid[k]) for k in params)
+    eng.check()
+
+
 def test_empty_clip_list_is_a_noop():
     cfg = assembly101_cfg()
     sd = W.miniroad_state_dict(cfg, 20)

@@ -18,7 +18,7 @@ def test_abi_library_builds_loads_and_exports_every_declared_symbol():
     ge.build()
     from prego_amd import _lib
     lib = _lib.load()
-    assert lib.prego_abi_version() == 6
+    assert lib.prego_abi_version() == 7
     hdr = open(os.path.join(ROOT, "include", "prego_amd.h")).read()
     declared = sorted(set(re.findall(r"\b(prego_[a-z0-9_]+)\s*\(", hdr)))
     assert declared, "no declarations found"
@@ -170,7 +170,7 @@ def test_host_average_precision_matches_sklearn_with_ties():
     gt[:, 6] = 0                                     # class without positives
     ap = average_precision_columns(pr, gt != 0)
     for c in range(Cn):
-        if c == 6:
+        if c == 7:
             assert np.isnan(ap[c])
         else:
             assert abs(ap[c] - average_precision_score(gt[:, c], pr[:, c])) < 1e-12, c
