@@ -10,7 +10,11 @@ default (`dtype` in the line; the same width, bytes and matrix rate as the bf16 
 DESIGN.md section 3); the same line carries `value_bf16`, `value_fp16x2` (split operands: argmax-identical to the reference)
 and `value_fp32`.
 With --gpus N every rank owns its own clip set of that size (clip-sharded data parallel, no collective on the
-data path): weak scaling.  Rank 0 prints ONE JSON line.
+data path): weak scaling, the default.  `--scaling strong` shards the ONE 182-clip set over the ranks instead
+(data.shard_clips: longest first onto the lightest rank) and reports the frames of that one set / the slowest rank's
+time - bounded by the longest clip's sequential steps (prego_amd/cost_model.py).  Every line carries
+`per_rank` (frames, clips, sequential steps, ms) and `predicted` (the cost model's N = 1/2/4/8 table, weak and strong).
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -40,6 +44,9 @@ def parse():
     ap.add_argument("--mode", default="eval", choices=["eval", "train"],
                     help="eval = the headline metric (per-frame inference); train = BASELINE configs[2]: data-parallel training steps "
                          "(fwd + OadLoss + BPTT + bucketed gradient all-reduce over RCCL + fused AdamW), global batch fixed (strong scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="--mode eval with --gpus N: weak = every rank its own eval-set-sized clip list (per-GPU work fixed); strong = ONE "
+                         "eval set sharded over the ranks (total work fixed; bounded by the longest clip, see DESIGN.md section 10)")
     ap.add_argument("--global-batch", type=int, default=16, help="--mode train: windows per step over all ranks (configs/miniroad_assembly101-O.yaml: 16)")
     ap.add_argument("--local-batch", type=int, default=0, help="--mode train: windows per step PER RANK (weak scaling: the global batch grows with N); "
                                                                "0 = split --global-batch over the ranks")
@@ -93,6 +100,18 @@ def dry_run(args, rank, world):
     print(f"[bench] rank {rank}: dist.get_world_size() = {dist.get_world_size()}", file=sys.stderr, flush=True)
     assert dist.get_world_size() == world == args.gpus and float(t.item()) == world
     line = {"metric": "dry-run", "value": None, "n_gpus": world, "steps": 0, "dry_run": True, "mode": args.mode}
+    if args.mode == "eval":
+        # the clip lists the ranks WOULD run (no GPU work): gathered the way the timed run gathers them, with the cost model's table
+        from prego_amd import cost_model as CM
+        lens, frames_set = eval_clip_list(args, rank, world)
+        p = CM.predict_eval_pass_ms(lens)
+        mine = torch.tensor([float(sum(lens)), float(len(lens)), float(max(lens) if lens else 0), float(p["sequential_steps"])], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        line.update(scaling=args.scaling, frames_per_step_all_ranks=int(sum(int(a[0]) for a in allr)), frames_of_the_set=frames_set,
+                    per_rank={"frames": [int(a[0]) for a in allr], "clips": [int(a[1]) for a in allr], "longest_clip": [int(a[2]) for a in allr],
+                              "predicted_sequential_steps": [int(a[3]) for a in allr]},
+                    predicted=predicted_tables(args))
     if args.mode == "train":
         from prego_amd.distributed import allreduce_mean_buckets_
         n = GRAD_BUCKET_ELEMS
@@ -107,6 +126,37 @@ def dry_run(args, rank, world):
     if rank == 0:
         print(json.dumps(line), flush=True)
     dist.destroy_process_group()
+
+
+def eval_clip_list(args, rank, world):
+    """(clip lengths of this rank, frames of one eval set).  weak: the eval-set-sized list on EVERY rank (the same lengths, so the
+    per-GPU work is exactly fixed as N grows; feature values differ per rank); strong: this rank's shard of the one list."""
+    from prego_amd.data import shard_clips
+    from prego_amd.workloads import assembly101_eval_lengths
+    if args.workload == "synth512":
+        lens = [512] * 512
+    else:
+        lens = assembly101_eval_lengths(seed=20)
+    if args.clips:
+        lens = lens[: args.clips]
+    lens = [max(1, int(l * args.len_scale)) for l in lens]
+    total = int(sum(lens))
+    if args.scaling == "strong" and world > 1:
+        lens = [lens[i] for i in shard_clips(lens, world, rank)]
+    return lens, total
+
+
+def predicted_tables(args):
+    """the cost model's N = 1 / 2 / 4 / 8 table for this workload (prego_amd/cost_model.py): what the driver's SCALE file is to be held against"""
+    from prego_amd import cost_model as CM
+    if args.mode == "train":
+        return {"train": CM.predict_train_scaling(args.global_batch, args.local_batch or 16), "model": "prego_amd/cost_model.py"}
+    import copy
+    a = copy.copy(args)
+    a.scaling = "weak"
+    lens, _ = eval_clip_list(a, 0, 1)
+    t = CM.predict_eval_scaling(lens)
+    return {"eval": t, "model": "prego_amd/cost_model.py (the library's pass-choice constants x round-5 measured / estimated ratios)"}
 
 
 def train_mode(args, rank, world, dev, dist):
@@ -176,7 +226,7 @@ def train_mode(args, rank, world, dev, dist):
             "roofline": {"bound": "mfma", "achieved": fl / step_ms / 1e9 / world, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": fl / step_ms / 1e9 / world / PEAK_BF16_TFLOPS,
                          "note": "per GPU; 3 x forward FLOPs over the whole step; 128 sequential BPTT steps: latency-bound", "traffic": None},
-            "final_loss_sum": float(loss)}), flush=True)
+            "predicted": predicted_tables(args), "final_loss_sum": float(loss)}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -227,13 +277,10 @@ def main():
         eng.rows_per_chunk = args.rows_per_chunk
 
     synth = args.workload == "synth512"
-    if synth:       # BASELINE configs[4]: 4096 clips x 512 frames over 8 GPUs = 512 clips per GPU; the flow half is zeros and is
-        lens = [512] * 512      # never materialised, so the zero-flow fast path IS this workload
-    else:
-        lens = assembly101_eval_lengths(seed=20 + rank)
-    if args.clips:
-        lens = lens[: args.clips]
-    lens = [max(1, int(l * args.len_scale)) for l in lens]
+    # synth512 = BASELINE configs[4]: 4096 clips x 512 frames over 8 GPUs = 512 clips per GPU; the flow half is zeros and is never
+    # materialised, so the zero-flow fast path IS this workload
+    lens, frames_set = eval_clip_list(args, rank, world)
+    strong = args.scaling == "strong" and world > 1
     frames = int(sum(lens))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -270,11 +317,22 @@ def main():
     eng.timing_enable(False)
     eng.check()
     pinfo = eng.pass_info()          # mode 0: chunked pass; R > 0: split pass (recurrence on R XCDs beside one feed-forward launch on the rest)
+    dt_rank = dt
+    per_rank = {"frames": [frames], "clips": [len(lens)], "sequential_steps": [pinfo["steps"]], "pass_mode": [pinfo["mode"]],
+                "ms_per_step": [dt / args.steps * 1e3]}
     if dist is not None:
+        mine = torch.tensor([float(frames), float(len(lens)), float(pinfo["steps"]), float(pinfo["mode"]), dt_rank / args.steps * 1e3],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"frames": [int(a[0]) for a in allr], "clips": [int(a[1]) for a in allr], "sequential_steps": [int(a[2]) for a in allr],
+                    "pass_mode": [int(a[3]) for a in allr], "ms_per_step": [float(a[4]) for a in allr]}
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    value = world * frames * args.steps / dt
+    frames_all = sum(per_rank["frames"])            # weak: N eval sets; strong: the one set (its shards add up to it)
+    assert not strong or frames_all == frames_set
+    value = frames_all * args.steps / dt
 
     extra = {}
     if not args.no_zero_flow and not synth:
@@ -283,7 +341,11 @@ def main():
         for _ in range(max(1, args.warmup)):
             step(None)
         dtz, _ = timed(None, args.steps)
-        extra["frames_per_s_zero_flow_fastpath"] = world * frames * args.steps / dtz
+        if dist is not None:
+            t = torch.tensor([dtz], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtz = float(t.item())
+        extra["frames_per_s_zero_flow_fastpath"] = frames_all * args.steps / dtz
 
     # sanity on the last output: probabilities sum to 1, argmax consistent
     probs, arg = out[0][0], out[1][0]
@@ -364,7 +426,7 @@ def main():
         line = {
             "metric": "frames/sec (per-frame action logits) on Assembly101-O TSN features",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": ({"workload": "BASELINE configs[4] per-GPU share: synthetic 512 clips x 512 frames x 2048-d rgb (4096 clips over 8 "
                                     "GPUs), MiniROAD eval path -> per-frame probs[86] + argmax",
@@ -375,8 +437,11 @@ def main():
                                     "(rgb+flow fp32 [T,2048] each -> per-frame probs[86] + argmax)",
                         "clips_per_gpu": len(lens), "frames_per_gpu": frames, "min_T": min(lens), "max_T": max(lens),
                         "lengths": "seeded draw from the Epic-tent-O length distribution (real Assembly101-O lengths unknown)",
-                        "flow": "non-zero (full K=4096 layer1 GEMM)", "parallelism": f"clip-sharded dp{world}, no collective",
+                        "flow": "non-zero (full K=4096 layer1 GEMM)",
+                        "parallelism": (f"clip-sharded dp{world}, no collective: the ONE eval set sharded over the ranks (longest clip first onto the lightest rank)"
+                                        if strong else f"clip-sharded dp{world}, no collective: every rank its own eval-set-sized clip list"),
                         "weights": "random init, seed 20"}),
+            "frames_per_step_all_ranks": frames_all, "per_rank": per_rank, "predicted": predicted_tables(args),
             # the kernel with the largest share of the timed region; every kernel's own roofline is under "rooflines"
             "roofline": dict(dominant, traffic_source=traffic_source),
             "rooflines": {"gemm": rl_gemm, "gru_recurrence": rl_gru, "pack": rl_pack},

@@ -238,6 +238,37 @@ def test_bench_train_mode_dry_run_reduces_a_real_size_bucket():
         assert line["grad_compress"] == (extra[1] if extra else None)
 
 
+def test_bench_strong_scaling_dry_run_shards_the_one_eval_set_over_eight_ranks():
+    """`bench.py --gpus 8 --scaling strong --dry-run` (gloo): the ONE 182-clip eval set is sharded over the ranks by data.shard_clips -
+    every clip on exactly one rank, loads within one clip of each other, the longest clip's frames a lower bound of some rank's
+    sequential steps - and the line carries `scaling`, per-rank frames / sequential steps and the cost model's N = 1/2/4/8 table;
+    `--scaling weak` gives every rank the whole list."""
+    import subprocess
+    import sys
+    from prego_amd.workloads import assembly101_eval_lengths
+    lens = assembly101_eval_lengths(seed=20)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for scaling in ("strong", "weak"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--scaling", scaling],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        pr = line["per_rank"]
+        assert line["n_gpus"] == 8 and line["scaling"] == scaling and len(pr["frames"]) == 8
+        if scaling == "strong":
+            assert sum(pr["frames"]) == sum(lens) == line["frames_per_step_all_ranks"] and sum(pr["clips"]) == len(lens)
+            assert max(pr["frames"]) - min(pr["frames"]) <= max(lens)
+            assert max(pr["longest_clip"]) == max(lens) and max(pr["predicted_sequential_steps"]) >= max(lens)
+        else:
+            assert pr["frames"] == [sum(lens)] * 8 and line["frames_per_step_all_ranks"] == 8 * sum(lens)
+        ev = line["predicted"]["eval"]
+        assert [row["n_gpus"] for row in ev["strong"]] == [1, 2, 4, 8] == [row["n_gpus"] for row in ev["weak"]]
+        # the documented bound: strong scaling of one eval set cannot beat one-GPU time / the longest clip's sequential floor
+        bound = ev["strong"][0]["ms_per_step"] / ev["strong_bound"]["floor_ms"]
+        assert all(row["speedup"] <= bound + 1e-9 for row in ev["strong"]) and ev["strong"][-1]["speedup"] < 2.0
+        assert ev["weak"][-1]["speedup"] > 6.5
+
+
 def _g9_tree(tmp_path):
     from prego_amd import weights as W
     lens = {"vidA": 300, "vidB": 157}
