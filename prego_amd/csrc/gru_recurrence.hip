@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     na_c = na_n; rb_c = rb_n; na_n = na_2; rb_n = rb_2;
     return true;
   };
+  const unsigned long long rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;       // 100 MHz: with the cycle sums below = this XCD's shader clock
   for (int tl = 0; tl < nsteps; tl += 2) {
     if (tfirst[0] >= na_c) break;             // every slot of this group has ended: leave, free the CU
     if (!step(tl, giA, giB)) return;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   if (stamp && lane == 0) {
     for (int i = 0; i < 6; ++i) a.stamps[i] += st_acc[i];
     a.stamps[6] += (unsigned long long)nsteps;
+    a.stamps[7] += __builtin_amdgcn_s_memrealtime() - rt0;
   }
 #undef STAMP
   if constexpr (PASS) {                       // this group is done with every remaining chunk

@@ -143,3 +143,30 @@ def attention_layer_state_dict(d_model: int, seed: int = 20) -> dict:
     for nm in ("query_projection", "key_projection", "value_projection", "out_projection"):
         sd[nm + ".weight"], sd[nm + ".bias"] = _lin((d_model, d_model), seed, "attnlayer." + nm)
     return sd
+
+
+# ---- fixture G11: TRAINED weights -----------------------------------------------------------------------------------------------
+G11_LEVELS = 7      # oracle/train_g11.py: the trained delta of every tensor on a 15-level grid, two levels per byte
+
+
+def g11_state_dict(tag: str, golden_dir: str | None = None) -> dict:
+    """The fixture model of G11: `miniroad_state_dict(cfg, seed 20)` + the de-quantised delta the imported reference's own training loop
+    produced (oracle/train_g11.py: `train_one_epoch`, AdamW lr 1e-4 wd 0.05, dropout 0.2, on `workloads.action_video` windows), read
+    from tests/golden/g11_weights_<tag>.npz.  tag: 'a101' (86 classes) or 'epic' (12).  Pure numpy, fp64 sums rounded once to fp32:
+    the same bits on every box - the reference's Evaluate produced tests/golden/g11_eval_<tag>.npz from exactly these tensors."""
+    import os
+    from .config import assembly101_cfg, epic_tent_cfg
+    cfg = {"a101": assembly101_cfg, "epic": epic_tent_cfg}[tag]()
+    if golden_dir is None:
+        golden_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    z = np.load(os.path.join(golden_dir, f"g11_weights_{tag}.npz"))
+    sd = miniroad_state_dict(cfg, seed=20)
+    out = {}
+    for k, w0 in sd.items():
+        packed = z["q." + k]
+        u = np.empty(packed.size * 2, np.uint8)
+        u[0::2] = packed & 15
+        u[1::2] = packed >> 4
+        q = u[: w0.size].astype(np.float64) - G11_LEVELS
+        out[k] = (w0.astype(np.float64).reshape(-1) + q * float(z["scale." + k])).astype(np.float32).reshape(w0.shape)
+    return out

@@ -1,6 +1,6 @@
 """Argmax bookkeeping of the north star ("identical argmax action sequences") against the reference fixtures, kept as data:
-for G1 (cfg1, plain and peaky head), G1c (head gain 32, trained-like), G2 (T = 4096 with flow, T = 31 114) and G7 (Evaluate end
-to end) in fp16, bf16, fp32 and fp16x2 (split-operand) modes: frames, argmax mismatches, the LARGEST reference top-1/top-2 margin among the mismatching frames (the
+for G1 (cfg1, plain and peaky head), G1c (head gain 32), G2 (T = 4096 with flow, T = 31 114), G7 (Evaluate end
+to end) and G11 (TRAINED weights, both shipped configs, four videos each incl. T = 31 114) in fp16, bf16, fp32 and fp16x2 (split-operand) modes: frames, argmax mismatches, the LARGEST reference top-1/top-2 margin among the mismatching frames (the
 "smallest margin that was still violated" bound: every frame whose margin exceeds it agrees), max |dprob|.
 
     python scripts/parity_report.py gpurun_out/parity_r04.json [fp16x2,fp32]     # on the GPU box; copy the file to profiles/
@@ -92,6 +92,29 @@ def main(out_path):
             tot["smallest_reference_margin"] = min(tot["smallest_reference_margin"], e["smallest_reference_margin"])
             tot["max_abs_dprob"] = max(tot["max_abs_dprob"], e["max_abs_dprob"])
         rep[f"g7_evaluate_{dtype}"] = tot
+        # G11: TRAINED weights (the reference's own training loop, oracle/train_g11.py), expected outputs from the reference's Evaluate
+        from prego_amd import workloads as WL
+        for tag, gcfg in (("a101", assembly101_cfg()), ("epic", epic_tent_cfg())):
+            g = np.load(os.path.join(G, f"g11_eval_{tag}.npz"))
+            gm = model(gcfg, W.g11_state_dict(tag), dtype)
+            vids = [WL.action_video(int(T), gcfg["num_classes"], 20, f"g11.{tag}.eval.{i}")[0] for i, T in enumerate(g["lengths"])]
+            outs, args, _ = gm.engine().forward_ragged([torch.from_numpy(v).cuda() for v in vids], None, want_argmax=True)
+            gm.engine().check()
+            tot = None
+            for i in range(len(vids)):
+                got = outs[i].cpu().numpy()
+                e = entry(args[i].cpu().numpy(), g[f"pred{i}"].astype(np.int32), g[f"margin{i}"],
+                          np.abs(got[g[f"sample_idx{i}"]] - g[f"sample_probs{i}"]).max())
+                if tot is None:
+                    tot = e
+                else:
+                    for k in ("frames", "argmax_mismatches", "mismatches_above_1e-3_margin"):
+                        tot[k] += e[k]
+                    for k in ("largest_margin_among_mismatches", "max_abs_dprob"):
+                        tot[k] = max(tot[k], e[k])
+                    tot["smallest_reference_margin"] = min(tot["smallest_reference_margin"], e["smallest_reference_margin"])
+            tot["reference_mAP"] = float(g["mAP"])
+            rep[f"g11_trained_{tag}_{dtype}"] = tot
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(rep, open(out_path, "w"), indent=1)
     print(json.dumps(rep, indent=1))

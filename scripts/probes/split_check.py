@@ -71,5 +71,6 @@ if os.environ.get("PREGO_GRU_STAMPS") and not os.environ.get("PREGO_SPLIT_STATS"
     steps = max(1, out[6])
     names = ["rest of gather + mfma", "step top -> first segment valid", "reduce+barrier", "gates+publish", "outputs"]
     tot = sum(out[i] for i in range(5))
-    print(f"recurrence workgroup 0 / wave 0 (s_memtime ticks of 10 ns per step, {steps} steps): total {tot/steps:.1f}: " +
-          ", ".join(f"{names[i]} {out[i]/steps:.1f}" for i in range(5)) + f"; retry rounds/step {out[5]/steps:.2f}", flush=True)
+    print(f"recurrence workgroup 0 / wave 0 (shader cycles per step, {steps} steps): total {tot/steps:.1f}: " +
+          ", ".join(f"{names[i]} {out[i]/steps:.1f}" for i in range(5)) + f"; retry rounds/step {out[5]/steps:.2f}; "
+          f"loop {out[7] / 100 / steps:.3f} us per step of real time -> shader clock of that XCD {tot / max(1, out[7]) * 100:.0f} MHz", flush=True)

@@ -320,7 +320,9 @@ def test_forward_allocates_nothing_for_the_whole_call_buffer(weights):
     o, _, info = _run(eng, rgb_b, None, softmax=True, want_out=True, want_argmax=False)
     m2, w2 = counts()
     assert m2 == m1 and info["mode"] == 3
-    assert w2 - w1 <= 1, f"a steady-state forward + check waited {w2 - w1} times on the host (check()'s own synchronisation is the one)"
+    # host waits of a steady-state forward + check: check()'s own synchronisation, and the event of the PREVIOUS call's pointer-table
+    # copy out of the handle's pinned staging buffer (long complete; include/prego_amd.h, conventions) - nothing that waits for this call
+    assert w2 - w1 <= 2, f"a steady-state forward + check waited {w2 - w1} times on the host"
     # a buffer that is too small: chunked pass, per-chunk classifier, same bits; none at all: likewise
     small = torch.empty(need_a // 2 // 256 * 256, dtype=torch.uint8, device="cuda")
     for buf in (small, None):

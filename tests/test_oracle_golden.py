@@ -300,3 +300,24 @@ def test_g5b_vit_training_step(layers):
         assert abs(np.linalg.norm(gg) - ref_norm) < 5e-4 * ref_norm + 1e-9, (k, np.linalg.norm(gg), ref_norm)
         ref = g["val." + k]
         assert np.abs(gg[g["idx." + k]] - ref).max() < 1e-7 + 5e-3 * np.abs(ref).max(), k
+
+
+@pytest.mark.parametrize("tag", ["a101", "epic"])
+def test_g11_trained_weights_oracle_vs_reference_evaluate(tag):
+    """G11 (round 6): weights that went through the reference's own training loop (oracle/train_g11.py), expected outputs from the
+    reference's own Evaluate.  The oracle on the two short videos: probabilities at the sampled frames and every argmax above a 1e-5
+    margin (fp64 oracle vs torch fp32)."""
+    from prego_amd import workloads as WL
+    g = _ld(f"g11_eval_{tag}.npz")
+    cfg = {"a101": assembly101_cfg, "epic": epic_tent_cfg}[tag]()
+    sd = W.g11_state_dict(tag)
+    z = _ld(f"g11_weights_{tag}.npz")
+    assert int(z["steps"]) >= 1000 and float(z["loss_curve"][-50:].mean()) < 0.5 * float(z["loss_curve"][:10].mean())     # it did train
+    for i in (0, 1):
+        T = int(g["lengths"][i])
+        rgb, lab = WL.action_video(T, cfg["num_classes"], 20, f"g11.{tag}.eval.{i}")
+        assert np.array_equal(lab, g[f"gt{i}"].astype(np.int64))
+        out = O.miniroad_forward(sd, rgb[None], None)["logits"][0]
+        assert np.abs(out[g[f"sample_idx{i}"]] - g[f"sample_probs{i}"]).max() < 2e-5
+        safe = g[f"margin{i}"] > 1e-5
+        assert np.array_equal(out.argmax(1)[safe], g[f"pred{i}"].astype(np.int64)[safe])
