@@ -529,7 +529,34 @@ def g10():
         print("g10", tag, "min margin", float(min(save["margin0"].min(), save["margin1"].min())))
 
 
-GROUPS = {"g10": g10, "g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
+def g4d():
+    """Training step at the hidden sizes the shipped yamls do not use (rnn.py:31-38 takes any hidden_dim; round-5 verdict "missing 2"):
+    hidden_dim 512 and 2048, full feature / embedding sizes, B = 5 windows x T = 24 frames (not a tile multiple), rgb + non-zero flow,
+    one all-zero and one multi-label last-frame target row, dropout 0: loss, last-frame logits, per-tensor gradient norms + sampled
+    entries (trainer/train.py:20-23)."""
+    from model import build_model
+    from criterions import build_criterion
+    B, T = 5, 24
+    for hid in (512, 2048):
+        cfg = assembly101_cfg(dropout=0.0, hidden_dim=hid)
+        sd = W.miniroad_state_dict(cfg, seed=20)
+        model = _load(build_model(cfg, "cpu"), sd).train()
+        crit = build_criterion(cfg, "cpu")
+        rgb = W.tsn_features((B, T, 2048), 20, f"g4d.{hid}.rgb")
+        flow = W.tsn_features((B, T, 2048), 20, f"g4d.{hid}.flow")
+        tgt = make_targets(B, T, 86, 20, f"g4d.{hid}.tgt")
+        tgt[1, -1] = 0.0
+        tgt[2, -1, 7] = 1.0
+        out = model(torch.from_numpy(rgb), torch.from_numpy(flow))
+        loss = crit(out, torch.from_numpy(tgt))
+        loss.backward()
+        save = {"loss": np.float64(float(loss)), "logits_last": out["logits"][:, -1, :].detach().numpy().copy()}
+        _grad_summary(model, save)
+        np.savez_compressed(os.path.join(OUT, f"g4d_miniroad_train_h{hid}.npz"), **save)
+        print("g4d", hid, "loss", float(loss))
+
+
+GROUPS = {"g4d": g4d, "g10": g10, "g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -32,6 +32,11 @@ class _MiniRoadTrainFn(torch.autograd.Function):
 
 
 def miniroad_train_forward(model, rgb_input, flow_input):
+    if model.num_layers != 1:
+        # fail fast and say what the limit is (advisor, round 5): construction, optimizer set-up and data loading of a two-layer model
+        # all succeed, and the run used to die in the C ABI at its first training forward
+        raise PregoError(f"MiniROAD training covers num_layers 1 (cfg['num_layers'] = {model.num_layers}): a stacked GRU runs inference "
+                         "only in this build - hidden_dim 512 / 1024 / 2048 train (2048: bf16 operands)")
     named = dict(model.named_parameters())
     params = [named[k] for k in _PARAM_ORDER]
     flow = flow_input if (model.use_flow and (not model.assume_zero_flow or not model.use_rgb)) else None

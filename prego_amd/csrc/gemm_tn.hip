@@ -188,26 +188,34 @@ __global__ __launch_bounds__(SPLITK ? 512 : 256, SPLITK ? 1 : 2) void gemm_bf16_
   };
 
   const int nk = K / TBK;
+  // The barrier that hands a staged tile to the fragment reads must see the LDS-DMA pieces LANDED: the transposed reads are inline asm
+  // without a memory operand (above), so nothing in the source tells the compiler that they read what stage() writes, and a
+  // workgroup-scope fence does not imply vmcnt on gfx9.  hipcc 7.2 happens to emit the wait in front of the loop's s_barrier (advisor,
+  // round 5: checked in the disassembly); the explicit wait makes it a property of the source instead of the toolchain.
+  auto landed_and_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
   if constexpr (!SPLITK) {
     stage(0, 0);
-    __syncthreads();
+    landed_and_sync();
     int cur = 0;
     for (int kt = 0; kt < nk - 1; ++kt) {
       stage(cur ^ 1, kt + 1);
       compute(cur);
-      __syncthreads();
+      landed_and_sync();
       cur ^= 1;
     }
     compute(cur);
   } else {
     const int rounds = (nk + 1) >> 1;                      // group g multiplies tile 2 i + g in round i (the last round may have none for g = 1)
     if (grp < nk) stage(0, grp);
-    __syncthreads();
+    landed_and_sync();
     int cur = 0;
     for (int i = 0; i < rounds; ++i) {
       if (2 * (i + 1) + grp < nk) stage(cur ^ 1, 2 * (i + 1) + grp);
       if (2 * i + grp < nk) compute(cur);
-      __syncthreads();
+      landed_and_sync();
       cur ^= 1;
     }
     // the odd tiles' sums join the even ones through LDS (both groups are past their last fragment read): 64 KB of accumulators into

@@ -303,22 +303,24 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
 
 size_t gru_bptt_hx_bytes(bool bf16, int hid, int G) { return (size_t)BPTT_BUFS * G * (3 * hid / (bf16 ? 32 : 16)) * BPTT_MAX_TILES * 1024; }
 
-// returns 0 on success, -1 for an unsupported shape (the caller falls back to the step-by-step loop)
-int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
-  if (hid != 1024 || nct > BPTT_MAX_TILES) return -1;
-  const int P = bf16 ? 32 : 64;
+// returns 0 on success, -1 for an unsupported shape (the caller falls back to the step-by-step loop).  Hidden sizes 1024 and 512, bf16
+// (32 units per workgroup) or fp32 (16) operands.  hidden_dim 2048 trains through the step-by-step loop: its workgroups would own 16
+// units (3 x 2048 / 4 columns of W_hh^T per wave = 192 registers), i.e. ONE bf16 element per lane - the exchange below publishes, resets
+// and validates 32-bit words (a lane's bf16 PAIR), a word shared by two waves would look published when half of it is
+template <int HID>
+static int launch_gru_bptt_hid(bool bf16, int nct, const BpttArgs& a, hipStream_t s) {
+  constexpr int UTB = 2;
+  const int P = HID / (bf16 ? 16 * UTB : 16);
   const int grid = a.G * P;
-  (void)hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), s);      // [0,64): placement words
-  (void)hipMemsetAsync(a.hx, 0xFF, gru_bptt_hx_bytes(bf16, hid, a.G), s);      // every word "not yet published"
 #define LAUNCHB(WT, UT, NCT)                                                                       \
   do {                                                                                             \
     const size_t lds = (size_t)2 * 4 * UT * 64 * 16;                                               \
-    gru_bptt_kernel<WT, 1024, UT, NCT><<<grid, 256, lds, s>>>(a);                                  \
+    gru_bptt_kernel<WT, HID, UT, NCT><<<grid, 256, lds, s>>>(a);                                   \
   } while (0)
   if (bf16) {
-    if (nct == 1) LAUNCHB(bf16_t, 2, 1);
-    else if (nct == 2) LAUNCHB(bf16_t, 2, 2);
-    else LAUNCHB(bf16_t, 2, 4);
+    if (nct == 1) LAUNCHB(bf16_t, UTB, 1);
+    else if (nct == 2) LAUNCHB(bf16_t, UTB, 2);
+    else LAUNCHB(bf16_t, UTB, 4);
   } else {
     if (nct == 1) LAUNCHB(float, 1, 1);
     else if (nct == 2) LAUNCHB(float, 1, 2);
@@ -326,4 +328,11 @@ int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
   }
 #undef LAUNCHB
   return 0;
+}
+
+int launch_gru_bptt(bool bf16, int hid, int nct, BpttArgs a, hipStream_t s) {
+  if ((hid != 1024 && hid != 512) || nct > BPTT_MAX_TILES) return -1;
+  (void)hipMemsetAsync(a.sync, 0, 1024 * sizeof(unsigned), s);      // [0,64): placement words
+  (void)hipMemsetAsync(a.hx, 0xFF, gru_bptt_hx_bytes(bf16, hid, a.G), s);      // every word "not yet published"
+  return hid == 1024 ? launch_gru_bptt_hid<1024>(bf16, nct, a, s) : launch_gru_bptt_hid<512>(bf16, nct, a, s);
 }

@@ -1097,6 +1097,23 @@ static int launch_gru_recurrence_other(bool bf16, int nct, const GruArgs& a, int
     else gru_recurrence_kernel<WT, HID, UT, NCT, false><<<grid, 256, lds, s>>>(a);                                \
   } while (0)
   constexpr int UTB = HID <= 1024 ? 2 : 1;
+  // training (round 6: rnn.py:31-38 takes any hidden_dim, and so does trainer/train.py): the instantiation that keeps the gate
+  // activations / raw state for BPTT (fp32 GI; bf16 or - H = 512 - exact-fp32 operands)
+  if (a.keep_r != nullptr || a.h_raw_out != nullptr) {
+#define LAUNCH_T(WT, UT, NCT)                                                                                    \
+    do {                                                                                                           \
+      const size_t lds = (size_t)2 * 4 * 3 * UT * 64 * 16;                                                         \
+      gru_recurrence_kernel<WT, HID, UT, NCT, true><<<grid, 256, lds, s>>>(a);                                    \
+    } while (0)
+    if (a.gi_bf16 || a.f16) return -1;
+    if (bf16) { if (nct == 1) LAUNCH_T(bf16_t, UTB, 1); else if (nct == 2) LAUNCH_T(bf16_t, UTB, 2); else if (nct <= 4) LAUNCH_T(bf16_t, UTB, 4); else return -1; }
+    else {
+      if constexpr (HID > 512) return -1;
+      else { if (nct == 1) LAUNCH_T(float, 1, 1); else if (nct == 2) LAUNCH_T(float, 1, 2); else if (nct <= 4) LAUNCH_T(float, 1, 4); else return -1; }
+    }
+#undef LAUNCH_T
+    return 0;
+  }
   if (bf16) {
     if (!a.gi_bf16) return -1;                 // 16-bit operands run with 16-bit GI (inference)
     if (a.f16) { if (nct == 1) LAUNCH_O(f16_t, UTB, 1); else if (nct == 2) LAUNCH_O(f16_t, UTB, 2); else if (nct <= 4) LAUNCH_O(f16_t, UTB, 4); else return -1; }
@@ -1115,7 +1132,6 @@ bool gru_hidden_supported(bool bf16, int hid) { return hid == 1024 || hid == 512
 int launch_gru_recurrence(bool bf16, int hid, int nct, GruArgs a, hipStream_t s) {
   if (hid != 1024) {
     if (!gru_hidden_supported(bf16, hid)) return -1;
-    if (a.keep_r != nullptr || a.h_raw_out != nullptr) return -1;          // training keeps hidden_dim 1024
     if (!a.armed) gru_arm_kernel<<<256, 256, 0, s>>>((unsigned*)a.hx, gru_hx_bytes(bf16, hid, a.G) / 2 / 4, bf16 ? 0x40004000u : 0x40000000u, a.sync);
     const int grid = a.G * gru_group_size(bf16, hid);
     return hid == 512 ? launch_gru_recurrence_other<512>(bf16, nct, a, grid, s) : launch_gru_recurrence_other<2048>(bf16, nct, a, grid, s);

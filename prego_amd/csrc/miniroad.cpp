@@ -1002,8 +1002,11 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "forward before set_weights");
   if (h->layers == 2 && !h->have_layer2) return fail(PREGO_EINVAL, "forward of a 2-layer handle before set_gru_layer(1)");
-  if ((flags & PREGO_FWD_KEEP) && (h->hid != 1024 || h->layers != 1))
-    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with hidden_dim %d / num_layers %d: the training kernels (kept gates, BPTT) are built for 1024 / 1", h->hid, h->layers);
+  if ((flags & PREGO_FWD_KEEP) && h->layers != 1)
+    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with num_layers %d: the training path (kept gates, BPTT, weight gradients) covers one GRU layer "
+                "(hidden_dim 512 / 1024 / 2048); a two-layer model runs inference only", h->layers);
+  if ((flags & PREGO_FWD_KEEP) && !h->bf16 && h->hid == 2048)
+    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with hidden_dim 2048 needs bf16 operands (an fp32 W_hh slice of 2048 does not fit the register file)");
   if (n_clips <= 0 || !lens) return fail(PREGO_EINVAL, "no clips");
   if (n_clips > max_clips_of(h)) return fail(PREGO_EINVAL, "%d clips > max_clips %d per call", n_clips, max_clips_of(h));
   if (h->d_rgb > 0 && !rgb) return fail(PREGO_EINVAL, "rgb pointer array is NULL");
