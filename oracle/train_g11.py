@@ -8,7 +8,7 @@ main.py:62-67 builds it (lr 1e-4, weight decay 0.05) and its own `train_one_epoc
 on a synthetic learnable feature tree (`prego_amd/workloads.py:action_video`) written to a temp dir.  Initial weights come from
 the build-owned generator (seed 20, head gain 1), so `trained - init` is a reproducible delta.
 
-    python oracle/train_g11.py train a101 500 6      # C = 86, 6 epochs of 500 steps (~0.5 s each on 8 cores) -> oracle/_scratch/
+    python oracle/train_g11.py train a101 500 6      # C = 86, 6 epochs of 500 steps (~0.5 s each on 8 cores) -> gpurun_out/_scratch/
     python oracle/train_g11.py train epic 400 3      # C = 12
     python oracle/train_g11.py pack a101             # quantise the delta -> tests/golden/g11_weights_a101.npz
     python oracle/train_g11.py eval a101             # reference Evaluate on the PACKED weights -> tests/golden/g11_eval_a101.npz
@@ -41,7 +41,7 @@ from prego_amd import weights as W                           # noqa: E402
 from prego_amd import workloads as WL                        # noqa: E402
 from prego_amd.config import assembly101_cfg, epic_tent_cfg  # noqa: E402
 
-SCRATCH = os.path.join(REPO, "oracle", "_scratch")
+SCRATCH = os.path.join(REPO, "gpurun_out", "_scratch")       # never travels to a GPU box, never committed
 CFGS = {"a101": assembly101_cfg, "epic": epic_tent_cfg}
 TRAIN_VIDEO_FRAMES = 800
 # the eval videos of the fixture: two short ones, one past 4 096 frames, the longest Epic-tent-O length
