@@ -528,11 +528,13 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
                          "ms": ms, "roofline": {"bound": "mfma", "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                                 "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS,
                                                 "note": "3 x forward FLOPs over the whole step; 128 sequential BPTT steps: latency-bound"}}
-    # ---- the same step inside TRAINER["OAD"] (train.py:5-29): batches arrive from a pinned loader over the link, loss.item() per step
-    # as the reference has it; batch k + 1 is copied on a side stream while step k runs (prego_amd/trainer.py)
+    # ---- the same step inside TRAINER["OAD"] (train.py:5-29): batches arrive from a pinned loader over the link; batch k + 1 is copied
+    # on a side stream while step k runs (prego_amd/trainer.py).  Two loops, labelled for what they are (advisor, round 5): the GUARDED
+    # loop this optimizer selects (FusedAdamW bound to the model: no host synchronisation per step, losses read once per epoch) and the
+    # REFERENCE-PROTOCOL loop (a synchronisation + loss.item() per step, train.py:26)
     try:
         from prego_amd.registry import build_trainer
-        import prego_amd.trainer  # noqa: F401
+        import prego_amd.trainer as TR
         tr = build_trainer(cfg)
         gcpu = torch.Generator().manual_seed(1)
         loop_batches = []
@@ -542,18 +544,31 @@ def secondary(dev, lens, sd, head_dtype="fp16"):
             t_ = torch.zeros(B, T, 86)
             t_[:, :, i % 86] = 1
             loop_batches.append((r_, f_, t_.pin_memory(), ["v"] * B, torch.zeros(B), torch.full((B,), T)))
-        tr(loop_batches[:3], m, crit, opt, None, 0, dev)
-        best = float("inf")
-        for _ in range(3):
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            tr(loop_batches, m, crit, opt, None, 0, dev)
-            torch.cuda.synchronize(dev)
-            best = min(best, (time.perf_counter() - t0) / len(loop_batches))
-        m.engine(train=True).check()
+
+        def time_loop():
+            tr(loop_batches[:3], m, crit, opt, None, 0, dev)
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                tr(loop_batches, m, crit, opt, None, 0, dev)
+                torch.cuda.synchronize(dev)
+                best = min(best, (time.perf_counter() - t0) / len(loop_batches))
+            m.engine(train=True).check()
+            return best
+        best = time_loop()
+        guarded_was = TR.GUARDED_LOOP
+        TR.GUARDED_LOOP = False
+        try:
+            best_ref = time_loop()
+        finally:
+            TR.GUARDED_LOOP = guarded_was
         res["train_loop_ms_per_step"] = best * 1e3
-        res["train_loop"] = {"shape": "train_one_epoch over 10 pinned batches of 16 x 128 windows (rgb + flow, 34 MB each): H2D + step + loss.item()",
-                             "ms_per_step": best * 1e3, "frames_per_s": B * T / best}
+        res["train_loop"] = {"shape": "train_one_epoch over 10 pinned batches of 16 x 128 windows (rgb + flow, 34 MB each): H2D (prefetched) + step; "
+                                      "the sync-free guarded loop (device-guarded AdamW, losses read at the end of the epoch)",
+                             "ms_per_step": best * 1e3, "frames_per_s": B * T / best,
+                             "reference_protocol": {"shape": "the same epoch with a synchronisation + loss.item() per step (train.py:26; GUARDED_LOOP = False)",
+                                                    "ms_per_step": best_ref * 1e3, "frames_per_s": B * T / best_ref}}
         del loop_batches
     except Exception as e:            # a secondary number must not take the bench line down
         res["train_loop_error"] = repr(e)
