@@ -170,7 +170,7 @@ def test_host_average_precision_matches_sklearn_with_ties():
     gt[:, 6] = 0                                     # class without positives
     ap = average_precision_columns(pr, gt != 0)
     for c in range(Cn):
-        if c == 7:
+        if c == 6:
             assert np.isnan(ap[c])
         else:
             assert abs(ap[c] - average_precision_score(gt[:, c], pr[:, c])) < 1e-12, c
