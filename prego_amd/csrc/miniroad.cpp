@@ -803,9 +803,13 @@ static void refresh_placement(prego_miniroad* h) {
 // of 24 units (six super-rounds of four) per feed-forward XCD, a GI ring of 256 units = 4 chunks.  The rings come out of the caller's
 // workspace (0.9 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer
 // (the head runs once, behind the pass).
-static const int kSplitGiRingUnits = 256, kSplitRingPerXcd = 24;   // ring: 6 super-rounds of 4 units
+static const int kSplitGiRingUnits = 256, kSplitRingPerXcd = 24;   // ring: 12 super-rounds of 2 units
+// units per super-round (debug library: sweep).  Round 6: 2 instead of 4.  ALONE the feed-forward launch is flat between 2 and 4 (93.0 / 92.3 ms,
+// round 5); IN THE PASS 2 is 1.0-1.2 % faster on every box and alternation (profiles/r06_split_knobs.log: 95.6-97.7 against 96.8-98.6 ms):
+// half the look-ahead in rows (lags 2 / 3 / 4 super-rounds = 4 / 6 / 8 units) keeps a unit's X -> Y -> E -> GI chain closer together in
+// the XCD's L2, and a weight slab is still shared by two row blocks.  1 (no sharing) runs the GEMM tiles at 0.75 of the rate: 127 ms.
 static const int kSplitSg = (prego_tune_env("PREGO_SPLIT_SG") && kSplitRingPerXcd % std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) == 0)
-                                ? std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) : 4;     // units per super-round (debug library: sweep)
+                                ? std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) : 2;
 static const int kSplitChunkUnitShift = prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
