@@ -163,10 +163,19 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
       const int sl = sidx[ct] < na ? sidx[ct] : 0;             // inactive lanes read row 0 of the step (exists) and ignore it
       const size_t eo = (size_t)(row_t + sl) * HID + ucol;
       const size_t ep = (size_t)(row_tm1 + sl) * HID + ucol;   // t == 0: row 0 of step 0, ignored
+      if constexpr (OWN_R == 2) {
+        // a lane's two units are neighbours (ucol is even): ONE 8-byte load per array instead of two scalar ones - six vector-memory
+        // instructions per tile and step instead of twelve in front of the gather (round 6)
+        const float2 v0 = *(const float2*)(a.dHout + eo), v1 = *(const float2*)(a.R + eo), v2 = *(const float2*)(a.Z + eo);
+        const float2 v3 = *(const float2*)(a.N + eo), v4 = *(const float2*)(a.GHN + eo), v5 = *(const float2*)(a.Hraw + ep);
+        in_dh[ct][0] = v0.x; in_dh[ct][1] = v0.y; in_r[ct][0] = v1.x; in_r[ct][1] = v1.y; in_z[ct][0] = v2.x; in_z[ct][1] = v2.y;
+        in_n[ct][0] = v3.x; in_n[ct][1] = v3.y; in_g[ct][0] = v4.x; in_g[ct][1] = v4.y; in_hp[ct][0] = v5.x; in_hp[ct][1] = v5.y;
+      } else {
 #pragma unroll
-      for (int e = 0; e < OWN_R; ++e) {
-        in_dh[ct][e] = a.dHout[eo + e]; in_r[ct][e] = a.R[eo + e]; in_z[ct][e] = a.Z[eo + e];
-        in_n[ct][e] = a.N[eo + e]; in_g[ct][e] = a.GHN[eo + e]; in_hp[ct][e] = a.Hraw[ep + e];
+        for (int e = 0; e < OWN_R; ++e) {
+          in_dh[ct][e] = a.dHout[eo + e]; in_r[ct][e] = a.R[eo + e]; in_z[ct][e] = a.Z[eo + e];
+          in_n[ct][e] = a.N[eo + e]; in_g[ct][e] = a.GHN[eo + e]; in_hp[ct][e] = a.Hraw[ep + e];
+        }
       }
     }
     float dpr[NCT][OWN_R], dpz[NCT][OWN_R], dpn[NCT][OWN_R], dpnr[NCT][OWN_R];
@@ -284,16 +293,31 @@ __global__ __launch_bounds__(256, 1) void gru_bptt_kernel(BpttArgs a) {
     for (int ct = 0; ct < NCT; ++ct) {
       if (tfirst[ct] < na && sidx[ct] < na) {
         const size_t go = (size_t)(row_t + sidx[ct]) * K3 + ucol;
+        // a.dGI / a.dGH (fp32 copies) are NULL when nobody reads them: a bf16 handle's weight gradients, bias sums and dgrad all take
+        // the operand copies (gemm_tn.hip).  With the pair stores below a step issues 6 result stores instead of 24 (round 6)
+        if (a.dGI != nullptr) {
 #pragma unroll
-        for (int e = 0; e < OWN_R; ++e) {
-          a.dGI[go + e] = dpr[ct][e]; a.dGI[go + HID + e] = dpz[ct][e]; a.dGI[go + 2 * HID + e] = dpn[ct][e];
-          a.dGH[go + e] = dpr[ct][e]; a.dGH[go + HID + e] = dpz[ct][e]; a.dGH[go + 2 * HID + e] = dpnr[ct][e];
-          if constexpr (BF) {
-            ((bf16_t*)a.dGIop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGIop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGIop)[go + 2 * HID + e] = f2bf(dpn[ct][e]);
-            ((bf16_t*)a.dGHop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGHop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGHop)[go + 2 * HID + e] = f2bf(dpnr[ct][e]);
-          } else {
-            ((float*)a.dGIop)[go + e] = dpr[ct][e]; ((float*)a.dGIop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGIop)[go + 2 * HID + e] = dpn[ct][e];
-            ((float*)a.dGHop)[go + e] = dpr[ct][e]; ((float*)a.dGHop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGHop)[go + 2 * HID + e] = dpnr[ct][e];
+          for (int e = 0; e < OWN_R; ++e) {
+            a.dGI[go + e] = dpr[ct][e]; a.dGI[go + HID + e] = dpz[ct][e]; a.dGI[go + 2 * HID + e] = dpn[ct][e];
+            a.dGH[go + e] = dpr[ct][e]; a.dGH[go + HID + e] = dpz[ct][e]; a.dGH[go + 2 * HID + e] = dpnr[ct][e];
+          }
+        }
+        if constexpr (BF && OWN_R == 2) {
+          bf16_t* gi = (bf16_t*)a.dGIop + go;
+          bf16_t* gh = (bf16_t*)a.dGHop + go;
+          const unsigned pr = pack_bf16x2(dpr[ct][0], dpr[ct][1]), pz = pack_bf16x2(dpz[ct][0], dpz[ct][1]);
+          *(unsigned*)gi = pr; *(unsigned*)(gi + HID) = pz; *(unsigned*)(gi + 2 * HID) = pack_bf16x2(dpn[ct][0], dpn[ct][1]);
+          *(unsigned*)gh = pr; *(unsigned*)(gh + HID) = pz; *(unsigned*)(gh + 2 * HID) = pack_bf16x2(dpnr[ct][0], dpnr[ct][1]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < OWN_R; ++e) {
+            if constexpr (BF) {
+              ((bf16_t*)a.dGIop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGIop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGIop)[go + 2 * HID + e] = f2bf(dpn[ct][e]);
+              ((bf16_t*)a.dGHop)[go + e] = f2bf(dpr[ct][e]); ((bf16_t*)a.dGHop)[go + HID + e] = f2bf(dpz[ct][e]); ((bf16_t*)a.dGHop)[go + 2 * HID + e] = f2bf(dpnr[ct][e]);
+            } else {
+              ((float*)a.dGIop)[go + e] = dpr[ct][e]; ((float*)a.dGIop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGIop)[go + 2 * HID + e] = dpn[ct][e];
+              ((float*)a.dGHop)[go + e] = dpr[ct][e]; ((float*)a.dGHop)[go + HID + e] = dpz[ct][e]; ((float*)a.dGHop)[go + 2 * HID + e] = dpnr[ct][e];
+            }
           }
         }
       }

@@ -599,8 +599,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           }
           if constexpr (TRAIN) {
             if (a.h_raw_out) {
-#pragma unroll
-              for (int e = 0; e < OWN_R; ++e) a.h_raw_out[o + e] = hreg[ct][e];
+              if constexpr (OWN_R == 2) *(f32x2*)(a.h_raw_out + o) = (f32x2){hreg[ct][0], hreg[ct][1]};       // neighbours: one 8-byte store
+              else a.h_raw_out[o] = hreg[ct][0];
             }
           }
         }

@@ -1829,7 +1829,9 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
     if (!stepwise) {
       BpttArgs ba;
       ba.whhT = bw + L.WhhT; ba.dHout = (const float*)(bw + L.dHR); ba.R = KR; ba.Z = KZ; ba.N = KN; ba.GHN = KG; ba.Hraw = HRAW;
-      ba.dGI = (float*)(bw + L.dGI); ba.dGH = (float*)(bw + L.dGH); ba.dGIop = bw + L.dGIop; ba.dGHop = bw + L.dGHop;
+      // the fp32 copies of dGI / dGH are read by the exact-fp32 path only (column sums, transposes): a bf16 handle's k-major GEMMs take
+      // the operand copies, so its BPTT kernel does not store them at all
+      ba.dGI = tn ? nullptr : (float*)(bw + L.dGI); ba.dGH = tn ? nullptr : (float*)(bw + L.dGH); ba.dGIop = bw + L.dGIop; ba.dGHop = bw + L.dGHop;
       ba.hx = bw + L.bhx; ba.sync = (unsigned*)(bw + L.bsync); ba.abort_word = h->abort_word;
       ba.rowoff = h->d_rowoff; ba.nact = h->d_nact; ba.t_max = h->t_max; ba.n_clips = h->n_slots; ba.G = h->G;
       ba.force_sc1 = h->no_local ? 1 : 0;
