@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(3))) unsigned u32x3;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 typedef unsigned short bf16_t;                               // raw bf16 bits in memory
 

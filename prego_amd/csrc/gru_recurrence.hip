@@ -319,9 +319,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const int r = rbase + (sidx[ct] < na ? sidx[ct] : 0);
 #pragma unroll
     for (int gate = 0; gate < 3; ++gate) {
-      if constexpr (PASS) {                    // ring slot of the absolute row; the row was written on another XCD: sc1
-        const unsigned off = ((unsigned)r & a.gi_row_mask) * (unsigned)(3 * HID * 2) + (unsigned)((gate * HID + ucol) * 2);
-        dst[gate][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_gi, (int)off, 0, AUX_SC1));
+      if constexpr (PASS) {                    // (handled above: one 12-byte load for the three gates)
       } else
       if constexpr (GI16) {
         const bf16_t* p = (const bf16_t*)a.gi + (size_t)r * (3 * HID) + gate * HID + ucol;
@@ -340,6 +338,17 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     }
   };
 
+  // pass mode: ring slot of the absolute row; the row was written on another XCD: sc1.  The feed-forward launch of a split pass projects
+  // with W_ih's rows permuted to (unit pair, gate, unit % 2) order (miniroad.cpp: w_ih_perm), so this lane's r / z / n pairs are 12 adjacent
+  // bytes: ONE vector-memory instruction per step instead of three (round 6; they queue in front of the next step's gather).  The three
+  // dwords stay ONE register triple from the load to the gate phase: copied into separate registers they cost an s_waitcnt vmcnt(0) right
+  // behind the load (measured: +0.35 us per step)
+  static_assert(!PASS || OWN_R == 2, "pass mode: a lane owns a pair of units");
+  auto load_gi_pass = [&](int ct, int na, int rbase) -> u32x3 {
+    const int r = rbase + (sidx[ct] < na ? sidx[ct] : 0);
+    const unsigned off = ((unsigned)r & a.gi_row_mask) * (unsigned)(3 * HID * 2) + (unsigned)((ucol >> 1) * 12);
+    return __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)off, 0, AUX_SC1);
+  };
   const bool stamp = a.stamps != nullptr && (PASS ? (g == 0 && w == 0) : blockIdx.x == 0) && q == 0;   // pass mode: workgroup 0 may sit on an XCD without a group
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long st_t = 0;
@@ -357,14 +366,19 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   int na_n = nsteps > 1 ? nact_c[a.t0 + 1] : 0, rb_n = nsteps > 1 ? rowoff_c[a.t0 + 1] : 0;   // step tl+1
   // prologue: h_{t0-1} -> buffer 1 with the tag of step "-1" (= 1); gi of the first step
   float giA[NCT][3][OWN_R], giB[NCT][3][OWN_R];                         // ping-pong: no register copies
+  u32x3 gvA[NCT], gvB[NCT];                                             // pass mode: the same as one register triple per tile
   if constexpr (PASS) { if (!pass_wait_row(rowoff_c[a.t0 + 1] - 1)) return; }      // the first step's rows
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)
-    if (tfirst[ct] < na_c) { publish(ct, 1, 1u, false); load_gi(giA[ct], ct, na_c, rb_c - a.row_base); }
+    if (tfirst[ct] < na_c) {
+      publish(ct, 1, 1u, false);
+      if constexpr (PASS) gvA[ct] = load_gi_pass(ct, na_c, rb_c - a.row_base);
+      else load_gi(giA[ct], ct, na_c, rb_c - a.row_base);
+    }
   int parity = 0;
 
   // one time step; gir = gi of this step (loaded a step ago), gin = where the next step's gi lands
-  auto step = [&](const int tl, float (&gir)[NCT][3][OWN_R], float (&gin)[NCT][3][OWN_R]) -> bool {
+  auto step = [&](const int tl, float (&gir)[NCT][3][OWN_R], float (&gin)[NCT][3][OWN_R], u32x3 (&gvr)[NCT], u32x3 (&gvn)[NCT]) -> bool {
     const int t = a.t0 + tl;
     const int na = na_c;
     const int rbase = rb_c - a.row_base;
@@ -472,10 +486,13 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
         // ---- (1b) the gather's vmcnt(0) has just retired every older vector-memory op, including the loads of this
         // step's gi (issued one step ago).  Pin that fact for the compiler (it would otherwise put a vmcnt(0) in front
         // of the first use of the loop-carried registers, i.e. behind the prefetch issued next), then prefetch gi(t+1)
+        if constexpr (PASS) asm volatile("" : "+v"(gvr[ct]));
+        else {
 #pragma unroll
-        for (int gate = 0; gate < 3; ++gate)
+          for (int gate = 0; gate < 3; ++gate)
 #pragma unroll
-          for (int e = 0; e < OWN_R; ++e) asm volatile("" : "+v"(gir[ct][gate][e]));
+            for (int e = 0; e < OWN_R; ++e) asm volatile("" : "+v"(gir[ct][gate][e]));
+        }
         if constexpr (PASS) {
           // rows below rowoff[t] belong to finished steps and nothing of them is in flight (the vmcnt(0) above): report their chunks;
           // then make sure the chunk(s) of step t + 1's rows are complete before the prefetch below reads them
@@ -483,7 +500,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           if (sig < c_done) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pass_signal_upto(c_done); }
           if (more) { if (!pass_wait_row(re_n - 1)) return false; }
         }
-        if (more && tfirst[ct] < na_n) load_gi(gin[ct], ct, na_n, rb_n - a.row_base);
+        if (more && tfirst[ct] < na_n) {
+          if constexpr (PASS) gvn[ct] = load_gi_pass(ct, na_n, rb_n - a.row_base);
+          else load_gi(gin[ct], ct, na_n, rb_n - a.row_base);
+        }
 
         // ---- (2) cross-wave (K-quarter) reduction through LDS, double buffered: one barrier per tile
         // (round 5: rocprofv3 counts SQ_LDS_BANK_CONFLICT = 1/3 of this kernel's active LDS cycles - the gate phase reads 8 bytes per lane
@@ -522,7 +542,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
               const f32x2 one = {1.f, 1.f};
               f32x2 gr, gz, gn;
               if constexpr (GI16) {          // one dword = the bf16 pair of my two units
-                const unsigned ur = __float_as_uint(gir[ct][0][0]), uz = __float_as_uint(gir[ct][1][0]), un = __float_as_uint(gir[ct][2][0]);
+                const unsigned ur = PASS ? gvr[ct][0] : __float_as_uint(gir[ct][0][0]), uz = PASS ? gvr[ct][1] : __float_as_uint(gir[ct][1][0]),
+                               un = PASS ? gvr[ct][2] : __float_as_uint(gir[ct][2][0]);
                 gr = (f32x2){op16<OT>::lo(ur), op16<OT>::hi(ur)};
                 gz = (f32x2){op16<OT>::lo(uz), op16<OT>::hi(uz)};
                 gn = (f32x2){op16<OT>::lo(un), op16<OT>::hi(un)};
@@ -620,8 +641,8 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
   const unsigned long long rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;       // 100 MHz: with the cycle sums below = this XCD's shader clock
   for (int tl = 0; tl < nsteps; tl += 2) {
     if (tfirst[0] >= na_c) break;             // every slot of this group has ended: leave, free the CU
-    if (!step(tl, giA, giB)) return;
-    if (tl + 1 < nsteps && !step(tl + 1, giB, giA)) return;
+    if (!step(tl, giA, giB, gvA, gvB)) return;
+    if (tl + 1 < nsteps && !step(tl + 1, giB, giA, gvB, gvA)) return;
   }
   if (stamp && lane == 0) {
     for (int i = 0; i < 6; ++i) a.stamps[i] += st_acc[i];

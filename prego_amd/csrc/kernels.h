@@ -260,6 +260,9 @@ size_t perframe_ap_workspace_bytes(long long n_frames, int n_classes);
 int launch_perframe_ap(const float* scores, const float* target, const int* labels, long long n_frames, int n_classes, double* ap, long long* n_pos,
                        double* score_sum, void* workspace, hipStream_t s);
 
+// split pass (round 6): rows gate * H + u of a 16-bit [3H][E] matrix and an fp32 [3H] vector -> rows (u / 2) * 6 + 2 * gate + u % 2 (rowwise.hip)
+void launch_permute_gi_rows(const void* w, const float* bias, void* w_perm, float* bias_perm, int H, int E, hipStream_t s);
+
 // fused multi-tensor AdamW (optim.hip)
 int launch_adamw(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                  void* const* copies, const long long* numel, bool copy_bf16, long long step, float lr, float b1, float b2, float eps,

@@ -82,6 +82,10 @@ struct prego_miniroad {
   void* w_ih = nullptr;         // [3H][emb] WT
   void* w_hh = nullptr;         // [3H][H] WT
   float* bias2 = nullptr;       // b_ih + (b_hh for r,z rows)
+  // split pass (round 6): W_ih / bias2 with their rows PERMUTED so that a recurrence lane's r / z / n pairs of a GI row are 12 adjacent
+  // bytes: row (u / 2) * 6 + 2 * gate + u % 2 holds nn.GRU's row gate * H + u.  Built lazily in front of a split pass when the weights
+  // have changed since (set_weights, the fused AdamW step); 16-bit handles of hidden_dim 1024 / one layer only
+  void* w_ih_perm = nullptr; float* bias2_perm = nullptr; bool perm_stale = true;
   float* b_hn = nullptr;        // [H]
   void* w_c = nullptr;          // [ncls_pad][H] WT zero padded
   float* b_c = nullptr;         // [ncls_pad]
@@ -251,6 +255,7 @@ extern "C" int prego_miniroad_create_layers(prego_miniroad** out, int d_rgb, int
   A(&h->w1, (size_t)emb * din * es); A((void**)&h->b1, emb * 4); A((void**)&h->ln_g, emb * 4); A((void**)&h->ln_b, emb * 4);
   A(&h->w_ih, (size_t)3 * H * emb * es); A(&h->w_hh, (size_t)3 * H * H * es);
   A((void**)&h->bias2, 3 * H * 4); A((void**)&h->b_hn, H * 4);
+  if (h->bf16 && H == 1024 && h->layers == 1) { A(&h->w_ih_perm, (size_t)3 * H * emb * es); A((void**)&h->bias2_perm, 3 * H * 4); }
   A(&h->w_c, (size_t)h->ncls_pad * H * es); A((void**)&h->b_c, h->ncls_pad * 4);
   A(&h->hx, h->x2 ? gru_x2_hx_bytes(H, h->G) : gru_hx_bytes(h->bf16, H, h->G));
   if (h->x2) A((void**)&h->x2_scale, 6 * sizeof(float));
@@ -327,7 +332,7 @@ extern "C" void prego_miniroad_destroy(prego_miniroad* h) {
   if (h->side) { PREGO_TEARDOWN(hipStreamSynchronize(h->side)); PREGO_TEARDOWN(hipStreamDestroy(h->side)); }
   void* ptrs[] = {h->w1, h->b1, h->ln_g, h->ln_b, h->w_ih, h->w_hh, h->bias2, h->b_hn, h->w_c, h->b_c, h->hx,
                   h->flags, h->h_state, h->stamps, h->tile_ctr, h->d_rowoff, h->d_nact, h->d_sorted, h->d_seg_off, h->d_seg_clip,
-                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale, h->l2_w_ih, h->l2_w_hh, h->l2_bias2, h->l2_b_hn};
+                  h->d_seg_start, h->d_ptrs, h->d_blkstep, h->st_scratch, h->x2_scale, h->l2_w_ih, h->l2_w_hh, h->l2_bias2, h->l2_b_hn, h->w_ih_perm, h->bias2_perm};
   for (size_t i = 0; i < sizeof ptrs / sizeof ptrs[0]; ++i)
     if (ptrs[i]) {
 #ifdef PREGO_DEBUG_ABI
@@ -377,6 +382,7 @@ extern "C" int prego_miniroad_set_weights(prego_miniroad* h, const float* layer1
   HIPCHK(hipMemcpyAsync(h->ln_g, ln_w, E * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpyAsync(h->ln_b, ln_b, E * 4, hipMemcpyDeviceToDevice, s));
   launch_add_vec(b_ih, b_hh, h->bias2, 3 * H, 2 * H, s);   // r,z rows: b_ih + b_hh ; n rows: b_ih
+  h->perm_stale = true;
   HIPCHK(hipMemcpyAsync(h->b_hn, b_hh + 2 * H, H * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   h->have_weights = true;
@@ -895,7 +901,7 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   fa.rgb_ptrs = d_rgb_ptrs; fa.flow_ptrs = with_flow ? d_flow_ptrs : nullptr; fa.plan = plan; fa.rowmap = RM;
   fa.d_rgb = h->d_rgb; fa.d_flow = with_flow ? h->d_flow : 0; fa.in16 = in16 ? 1 : 0; fa.kx = kx;
   fa.w1 = (const unsigned short*)h->w1; fa.ld_w1 = din; fa.b1 = h->b1; fa.ln_g = h->ln_g; fa.ln_b = h->ln_b; fa.ln_eps = 1e-5f;
-  fa.w_ih = (const unsigned short*)h->w_ih; fa.bias2 = h->bias2; fa.E = E; fa.n3 = 3 * H;
+  fa.w_ih = (const unsigned short*)h->w_ih_perm; fa.bias2 = h->bias2_perm; fa.E = E; fa.n3 = 3 * H;      // permuted rows: GI rows in (unit pair, gate) order
   fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = kSplitGiRingUnits;
   fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = kSplitChunkUnitShift;
   fa.rec_expect = R * h->P * 4; fa.nt1 = E / 256; fa.nt2 = 3 * H / 256;
@@ -937,6 +943,10 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   // everything the recurrence launch needs done first goes IN FRONT of the fork: once the feed-forward kernel is resident it fills its CUs
   // completely, and an ordinary kernel of the caller's stream (the arm kernel, a memset) would wait for it - with the recurrence queued behind
   launch_gru_arm(true, H, h->G, h->hx, h->flags, s);
+  if (h->perm_stale) {                       // in front of the fork, like the arm kernel: nothing of this stream may sit between the two launches
+    launch_permute_gi_rows(h->w_ih, h->bias2, h->w_ih_perm, h->bias2_perm, H, E, s);
+    h->perm_stale = false;
+  }
   std::lock_guard<std::mutex> split_lock(g_split_mu);          // held until this pass is enqueued and its end event recorded
   int dev_ = 0;
   HIPCHK(hipGetDevice(&dev_));
@@ -2039,6 +2049,7 @@ extern "C" int prego_miniroad_adamw_step(prego_miniroad* h, float* const* params
       launch_adamw(6, pb, gb, mb, vb, cb, nb, false, step, lr, beta1, beta2, eps, weight_decay, s, h->abort_word, h->peer_guard))
     return fail(PREGO_EINVAL, "adamw: bad step %lld", (long long)step);
   launch_add_vec(params[6], params[7], h->bias2, (int)(3 * H), (int)(2 * H), s);      // r,z rows: b_ih + b_hh ; n rows: b_ih
+  h->perm_stale = true;
   HIPCHK(hipMemcpyAsync(h->b_hn, params[7] + 2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipGetLastError());
   return PREGO_OK;

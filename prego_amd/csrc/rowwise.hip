@@ -330,3 +330,22 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* out, int n
 void launch_add_vec(const float* a, const float* b, float* out, int n, int n_add, hipStream_t s) {
   add_vec_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, out, n, n_add);
 }
+
+// ---- split pass: the GI row order the recurrence wants (miniroad.cpp: w_ih_perm) ------------------------------------------------------------
+// nn.GRU's W_ih rows are [r: H | z: H | n: H]; a recurrence lane owns two neighbouring units and needs their r, z and n entries of a GI row
+// every step - three 4-byte loads 2 KB apart.  With the rows of W_ih (and the bias) permuted ONCE to (unit pair, gate, unit % 2) order the
+// projection writes those six values next to each other and the lane takes them with one 12-byte load.  Same dot products, same K order:
+// every GI value is bit-identical, only its column moved.
+__global__ __launch_bounds__(256) void permute_gi_rows_kernel(const unsigned short* __restrict__ w, const float* __restrict__ bias,
+                                                              unsigned short* __restrict__ wp, float* __restrict__ bp, int H, int E) {
+  const int n = blockIdx.x;                         // destination row
+  const int pair = n / 6, rem = n - pair * 6, gate = rem >> 1, u = pair * 2 + (rem & 1);
+  const int src = gate * H + u;
+  const uint4* a = (const uint4*)(w + (size_t)src * E);
+  uint4* b = (uint4*)(wp + (size_t)n * E);
+  for (int i = threadIdx.x; i < E / 8; i += 256) b[i] = a[i];
+  if (threadIdx.x == 0) bp[n] = bias[src];
+}
+void launch_permute_gi_rows(const void* w, const float* bias, void* w_perm, float* bias_perm, int H, int E, hipStream_t s) {
+  permute_gi_rows_kernel<<<3 * H, 256, 0, s>>>((const unsigned short*)w, bias, (unsigned short*)w_perm, bias_perm, H, E);
+}
