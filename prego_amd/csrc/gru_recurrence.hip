@@ -429,7 +429,12 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             unsigned badv = 0u;
 #pragma unroll
             for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks)
-              badv |= ((hb[ks][0] ^ eword) | (hb[ks][1] ^ eword)) | ((hb[ks][2] ^ eword) | (hb[ks][3] ^ eword));   // tag bit survives iff stale
+            {
+              // the xor that tests the tag also REMOVES it (a fresh element carries exactly `eword`'s bits there): the fragment is
+              // un-tagged in place and goes to the MFMA as it is - no separate mask pass (32 VALU per step until round 5)
+              hb[ks][0] ^= eword; hb[ks][1] ^= eword; hb[ks][2] ^= eword; hb[ks][3] ^= eword;
+              badv |= (hb[ks][0] | hb[ks][1]) | (hb[ks][2] | hb[ks][3]);            // tag bit survives iff stale
+            }
             return !__all(!col_live || (badv & TAGM) == 0u);
           };
           if (seg_stale()) {
@@ -456,8 +461,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
           if (sg == 0) STAMP(1);                   // stamps only: top of step -> first segment valid (the hand-off latency)
 #pragma unroll
           for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks) {
-            u32x4 v = hb[ks];
-            v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;     // scalar mask: one VALU per register
+            const u32x4 v = hb[ks];               // un-tagged by the staleness test above (dead columns: zeros ^ eword, products nobody reads)
             if constexpr (BF) {
               const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
