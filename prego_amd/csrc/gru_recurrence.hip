@@ -349,6 +349,9 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
     const unsigned off = ((unsigned)r & a.gi_row_mask) * (unsigned)(3 * HID * 2) + (unsigned)((ucol >> 1) * 12);
     return __builtin_amdgcn_raw_buffer_load_b96(rs_gi, (int)off, 0, AUX_SC1);
   };
+  // (round 6, measured: compiling the stamps OUT of the pass instantiation - six wave-uniform branches per step less - makes the step 6 %
+  // SLOWER, 2.26 against 2.13 us on one box, and so does folding `local` into a constant there: the branches cut the step into the basic
+  // blocks its phases are, and hipcc's scheduler does worse with the freedom of one big block.  profiles/r06_ab_nostamp.log)
   const bool stamp = a.stamps != nullptr && (PASS ? (g == 0 && w == 0) : blockIdx.x == 0) && q == 0;   // pass mode: workgroup 0 may sit on an XCD without a group
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long st_t = 0;
