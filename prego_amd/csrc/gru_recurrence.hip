@@ -241,7 +241,13 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 
   // ---- gate-phase ownership inside a clip tile: the UT accumulator tiles x 4 registers are split over the 4 waves
   const int own_ut = UT == 2 ? (q & 1) : 0;
+#ifdef GRU_OWN_SWZ
+  // which register pair of its accumulator tile a lane owns alternates with bit 3 of the lane: the gate phase's 8-byte LDS reads of lanes
+  // l and l + 8 then fall on different banks (at one pair per wave they hit the same 16 of 32 banks: a two-way conflict on every read)
+  const int own_r0 = UT == 2 ? ((((q >> 1) ^ (lane >> 3)) & 1) * 2) : q;
+#else
   const int own_r0 = UT == 2 ? (q >> 1) * 2 : q;
+#endif
   const int ucol = w * UNITS + own_ut * 16 + l4 * 4 + own_r0;       // first hidden unit of this lane's registers
   float hreg[NCT][OWN_R];
   float bhn[OWN_R];
@@ -435,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
             {
               // the xor that tests the tag also REMOVES it (a fresh element carries exactly `eword`'s bits there): the fragment is
               // un-tagged in place and goes to the MFMA as it is - no separate mask pass (32 VALU per step until round 5)
-              hb[ks][0] ^= eword; hb[ks][1] ^= eword; hb[ks][2] ^= eword; hb[ks][3] ^= eword;
+              hb[ks][0] ^= eword; hb[ks][1] ^= eword; hb[ks][2] ^= eword; hb[ks][3] ^= eword;      // (skipping it on tag-0 steps behind a branch: 1 % slower)
               badv |= (hb[ks][0] | hb[ks][1]) | (hb[ks][2] | hb[ks][3]);            // tag bit survives iff stale
             }
             return !__all(!col_live || (badv & TAGM) == 0u);
