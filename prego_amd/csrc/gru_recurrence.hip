@@ -241,13 +241,9 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_kernel(GruArgs a) {
 
   // ---- gate-phase ownership inside a clip tile: the UT accumulator tiles x 4 registers are split over the 4 waves
   const int own_ut = UT == 2 ? (q & 1) : 0;
-#ifdef GRU_OWN_SWZ
-  // which register pair of its accumulator tile a lane owns alternates with bit 3 of the lane: the gate phase's 8-byte LDS reads of lanes
-  // l and l + 8 then fall on different banks (at one pair per wave they hit the same 16 of 32 banks: a two-way conflict on every read)
-  const int own_r0 = UT == 2 ? ((((q >> 1) ^ (lane >> 3)) & 1) * 2) : q;
-#else
+  // (round 6: letting the owned register pair alternate with bit 3 of the lane makes the gate phase's 8-byte LDS reads conflict-free -
+  // and changes nothing: 94.6 against 94.6 ms, profiles/r06_ab_ownswz.log.  The counted bank conflicts are not on the step's critical path)
   const int own_r0 = UT == 2 ? (q >> 1) * 2 : q;
-#endif
   const int ucol = w * UNITS + own_ut * 16 + l4 * 4 + own_r0;       // first hidden unit of this lane's registers
   float hreg[NCT][OWN_R];
   float bhn[OWN_R];
