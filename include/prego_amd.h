@@ -44,7 +44,8 @@ extern "C" {
  * 7: round 6.  prego_miniroad_forward no longer allocates or synchronises for the whole-call relu(h) buffer: the caller sizes it with
  *    prego_miniroad_resident_bytes and hands it over with prego_miniroad_set_resident (without one, every call runs the chunked pass
  *    with the per-chunk classifier - same results).  Added: prego_miniroad_resident_bytes / _set_resident, prego_miniroad_guard_publish /
- *    _set_peer_guard (data-parallel training: a timeout on one rank stops the optimizer step of every rank).  Existing signatures unchanged. */
+ *    _set_peer_guard (data-parallel training: a timeout on one rank stops the optimizer step of every rank), prego_miniroad_set_gru_layer_grads
+ *    (training of a two-layer GRU; PREGO_FWD_KEEP now takes hidden_dim 512 / 1024 / 2048 and num_layers 1 / 2).  Existing signatures unchanged. */
 #define PREGO_ABI_VERSION 7
 
 enum {
@@ -227,6 +228,10 @@ int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_done, void* 
  * this handle.  fn = NULL removes it. */
 typedef void (*prego_bucket_fn)(void* user, int bucket);
 int prego_miniroad_backward_callback(prego_miniroad* h, prego_bucket_fn fn, void* user);
+/* A stacked GRU (num_layers 2, rnn.py:32,38) under loss.backward() (ABI 7): where the gradients of gru.weight_ih_l1 [3H, H],
+ * gru.weight_hh_l1 [3H, H], gru.bias_ih_l1 [3H], gru.bias_hh_l1 [3H] go (device fp32, OVERWRITTEN by every following
+ * prego_miniroad_backward; layer 0's are that call's own arguments).  Required before the backward of a 2-layer handle. */
+int prego_miniroad_set_gru_layer_grads(prego_miniroad* h, int layer, float* g_w_ih, float* g_w_hh, float* g_b_ih, float* g_b_hh);
 size_t prego_miniroad_backward_workspace_bytes(const prego_miniroad* h, int n_clips, const int32_t* lens);
 int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int32_t* lens, const float* const* dlogits,
                             float* g_layer1_w, float* g_layer1_b, float* g_ln_w, float* g_ln_b, float* g_w_ih,

@@ -556,7 +556,34 @@ def g4d():
         print("g4d", hid, "loss", float(loss))
 
 
-GROUPS = {"g4d": g4d, "g10": g10, "g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
+def g4e():
+    """Training step of a STACKED GRU (cfg['num_layers'] = 2: nn.GRU(2048, H, 2), rnn.py:32,38 - trainer/train.py trains whatever the
+    constructor accepts): hidden_dim 1024 and 512, B = 5 windows x T = 24 frames, rgb + non-zero flow, an all-zero and a multi-label
+    last-frame target row, dropout 0: loss, last-frame logits, norms + sampled entries of all 14 gradients."""
+    from model import build_model
+    from criterions import build_criterion
+    B, T = 5, 24
+    for hid in (1024, 512):
+        cfg = assembly101_cfg(dropout=0.0, hidden_dim=hid, num_layers=2)
+        sd = W.miniroad_state_dict(cfg, seed=20)
+        model = _load(build_model(cfg, "cpu"), sd).train()
+        crit = build_criterion(cfg, "cpu")
+        rgb = W.tsn_features((B, T, 2048), 20, f"g4e.{hid}.rgb")
+        flow = W.tsn_features((B, T, 2048), 20, f"g4e.{hid}.flow")
+        tgt = make_targets(B, T, 86, 20, f"g4e.{hid}.tgt")
+        tgt[1, -1] = 0.0
+        tgt[2, -1, 7] = 1.0
+        out = model(torch.from_numpy(rgb), torch.from_numpy(flow))
+        loss = crit(out, torch.from_numpy(tgt))
+        loss.backward()
+        save = {"loss": np.float64(float(loss)), "logits_last": out["logits"][:, -1, :].detach().numpy().copy()}
+        _grad_summary(model, save)
+        assert "norm.gru.weight_ih_l1" in save
+        np.savez_compressed(os.path.join(OUT, f"g4e_miniroad_train_l2_h{hid}.npz"), **save)
+        print("g4e", hid, "loss", float(loss))
+
+
+GROUPS = {"g4e": g4e, "g4d": g4d, "g10": g10, "g4s": g4s, "g1": g1_g2_g3, "g1c": g1c, "g4": g4, "g4c": g4c, "g5": g5, "g5b": g5b, "g5c": g5c, "g6": g6, "g6b": g6b, "g7": g7, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -37,6 +37,7 @@ SYMBOLS = [
     "prego_miniroad_plan_starts", "prego_miniroad_set_feed_events", "prego_miniroad_pass_info",
     "prego_vit_set_compute_dtype", "prego_attention_layer_set_compute_dtype",
     "prego_miniroad_resident_bytes", "prego_miniroad_set_resident", "prego_miniroad_guard_publish", "prego_miniroad_set_peer_guard",
+    "prego_miniroad_set_gru_layer_grads",
 ]
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
 DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
@@ -79,6 +80,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
     lib.prego_miniroad_set_resident.argtypes = [vp, vp, sz]
     lib.prego_miniroad_guard_publish.argtypes = [vp, vp, vp]
     lib.prego_miniroad_set_peer_guard.argtypes = [vp, vp]
+    lib.prego_miniroad_set_gru_layer_grads.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.prego_miniroad_forward.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(vp), C.POINTER(vp),
                                            C.POINTER(vp), C.POINTER(vp), vp, vp, i32, vp, sz, vp]
     lib.prego_miniroad_step.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, vp]

@@ -6,7 +6,7 @@ from __future__ import annotations
 import torch
 
 from ._lib import PregoError
-from .engine import _PARAM_ORDER, oad_loss
+from .engine import oad_loss, param_order
 
 
 class _MiniRoadTrainFn(torch.autograd.Function):
@@ -28,17 +28,12 @@ class _MiniRoadTrainFn(torch.autograd.Function):
             raise PregoError("MiniROAD backward: another training forward ran on this model since the forward of this graph; its kept "
                              "activations were overwritten (run backward before the next forward, or use torch.no_grad() / eval() for it)")
         grads = ctx.eng.backward(dout)
-        return (None, None, None) + tuple(grads[k] for k in _PARAM_ORDER)
+        return (None, None, None) + tuple(grads[k] for k in param_order(ctx.eng.num_layers))
 
 
 def miniroad_train_forward(model, rgb_input, flow_input):
-    if model.num_layers != 1:
-        # fail fast and say what the limit is (advisor, round 5): construction, optimizer set-up and data loading of a two-layer model
-        # all succeed, and the run used to die in the C ABI at its first training forward
-        raise PregoError(f"MiniROAD training covers num_layers 1 (cfg['num_layers'] = {model.num_layers}): a stacked GRU runs inference "
-                         "only in this build - hidden_dim 512 / 1024 / 2048 train (2048: bf16 operands)")
     named = dict(model.named_parameters())
-    params = [named[k] for k in _PARAM_ORDER]
+    params = [named[k] for k in param_order(model.num_layers)]           # one GRU layer or two (rnn.py:32,38)
     flow = flow_input if (model.use_flow and (not model.assume_zero_flow or not model.use_rgb)) else None
     return _MiniRoadTrainFn.apply(model, rgb_input if model.use_rgb else None, flow, *params)
 

@@ -109,6 +109,7 @@ struct prego_miniroad {
   int kept_rows = 0;
   // data-parallel training: events the NEXT backward records when a group of gradient tensors is final (prego_miniroad_backward_events),
   // so that the caller can start reducing that bucket on another stream while the rest of the backward runs
+  float* g_l2[4] = {nullptr, nullptr, nullptr, nullptr};     // prego_miniroad_set_gru_layer_grads: dW_ih_l1, dW_hh_l1, db_ih_l1, db_hh_l1
   hipEvent_t bwd_ev[2] = {nullptr, nullptr};
   prego_bucket_fn bwd_cb = nullptr; void* bwd_cb_user = nullptr;     // prego_miniroad_backward_callback: called right behind each event record
   // plan cache
@@ -688,7 +689,7 @@ extern "C" int prego_miniroad_set_feed_events(prego_miniroad* h, int n_events, c
   return PREGO_OK;
 }
 
-struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, map, total; };
+struct RowBytes { size_t x, y, e, gi, hr, hraw, gates, stats, map, l2keep, total; };
 // bf16 mode, inference (no PREGO_FWD_KEEP): the two projections' outputs stay bf16 between the kernels (what a bf16 autocast
 // of the reference does too).  They are the largest HBM streams of the pass (20 KB per frame in fp32) and the store tail of a
 // GEMM tile is bound by bytes: with fp32 C the projections run 1.23 / 1.10 PFLOP/s (K = 4096 / 2048), without any C store 1.41 /
@@ -712,7 +713,9 @@ static RowBytes row_bytes(const prego_miniroad* h, bool with_flow, int flags) {
   r.gates = keep ? (size_t)h->hid * 4 * 4 : 0;      // r, z, n, W_hn h + b_hn
   r.stats = keep ? 8 : 0;                           // LayerNorm mean, rstd
   r.map = 16;                                       // row -> (clip, frame) for the head's scatter, two chunks deep
-  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw + r.gates + r.stats + r.map;
+  // training a two-layer GRU (round 6): layer 0's h_t as layer 1's input operand, layer 1's raw state and its four gate activations
+  r.l2keep = (keep && h->layers == 2) ? (size_t)h->hid * es + (size_t)h->hid * 4 + (size_t)h->hid * 4 * 4 : 0;
+  r.total = r.x + r.y + r.e + r.gi + r.hr + r.hraw + r.gates + r.stats + r.map + r.l2keep;
   return r;
 }
 
@@ -1016,9 +1019,6 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
   if (!h) return fail(PREGO_EINVAL, "handle is NULL");
   if (!h->have_weights) return fail(PREGO_EINVAL, "forward before set_weights");
   if (h->layers == 2 && !h->have_layer2) return fail(PREGO_EINVAL, "forward of a 2-layer handle before set_gru_layer(1)");
-  if ((flags & PREGO_FWD_KEEP) && h->layers != 1)
-    return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with num_layers %d: the training path (kept gates, BPTT, weight gradients) covers one GRU layer "
-                "(hidden_dim 512 / 1024 / 2048); a two-layer model runs inference only", h->layers);
   if ((flags & PREGO_FWD_KEEP) && !h->bf16 && h->hid == 2048)
     return fail(PREGO_EINVAL, "PREGO_FWD_KEEP (training) with hidden_dim 2048 needs bf16 operands (an fp32 W_hh slice of 2048 does not fit the register file)");
   if (n_clips <= 0 || !lens) return fail(PREGO_EINVAL, "no clips");
@@ -1218,6 +1218,14 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     STATS = (float*)carve((size_t)cap_rows * 8);
     h->kept_kx = kx; h->kept_rows = total_rows;
   }
+  // two-layer training: layer 0's h_t [rows][H] (operand type: layer 1's input, and the B operand of dW_ih_l1), layer 1's raw state and gates
+  void* HR0 = nullptr; float* HRAW2 = nullptr; float* KR2 = nullptr; float* KZ2 = nullptr; float* KN2 = nullptr; float* KG2 = nullptr;
+  if (keep && h->layers == 2) {
+    HR0 = carve((size_t)cap_rows * h->hid * (h->bf16 ? 2 : 4));
+    HRAW2 = (float*)carve((size_t)cap_rows * h->hid * 4);
+    KR2 = (float*)carve((size_t)cap_rows * h->hid * 4); KZ2 = (float*)carve((size_t)cap_rows * h->hid * 4);
+    KN2 = (float*)carve((size_t)cap_rows * h->hid * 4); KG2 = (float*)carve((size_t)cap_rows * h->hid * 4);
+  }
 
   char* RM = (char*)carve((size_t)cap_rows * rb.map);        // [2][cap_rows] int2: chunk c uses half c & 1 (the pack of chunk c+1
                                                              // runs under the recurrence of chunk c, before the head of chunk c)
@@ -1323,6 +1331,7 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
     ga.armed = (arm_fuse && rows > 0) ? 1 : 0;
     ga.no_mt = h->no_mt ? 1 : 0;
     ga.out_floor = h->layers == 2 ? -INFINITY : 0.f;      // 2 layers: layer 0 hands h_t itself to layer 1 (below)
+    if (HR0) ga.h_relu_out = HR0;                         // ... and when training, into a buffer of its own (backward needs it again)
     {
       // PREGO_GRU_COMPACT=1 (experiments): live slots packed into the fewest groups, the other XCDs leave at once.  Default
       // off: spreading the live slots over all groups is 2.6 ms per pass faster (the step cost grows with the fullest group's columns)
@@ -1392,11 +1401,12 @@ extern "C" int prego_miniroad_forward(prego_miniroad* h, int n_clips, const int3
       // (out_floor = -inf) in HR -, GI and HR are reused in place: gi' = h W_ih_l1^T + b (GI of layer 0 is dead), then the recurrence of
       // layer 1 over the same steps from its own state, relu(h'_t) -> HR for the classifier
       ev = ev_begin(h, 0, s);
-      proj(HR, H, h->l2_w_ih, H, h->l2_bias2, GI, 3 * H, rows, 3 * H, H);
+      proj(HR0 ? HR0 : HR, H, h->l2_w_ih, H, h->l2_bias2, GI, 3 * H, rows, 3 * H, H);
       ev_end(ev, s);
       if (h->timing) h->gemm_flop += 2.0 * rows * 3.0 * H * H;
       GruArgs g2 = ga;
       g2.whh = h->l2_w_hh; g2.b_hn = h->l2_b_hn; g2.h_state = h->h_state + slot_stride; g2.out_floor = 0.f;
+      if (HR0) { g2.h_relu_out = HR; g2.h_raw_out = HRAW2; g2.keep_r = KR2; g2.keep_z = KZ2; g2.keep_n = KN2; g2.keep_ghn = KG2; }
       g2.armed = 0;                 // the exchange buffers / rendezvous words were used by layer 0's launch: re-arm (launcher)
       g2.Gd = 0;
       ev = ev_begin(h, 1, s);
@@ -1709,7 +1719,7 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   L.part = put(std::max<size_t>(((size_t)R / 64 + 1) * 3 * H, ((size_t)R / 4 + 1) * 2 * E) * 4);
   L.T1 = put(std::max<size_t>(3 * H, E) * Rp * es);           // transposed "A" operand of a wgrad (dGIt / dGHt / dYt)
   L.T2 = put(std::max<size_t>(std::max<size_t>(E, H), Din) * Rp * es);   // transposed "B" operand (Et / Hprev_t / Xt)
-  L.WihT = put(E * 3 * H * es);
+  L.WihT = put(std::max(E, H) * 3 * H * es);
   L.dE = put((size_t)R * E * 4); L.dY = put((size_t)R * E * 4);
   L.dYb = put(Rp * E * 2);                                      // bf16 copy of dY: k-major A operand of layer1's wgrad
   L.Hprev = put((size_t)R * H * es);
@@ -1717,6 +1727,15 @@ static BwdLayout bwd_layout(const prego_miniroad* h, int R, int n_clips) {
   L.bhx = put(gru_bptt_hx_bytes(h->bf16, h->hid, h->G)); L.bsync = put(1024 * 4);     // persistent BPTT: exchange buffers, step counters
   L.total = off;
   return L;
+}
+
+extern "C" int prego_miniroad_set_gru_layer_grads(prego_miniroad* h, int layer, float* g_w_ih, float* g_w_hh, float* g_b_ih, float* g_b_hh) {
+  HandleScope scope_(h);
+  if (!h) return fail(PREGO_EINVAL, "handle is NULL");
+  if (layer != 1 || h->layers != 2) return fail(PREGO_EINVAL, "set_gru_layer_grads: layer %d of a %d-layer handle (layer 0's gradients are prego_miniroad_backward's own arguments)", layer, h->layers);
+  if (!g_w_ih || !g_w_hh || !g_b_ih || !g_b_hh) return fail(PREGO_EINVAL, "set_gru_layer_grads: NULL tensor");
+  h->g_l2[0] = g_w_ih; h->g_l2[1] = g_w_hh; h->g_l2[2] = g_b_ih; h->g_l2[3] = g_b_hh;
+  return PREGO_OK;
 }
 
 extern "C" int prego_miniroad_backward_events(prego_miniroad* h, void* ev_head_done, void* ev_gru_done) {
@@ -1781,6 +1800,15 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
   float* KR = (float*)carve((size_t)cap_rows * H * 4); float* KZ = (float*)carve((size_t)cap_rows * H * 4);
   float* KN = (float*)carve((size_t)cap_rows * H * 4); float* KG = (float*)carve((size_t)cap_rows * H * 4);
   float* STATS = (float*)carve((size_t)cap_rows * 8);
+  void* HR0 = nullptr; float* HRAW2 = nullptr; float* KR2 = nullptr; float* KZ2 = nullptr; float* KN2 = nullptr; float* KG2 = nullptr;
+  if (h->layers == 2) {
+    if (!h->g_l2[0] || !h->g_l2[1] || !h->g_l2[2] || !h->g_l2[3])
+      return fail(PREGO_EINVAL, "backward of a 2-layer handle before prego_miniroad_set_gru_layer_grads(1, ...)");
+    HR0 = carve((size_t)cap_rows * H * es);
+    HRAW2 = (float*)carve((size_t)cap_rows * H * 4);
+    KR2 = (float*)carve((size_t)cap_rows * H * 4); KZ2 = (float*)carve((size_t)cap_rows * H * 4);
+    KN2 = (float*)carve((size_t)cap_rows * H * 4); KG2 = (float*)carve((size_t)cap_rows * H * 4);
+  }
   const BwdLayout L = bwd_layout(h, R, n_clips);
   if (bwd_bytes < L.total) return fail(PREGO_EWORKSPACE, "backward workspace %zu < %zu", bwd_bytes, L.total);
   char* bw = (char*)bwd_workspace;
@@ -1822,11 +1850,22 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
     launch_transpose_convert(bf, bf, h->w_c, h->ncls_pad, H, H, bw + L.WcT, Cp, s);        // [H][Cp] (rows >= ncls_pad zero)
     gemm_nt(h, bw + L.dLp, Cp, bw + L.WcT, Cp, nullptr, (float*)(bw + L.dHR), H, R, H, Cp, s);    // d relu(h)
   }
-  launch_relu_mask((const float*)(bw + L.dHR), HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);
+  launch_relu_mask((const float*)(bw + L.dHR), h->layers == 2 ? HRAW2 : HRAW, (size_t)R * H, (float*)(bw + L.dHR), s);   // the head reads the LAST layer's relu(h)
 
-  // ---- BPTT through the GRU (rnn.py:61), reverse time
-  launch_transpose_convert(bf, bf, h->w_hh, 3 * H, H, H, bw + L.WhhT, 3 * H, s);          // [H][3H]
+  // ---- BPTT through the GRU (rnn.py:61), reverse time; a stacked GRU (num_layers 2, rnn.py:32,38) runs its layers last to first:
+  // layer 1 from the head's gradient, then dH0 = dGI1 . W_ih_l1 (no relu between the layers), then layer 0 from that
   const size_t Bp = align_up((size_t)n_clips, 16);
+  for (int layer = h->layers - 1; layer >= 0; --layer) {
+  const void* L_whh = layer == 1 ? h->l2_w_hh : h->w_hh;
+  const void* L_wih = layer == 1 ? h->l2_w_ih : h->w_ih;
+  const void* L_in = layer == 1 ? HR0 : Eb;                  // the layer's input rows (operand type)
+  const int L_k = layer == 1 ? H : E;                        // ... and their width
+  float* L_hraw = layer == 1 ? HRAW2 : HRAW;
+  float* L_kr = layer == 1 ? KR2 : KR; float* L_kz = layer == 1 ? KZ2 : KZ; float* L_kn = layer == 1 ? KN2 : KN; float* L_kg = layer == 1 ? KG2 : KG;
+  float* L_gwih = layer == 1 ? h->g_l2[0] : g_w_ih; float* L_gwhh = layer == 1 ? h->g_l2[1] : g_w_hh;
+  float* L_gbih = layer == 1 ? h->g_l2[2] : g_b_ih; float* L_gbhh = layer == 1 ? h->g_l2[3] : g_b_hh;
+  const bool last_layer = layer == 0;
+  launch_transpose_convert(bf, bf, L_whh, 3 * H, H, H, bw + L.WhhT, 3 * H, s);          // [H][3H]
   float* carry[2] = {(float*)(bw + L.carry), (float*)(bw + L.carry) + Bp * H};
   float* dhpart = (float*)(bw + L.dhpart);
   // one persistent launch (gru_bptt.hip); the step-by-step loop below is the fallback for shapes it does not take and the
@@ -1838,7 +1877,7 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
     const int nct = (slots + 15) / 16;
     if (!stepwise) {
       BpttArgs ba;
-      ba.whhT = bw + L.WhhT; ba.dHout = (const float*)(bw + L.dHR); ba.R = KR; ba.Z = KZ; ba.N = KN; ba.GHN = KG; ba.Hraw = HRAW;
+      ba.whhT = bw + L.WhhT; ba.dHout = (const float*)(bw + L.dHR); ba.R = L_kr; ba.Z = L_kz; ba.N = L_kn; ba.GHN = L_kg; ba.Hraw = L_hraw;
       // the fp32 copies of dGI / dGH are read by the exact-fp32 path only (column sums, transposes): a bf16 handle's k-major GEMMs take
       // the operand copies, so its BPTT kernel does not store them at all
       ba.dGI = tn ? nullptr : (float*)(bw + L.dGI); ba.dGH = tn ? nullptr : (float*)(bw + L.dGH); ba.dGIop = bw + L.dGIop; ba.dGHop = bw + L.dGHop;
@@ -1852,41 +1891,45 @@ extern "C" int prego_miniroad_backward(prego_miniroad* h, int n_clips, const int
     const int na = h->h_nact[t];
     const int na_next = t + 1 < h->t_max ? h->h_nact[t + 1] : 0;
     const int row_t = h->h_rowoff[t], row_tm1 = t > 0 ? h->h_rowoff[t - 1] : 0;
-    launch_gru_bwd_step(bf, t, na, na_next, row_t, row_tm1, H, (const float*)(bw + L.dHR), carry[(t + 1) & 1], dhpart, KR,
-                        KZ, KN, KG, HRAW, carry[t & 1], (float*)(bw + L.dGI), (float*)(bw + L.dGH), bw + L.dGIop,
+    launch_gru_bwd_step(bf, t, na, na_next, row_t, row_tm1, H, (const float*)(bw + L.dHR), carry[(t + 1) & 1], dhpart, L_kr,
+                        L_kz, L_kn, L_kg, L_hraw, carry[t & 1], (float*)(bw + L.dGI), (float*)(bw + L.dGH), bw + L.dGIop,
                         bw + L.dGHop, s);
     if (t > 0)   // dh_{t-1} += dgh_t . W_hh
       gemm_nt(h, bw + L.dGHop + (size_t)row_t * 3 * H * es, 3 * H, bw + L.WhhT, 3 * H, nullptr, dhpart, H, na, H, 3 * H, s);
   }
-  launch_build_hprev(bf, HRAW, h->d_rowoff, h->t_max, R, H, bw + L.Hprev, s);
+  launch_build_hprev(bf, L_hraw, h->d_rowoff, h->t_max, R, H, bw + L.Hprev, s);
   if (tn) {
     // dW_ih = dGI^T . e (+ db_ih), dW_hh = dGH^T . h_{t-1} (+ db_hh): bias sums from the bf16 operand copies the BPTT kernel wrote
-    if (launch_gemm_bf16_tn(true, true, bw + L.dGIop, 3 * H, Eb, E, nullptr, g_w_ih, E, 3 * H, E, Rp, R, g_b_ih, s) ||
-        launch_gemm_bf16_tn(true, true, bw + L.dGHop, 3 * H, bw + L.Hprev, H, nullptr, g_w_hh, H, 3 * H, H, Rp, R, g_b_hh, s))
+    if (launch_gemm_bf16_tn(true, true, bw + L.dGIop, 3 * H, L_in, L_k, nullptr, L_gwih, L_k, 3 * H, L_k, Rp, R, L_gbih, s) ||
+        launch_gemm_bf16_tn(true, true, bw + L.dGHop, 3 * H, bw + L.Hprev, H, nullptr, L_gwhh, H, 3 * H, H, Rp, R, L_gbhh, s))
       return fail(PREGO_EINVAL, "backward: GRU wgrad shape");
   } else {
     // biases of the GRU
-    launch_colsum((const float*)(bw + L.dGI), R, 3 * H, part, g_b_ih, s);
-    launch_colsum((const float*)(bw + L.dGH), R, 3 * H, part, g_b_hh, s);
+    launch_colsum((const float*)(bw + L.dGI), R, 3 * H, part, L_gbih, s);
+    launch_colsum((const float*)(bw + L.dGH), R, 3 * H, part, L_gbhh, s);
     // dW_ih = dGI^T . e
     launch_transpose_convert(bf, bf, bw + L.dGIop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
-    launch_transpose_convert(bf, bf, Eb, R, E, E, bw + L.T2, Rp, s);
-    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_ih, E, 3 * H, E, Rp, s);
+    launch_transpose_convert(bf, bf, L_in, R, L_k, L_k, bw + L.T2, Rp, s);
+    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, L_gwih, L_k, 3 * H, L_k, Rp, s);
     // dW_hh = dGH^T . h_{t-1}
     launch_transpose_convert(bf, bf, bw + L.dGHop, R, 3 * H, 3 * H, bw + L.T1, Rp, s);
     launch_transpose_convert(bf, bf, bw + L.Hprev, R, H, H, bw + L.T2, Rp, s);
-    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, g_w_hh, H, 3 * H, H, Rp, s);
+    gemm_nt(h, bw + L.T1, Rp, bw + L.T2, Rp, nullptr, L_gwhh, H, 3 * H, H, Rp, s);
   }
-  if (h->bwd_ev[1]) HIPCHK(hipEventRecord(h->bwd_ev[1], s));            // all four GRU gradients are final (layer1 / LayerNorm follow)
-  if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 1);
-  // d e = dGI . W_ih
+  if (last_layer) {
+    if (h->bwd_ev[1]) HIPCHK(hipEventRecord(h->bwd_ev[1], s));          // every GRU gradient is final (layer1 / LayerNorm follow)
+    if (h->bwd_cb) h->bwd_cb(h->bwd_cb_user, 1);
+  }
+  // gradient of the layer's input = dGI . W_ih: d e for layer 0 (LayerNorm's output), dH0 - the next BPTT's dHout, as it is - for layer 1
+  float* L_din = last_layer ? (float*)(bw + L.dE) : (float*)(bw + L.dHR);
   if (tn) {
-    if (launch_gemm_bf16_tn(false, true, bw + L.dGIop, 3 * H, h->w_ih, E, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, 3 * H, nullptr, s))
+    if (launch_gemm_bf16_tn(false, true, bw + L.dGIop, 3 * H, L_wih, L_k, nullptr, L_din, L_k, R, L_k, 3 * H, 3 * H, nullptr, s))
       return fail(PREGO_EINVAL, "backward: W_ih dgrad shape");
   } else {
-    launch_transpose_convert(bf, bf, h->w_ih, 3 * H, E, E, bw + L.WihT, 3 * H, s);          // [E][3H]
-    gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, (float*)(bw + L.dE), E, R, E, 3 * H, s);
+    launch_transpose_convert(bf, bf, L_wih, 3 * H, L_k, L_k, bw + L.WihT, 3 * H, s);        // [K][3H]
+    gemm_nt(h, bw + L.dGIop, 3 * H, bw + L.WihT, 3 * H, nullptr, L_din, L_k, R, L_k, 3 * H, s);
   }
+  }   // layers, last to first
 
   // ---- Dropout / ReLU / LayerNorm backward (rnn.py:41-43)
   const int nb = launch_ln_relu_bwd((const float*)(bw + L.dE), Y, STATS, h->ln_g, h->ln_b, R, E, h->drop_p, h->drop_seed, 0,

@@ -16,6 +16,17 @@ _PARAM_ORDER = [
     "gru.weight_ih_l0", "gru.weight_hh_l0", "gru.bias_ih_l0", "gru.bias_hh_l0",
     "f_classification.0.weight", "f_classification.0.bias",
 ]
+_L1_KEYS = ["gru.weight_ih_l1", "gru.weight_hh_l1", "gru.bias_ih_l1", "gru.bias_hh_l1"]       # nn.GRU(num_layers=2), rnn.py:32,38
+
+
+def param_order(num_layers: int = 1):
+    """the parameters a training step differentiates, in the flat gradient bucket's order: layer1 / LayerNorm | GRU layer 0 (| GRU layer
+    1) | head - the order the backward finishes its three sub-buckets in, reversed"""
+    if num_layers == 1:
+        return list(_PARAM_ORDER)
+    k = _PARAM_ORDER.index("f_classification.0.weight")
+    return _PARAM_ORDER[:k] + _L1_KEYS + _PARAM_ORDER[k:]
+
 
 
 def plan_passes(lens, max_clips: int, single: bool = False, max_slots: int = 512):
@@ -340,22 +351,25 @@ class MiniRoadEngine:
                   "f_classification.0.bias": (ncls,)}
         # one flat fp32 bucket (17.9 M elements = 71.7 MB), the ten gradients are views into it: data-parallel training
         # all-reduces the bucket in place (no gather / scatter copies around the collective)
-        sizes = [int(torch.Size(shapes[k]).numel()) for k in _PARAM_ORDER]
+        order = param_order(self.num_layers)
+        if self.num_layers == 2:
+            shapes.update({"gru.weight_ih_l1": (3 * hid, hid), "gru.weight_hh_l1": (3 * hid, hid), "gru.bias_ih_l1": (3 * hid,), "gru.bias_hh_l1": (3 * hid,)})
+        sizes = [int(torch.Size(shapes[k]).numel()) for k in order]
         offs, total = [], 0
         guard_off = None
-        for k, n in zip(_PARAM_ORDER, sizes):
+        for k, n in zip(order, sizes):
             if k == "gru.weight_ih_l0":             # end of the layer1 / LayerNorm bucket (the LAST one the backward finishes): one slot of
                 guard_off, total = total, total + 64    # 64 floats whose first element carries this rank's timeout flag through the all-reduce
             offs.append(total)
             total += (n + 63) // 64 * 64            # 256-byte aligned views
         self._grad_flat = torch.empty(total, dtype=torch.float32, device=self.device)   # every gradient tensor is overwritten by backward
-        grads = {k: self._grad_flat[o:o + n].view(shapes[k]) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}
+        grads = {k: self._grad_flat[o:o + n].view(shapes[k]) for k, o, n in zip(order, offs, sizes)}
         # buckets of the flat tensor in the order the backward finishes them (csrc/miniroad.cpp: head, GRU, then LayerNorm / layer1):
         # the first two are announced by events recorded inside the backward, the last one is final when backward returns
-        o_ih, o_fc = offs[_PARAM_ORDER.index("gru.weight_ih_l0")], offs[_PARAM_ORDER.index("f_classification.0.weight")]
+        o_ih, o_fc = offs[order.index("gru.weight_ih_l0")], offs[order.index("f_classification.0.weight")]
         self._grad_bounds = [(o_fc, total), (o_ih, o_fc), (0, o_ih)]       # bucket 2 ends with the guard slot
         self._guard_off = guard_off
-        self._grad_offsets = {k: (o, n) for k, o, n in zip(_PARAM_ORDER, offs, sizes)}     # where each tensor lives in the flat bucket
+        self._grad_offsets = {k: (o, n) for k, o, n in zip(order, offs, sizes)}     # where each tensor lives in the flat bucket
         self._grad_events = None
         self._early_done = set()
         self._cb_error = None
@@ -371,6 +385,8 @@ class MiniRoadEngine:
             self._grad_events = [self._bwd_events[0], self._bwd_events[1], None]
         dl_p = ptr_array([dlogits.data_ptr() + b * T * ncls * 4 for b in range(B)])
         with torch.cuda.device(self.device):
+            if self.num_layers == 2:        # the second layer's gradients: handed over beside the call (ABI 7)
+                check(self.lib.prego_miniroad_set_gru_layer_grads(self.h, 1, *[C.c_void_p(grads[k].data_ptr()) for k in _L1_KEYS]))
             check(self.lib.prego_miniroad_backward(
                 self.h, B, lens_arr, dl_p, *[C.c_void_p(grads[k].data_ptr()) for k in _PARAM_ORDER],
                 C.c_void_p(self._ws_train.data_ptr()), self._ws_train.numel(),
