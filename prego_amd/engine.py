@@ -188,6 +188,7 @@ class MiniRoadEngine:
         up = (C.c_int32 * n)(*[int(min(u, 2**31 - 1)) for u in upto_steps])
         ev = (C.c_void_p * n)(*[e.cuda_event for e in events])
         check(self.lib.prego_miniroad_set_feed_events(self.h, n, up, ev, int(link_row_bytes)))
+        self._link_fed_next = True          # a link-fed call keeps the per-chunk classifier: it needs no resident buffer
 
     def _forward_pass(self, rgb, flow, softmax, want_out, want_argmax, h0, h_last, outs, args, base):
         d_rgb, d_flow, emb, hid, ncls = self.dims
@@ -215,8 +216,9 @@ class MiniRoadEngine:
         lens_arr = (C.c_int32 * n)(*lens)
         flags = (_lib.FWD_SOFTMAX if softmax else 0) | (_lib.FWD_IN16 if dt != torch.float32 else 0)
         ws = self._workspace(n, lens_arr, flags)
-        if h0 is None and h_last is None:
+        if h0 is None and h_last is None and not getattr(self, "_link_fed_next", False):
             self._resident(n, lens_arr, flags)
+        self._link_fed_next = False
         rgb_p = None if rgb is None else ptr_array([r.data_ptr() for r in rgb])
         flow_p = None if flow is None else ptr_array([None if f is None else f.data_ptr() for f in flow])
         out_p = arg_p = None
