@@ -950,8 +950,9 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_mt_kernel(GruArgs a) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           u32x4 v = HB[ks];
-          if constexpr (SPEC) badv |= ((v[0] ^ eword) | (v[1] ^ eword)) | ((v[2] ^ eword) | (v[3] ^ eword));
-          v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;
+          // the xor that tests the tag also removes it (round 6, as in the classic kernel): one VALU per register instead of two
+          v[0] ^= eword; v[1] ^= eword; v[2] ^= eword; v[3] ^= eword;
+          if constexpr (SPEC) badv |= (v[0] | v[1]) | (v[2] | v[3]);
           const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
           for (int gate = 0; gate < 3; ++gate)
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_mt_kernel(GruArgs a) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {           // the same products, same order, on the valid fragments
               u32x4 v = HB[ks];
-              v[0] &= untag; v[1] &= untag; v[2] &= untag; v[3] &= untag;
+              v[0] ^= eword; v[1] ^= eword; v[2] ^= eword; v[3] ^= eword;          // valid fragments: the xor is the un-tagging
               const bf16x8 bfrag = __builtin_bit_cast(bf16x8, v);
 #pragma unroll
               for (int gate = 0; gate < 3; ++gate)

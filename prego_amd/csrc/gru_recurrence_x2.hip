@@ -205,8 +205,10 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_x2_kernel(GruArgs a, co
             unsigned badv = 0u;
 #pragma unroll
             for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks) {
-              badv |= ((hbh[ks][0] ^ eword) | (hbh[ks][1] ^ eword)) | ((hbh[ks][2] ^ eword) | (hbh[ks][3] ^ eword));
-              badv |= ((hbl[ks][0] ^ eword) | (hbl[ks][1] ^ eword)) | ((hbl[ks][2] ^ eword) | (hbl[ks][3] ^ eword));
+              // the xor that tests the tags also removes them (gru_recurrence.hip, round 6): the fragments go to the MFMAs as they are
+              hbh[ks][0] ^= eword; hbh[ks][1] ^= eword; hbh[ks][2] ^= eword; hbh[ks][3] ^= eword;
+              hbl[ks][0] ^= eword; hbl[ks][1] ^= eword; hbl[ks][2] ^= eword; hbl[ks][3] ^= eword;
+              badv |= ((hbh[ks][0] | hbh[ks][1]) | (hbh[ks][2] | hbh[ks][3])) | ((hbl[ks][0] | hbl[ks][1]) | (hbl[ks][2] | hbl[ks][3]));
             }
             return !__all(!col_live || (badv & TAGM) == 0u);
           };
@@ -237,9 +239,7 @@ __global__ __launch_bounds__(256, 1) void gru_recurrence_x2_kernel(GruArgs a, co
           }
 #pragma unroll
           for (int ks = sg * SEGK; ks < (sg + 1) * SEGK; ++ks) {
-            u32x4 vh = hbh[ks], vl = hbl[ks];
-            vh[0] &= untag; vh[1] &= untag; vh[2] &= untag; vh[3] &= untag;
-            vl[0] &= untag; vl[1] &= untag; vl[2] &= untag; vl[3] &= untag;
+            const u32x4 vh = hbh[ks], vl = hbl[ks];
             const bf16x8 fh = __builtin_bit_cast(bf16x8, vh), fl = __builtin_bit_cast(bf16x8, vl);
 #pragma unroll
             for (int gate = 0; gate < 3; ++gate) {
