@@ -4,11 +4,11 @@ Pure Python (no GPU, no library): `bench.py` prints the table into every line (`
 world-N dry-run test checks the sharding it is computed from.  The constants are the ones `csrc/miniroad.cpp` chooses the pass with
 (`prego_miniroad_forward`: chunked = recurrence estimate + rows x (projection flops at 1.4 PFLOP/s + 3 ns) + 30 us per chunk; split =
 max(steps x 2.0 us, rows x (flops at 1.4 PFLOP/s + pack bytes at 5.3 TB/s + 1.5 ns) x 8 / (8 - R)) + 1.5 ms), with the measured /
-estimated ratios of round 5's devices folded in (chunked 0.99, split 0.97): a prediction, to be held against the driver's SCALE file.
+estimated ratios of round 6's devices folded in (chunked 0.98, split 0.93): a prediction, to be held against the driver's SCALE file.
 
 Why strong scaling of the eval metric stops at ~1.6x: clips are independent but a clip is sequential (rnn.py:49,60-61: h_t needs
 h_t-1).  However many GPUs share the one 182-clip set, the rank that owns the longest clip (33 981 frames in the bench workload)
-runs 33 981 recurrence steps of ~1.6-1.8 us = 55-61 ms, against 98-101 ms for the whole set on one GPU.
+runs 33 981 recurrence steps of ~1.6-1.8 us = 55-61 ms, against 93-96 ms for the whole set on one GPU.
 """
 from __future__ import annotations
 
@@ -21,7 +21,7 @@ PACK_NS_PER_FRAME = 4096 * (4.0 + 2.0) / 5.3e12 * 1e9                        # 4
 STEP_US_CHUNKED = {16: 1.80, 8: 1.70, 4: 1.59}                                # per recurrence step at <= n live columns per group
 STEP_US_SPLIT = 2.0                                                           # in a split pass, beside the feed-forward launch
 ROWS_PER_CHUNK = 49152
-MEASURED_OVER_ESTIMATED = {"chunked": 0.99, "split": 0.97}                    # round-5 devices
+MEASURED_OVER_ESTIMATED = {"chunked": 0.98, "split": 0.93}                    # round-6 devices: 119.7 / 94.8 ms measured
 
 
 def _lpt_max_load(lens: Sequence[int], slots: int) -> int:
@@ -89,9 +89,9 @@ def predict_eval_scaling(lens_of_rank0: Sequence[int], lens_fn=None, worlds: Seq
     return out
 
 
-# training step (BASELINE configs[2]): measured 1.258 ms at 16 windows per GPU and 1.072 ms at 2 (profiles/r05_bench_line_train*.json):
-# 128 + 128 sequential recurrence / BPTT steps are the fixed part, the GEMMs the part that scales with the local batch
-TRAIN_FIXED_MS, TRAIN_MS_PER_WINDOW = 1.045, 0.0133
+# training step (BASELINE configs[2]): measured 1.181 ms at 16 windows per GPU and 1.009 ms at 2 (profiles/r06_bench_line_train*.json;
+# round 5: 1.258 / 1.072): 128 + 128 sequential recurrence / BPTT steps are the fixed part, the GEMMs the part that scales with the batch
+TRAIN_FIXED_MS, TRAIN_MS_PER_WINDOW = 0.984, 0.0123
 GRAD_BYTES = 71_704_920
 XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU, point to point
 
