@@ -90,7 +90,9 @@ int prego_miniroad_create(prego_miniroad** out, int d_rgb, int d_flow, int emb, 
 /* The same with cfg['num_layers'] (rnn.py:32,38: nn.GRU(embedding_dim, hidden_dim, num_layers)): 1 or 2.  Hidden sizes (rnn.py:31): 512,
  * 1024, 2048 with 16-bit operands; 512, 1024 with PREGO_F32; 1024 with PREGO_F16X2 (the recurrence keeps its slice of W_hh in registers:
  * what does not fit is refused here with a message).  Two layers: PREGO_F32 / PREGO_BF16 / PREGO_F16.  Inference (forward without
- * PREGO_FWD_KEEP) covers all of these; training, prego_miniroad_step and the split pass stay with hidden_dim 1024 / one layer. */
+ * PREGO_FWD_KEEP) covers all of these, and since ABI 7 so does training (PREGO_FWD_KEEP + prego_miniroad_backward; PREGO_BF16 / PREGO_F32
+ * handles, hidden_dim 2048: PREGO_BF16; two layers: prego_miniroad_set_gru_layer_grads); prego_miniroad_step and the split pass stay with
+ * hidden_dim 1024 / one layer. */
 int prego_miniroad_create_layers(prego_miniroad** out, int d_rgb, int d_flow, int emb, int hid, int n_classes, int num_layers,
                                  int compute_dtype);
 void prego_miniroad_destroy(prego_miniroad* h);
