@@ -46,6 +46,11 @@ int prego_debug_set_abort(prego_miniroad* h, unsigned value, prego_stream_t stre
  * this process (prego_miniroad_check's own synchronisation counts).  A test calls it around a hot call to hold "forward() allocates
  * nothing and waits for nothing" to zero (include/prego_amd.h, conventions). */
 int prego_debug_alloc_count(int64_t* device_mallocs, int64_t* host_waits);
+/* probe: a synthetic neighbour on XCDs >= xcd_lo for `ms` milliseconds - kind 1: back-to-back MFMAs on registers, no
+ * memory traffic; kind 2: streaming reads of read_buf (+ one write per eight reads into write_buf), no matrix work; kind 3: both.
+ * Launched on its own stream beside a replayed recurrence launch (prego_debug_split_fault mode 4) it separates what that launch loses to
+ * power / clocks from what it loses to the fabric.  bytes: size of each of the two buffers (>= 1 MiB).  sink: one device float. */
+int prego_debug_hog(int kind, int xcd_lo, int ms, const void* read_buf, void* write_buf, size_t bytes, float* sink, prego_stream_t stream);
 
 /* Debug / microbenchmark only: C[M,N] fp32 = A[M,K] bf16 . B[N,K]^T bf16 + bias with a chosen kernel variant
  * (0 = 128x128, 1 = 256x128 three-stage, 9 = 256x256 two-stage, 12 = the ping-pong kernel = the production kernel of the projections; scripts/gemm_bench.py).  N % 128 == 0 (256 for variants >= 9), K % 64 == 0. */

@@ -42,7 +42,7 @@ SYMBOLS = [
 # include/prego_amd_debug.h: only in libprego_amd_debug.so
 DEBUG_SYMBOLS = ["prego_miniroad_debug_stamps", "prego_debug_gemm_bf16", "prego_debug_attention_bwd", "prego_debug_attention_fwd",
                  "prego_debug_recurrence_only", "prego_debug_gemm_worker", "prego_debug_head_only",
-                 "prego_debug_split_fault", "prego_debug_split_state", "prego_debug_set_abort", "prego_debug_alloc_count"]
+                 "prego_debug_split_fault", "prego_debug_split_state", "prego_debug_set_abort", "prego_debug_alloc_count", "prego_debug_hog"]
 
 
 class PregoError(RuntimeError):
@@ -160,6 +160,7 @@ def _open(path: str, debug: bool) -> C.CDLL:
         lib.prego_debug_split_state.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i64), C.POINTER(i32)]
         lib.prego_debug_set_abort.argtypes = [vp, C.c_uint32, vp]
         lib.prego_debug_alloc_count.argtypes = [C.POINTER(i64), C.POINTER(i64)]
+        lib.prego_debug_hog.argtypes = [i32, i32, i32, vp, vp, sz, vp, vp]
     return lib
 
 

@@ -29,6 +29,7 @@ def _newer(a, b):
 
 DEBUG_LIB = os.path.join(LIBDIR, "libprego_amd_debug.so")
 DEBUG_ABI_SOURCES = ("miniroad.cpp", "vit_host.cpp")       # the only files that define prego_debug_* entry points (include/prego_amd_debug.h)
+DEBUG_ONLY_SOURCES = ("debug_hog.hip",)                    # kernels of probe hooks: linked into libprego_amd_debug.so only
 
 
 def _tree_hash() -> str:
@@ -64,7 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         sp = os.path.join(CSRC, src)
         op = os.path.join(LIBDIR, src.replace(".", "_") + ".o")
-        objs.append(op)
+        if src not in DEBUG_ONLY_SOURCES:
+            objs.append(op)
         variants = [(op, [])]
         if src in DEBUG_ABI_SOURCES:
             dop = os.path.join(LIBDIR, src.replace(".", "_") + "_dbg.o")

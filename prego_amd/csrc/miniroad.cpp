@@ -200,6 +200,14 @@ static std::atomic<long long> g_dbg_mallocs{0}, g_dbg_syncs{0};
 #define hipMalloc(p, n) (++g_dbg_mallocs, (hipMalloc)(p, n))
 #define hipStreamSynchronize(s) (++g_dbg_syncs, (hipStreamSynchronize)(s))
 #define hipEventSynchronize(e) (++g_dbg_syncs, (hipEventSynchronize)(e))
+void launch_debug_hog(int xcd_lo, int kind, int ms, const void* buf, void* wbuf, size_t bytes, float* sink, hipStream_t s);     // debug_hog.hip
+extern "C" int prego_debug_hog(int kind, int xcd_lo, int ms, const void* read_buf, void* write_buf, size_t bytes, float* sink, prego_stream_t stream) {
+  if (kind < 1 || kind > 3 || xcd_lo < 0 || xcd_lo > 7 || ms <= 0 || !sink || ((kind & 2) && (!read_buf || !write_buf || bytes < (1u << 20))))
+    return fail(PREGO_EINVAL, "debug hog: bad arguments");
+  launch_debug_hog(xcd_lo, kind, ms, read_buf, write_buf, bytes, sink, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return PREGO_OK;
+}
 extern "C" int prego_debug_alloc_count(int64_t* device_mallocs, int64_t* host_waits) {
   if (device_mallocs) *device_mallocs = g_dbg_mallocs.load();
   if (host_waits) *host_waits = g_dbg_syncs.load();
