@@ -208,13 +208,105 @@ __device__ __forceinline__ void ffp_tile(char* smem, const bf16_t* __restrict__ 
 
 // rows [row0, row0 + nrows) of the packed feature matrix (pack_rows_kernel's element arithmetic).  A wave owns 32 consecutive rows: lanes
 // 0 .. 31 look their (clip, frame) up side by side (one chain of table reads per wave instead of one per row: a persistent workgroup has
-// no other workgroups to hide that latency behind), then the wave streams its rows through two register buffers (below).
+// no other workgroups to hide that latency behind), then the wave streams its rows through two register buffers.
+//
+// Round 6: every access of the stream is a BUFFER access on a per-row resource.  The source rows come out of a pointer TABLE, so as plain
+// pointers they are generic-address-space: hipcc loaded them with flat_load_dwordx4 behind a branch per load (a NULL flow row, a column
+// beyond the row) and - flat accesses return in no order the counter can express - waited with vmcnt(0) + lgkmcnt(0) in front of every
+// drain: burst, wait, burst, 202 us per 256-row job = 31 GB/s per CU (ISA; profiles/r06_pass_clock.log).  A buffer resource whose
+// num_records is the row's byte length (0 for a missing row) returns zeros for what lies outside and drops stores outside, so the stream
+// has no branch, the loads are counted in order, and a round of loads is in flight while the round before it is converted and stored.
+// What that bought: 202 -> 190 us per job, no more - with two rounds in flight the job moves 6.3 MB at 33-37 GB/s, which is what ONE CU
+// takes in from HBM (the stand-alone pack kernel at 5.3 TB/s is 21 GB/s per CU; the job alone on the chip, every other job skipped, takes
+// 162 us: profiles/r06_rowjobs_alone.log).  Eight rows x one 512-column chunk per round instead of two rows x four (the rows' pages opened
+// side by side) is 7 % slower (profiles/r06_pack_wide.log).  The job's cost is the CU it occupies while it waits for memory.
+template <typename OT, bool IN16>
+__device__ __forceinline__ void ffp_pack_rows(const FfPassArgs& a, int my_rows, int wave, int lane, const char* srgb, const char* sflow,
+                                              bf16_t* __restrict__ Xs) {
+  constexpr int ES = IN16 ? 2 : 4, NV = IN16 ? 1 : 2;
+  constexpr int PR = 2;                                          // rows per round
+  const int din = a.kx;
+  // a round = PR rows x 2 048 columns of ONE source (four 512-column chunks, 8 columns per lane and chunk): rgb's column rounds, then flow's
+  const int cr_rgb = (a.d_rgb + 2047) >> 11, cpr = cr_rgb + ((a.d_flow + 2047) >> 11);
+  const int n_rounds = my_rows > 0 ? ((my_rows + PR - 1) / PR) * cpr : 0;
+  auto readlane_ptr = [](const char* p, int l) -> const char* {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return (const char*)(((unsigned long long)hi << 32) | lo);
+  };
+  // lane offsets of the stream, loop-invariant and opaque (the compiler otherwise rebuilds them in registers a pending load still owns
+  // and waits for that load): the column window moves the resource's BASE, not the offset
+  int voff_in = lane * 8 * ES, voff_in2 = voff_in + 1024 * ES, voff_out = lane * 16;
+  asm volatile("" : "+v"(voff_in), "+v"(voff_in2), "+v"(voff_out));
+  auto issue = [&](u32x4 (&v)[PR][4][NV], int k) {
+    const int rp = k / cpr, cj = k - rp * cpr;
+    const bool fl = cj >= cr_rgb;
+    const int cwin = (fl ? cj - cr_rgb : cj) << 11, seg_len = fl ? a.d_flow : a.d_rgb;
+#pragma unroll
+    for (int e = 0; e < PR; ++e) {
+      const int r = rp * PR + e, rr = r < my_rows ? r : 0;
+      const char* s0 = readlane_ptr(srgb, rr);
+      const char* s1 = readlane_ptr(sflow, rr);
+      const char* src = fl ? s1 : s0;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)cwin * ES), 0,
+                                                                          (r < my_rows && src != nullptr) ? (seg_len - cwin) * ES : 0, 0x00020000);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int w = 0; w < NV; ++w)
+          v[e][b][w] = __builtin_amdgcn_raw_buffer_load_b128(rs, (b < 2 ? voff_in : voff_in2) + ((b & 1) * 512 * ES + 16 * w), 0, AUX_NT);
+    }
+  };
+  auto drain = [&](const u32x4 (&v)[PR][4][NV], int k) {
+    const int rp = k / cpr, cj = k - rp * cpr;
+    const bool fl = cj >= cr_rgb;
+    const int cwin = (fl ? cj - cr_rgb : cj) << 11, seg_len = fl ? a.d_flow : a.d_rgb, seg_base = fl ? a.d_rgb : 0;
+#pragma unroll
+    for (int e = 0; e < PR; ++e) {
+      const int r = rp * PR + e;
+      bf16_t* dst = Xs + (size_t)(wave * 32 + (r < my_rows ? r : 0)) * din + seg_base + cwin;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, r < my_rows ? (seg_len - cwin) * 2 : 0, 0x00020000);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        u32x4 o = v[e][b][0];
+        if constexpr (!IN16) {
+          const u32x4 x = v[e][b][0], y = v[e][b][NV - 1];
+          o[0] = op16<OT>::pack2_sat(__uint_as_float(x[0]), __uint_as_float(x[1])); o[1] = op16<OT>::pack2_sat(__uint_as_float(x[2]), __uint_as_float(x[3]));
+          o[2] = op16<OT>::pack2_sat(__uint_as_float(y[0]), __uint_as_float(y[1])); o[3] = op16<OT>::pack2_sat(__uint_as_float(y[2]), __uint_as_float(y[3]));
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs, voff_out + b * 1024, 0, 0);
+      }
+    }
+  };
+  // steady state without a condition on the issues: the wait-count pass takes the FEWEST outstanding loads over the paths that meet at a
+  // join, so a skipped issue on one path makes every wait of the other one wait for the round it should leave in flight
+  u32x4 va[PR][4][NV], vb[PR][4][NV];
+  if (n_rounds == 0) return;
+  issue(va, 0);
+  int k = 0;
+  // (and with the phases fenced: left alone, the scheduler converts a round right behind its own loads - ISA)
+#define PACK_FENCE() __builtin_amdgcn_sched_barrier(0)
+  for (; k + 2 < n_rounds; k += 2) {
+    issue(vb, k + 1); PACK_FENCE();
+    drain(va, k); PACK_FENCE();
+    issue(va, k + 2); PACK_FENCE();
+    drain(vb, k + 1); PACK_FENCE();
+  }
+  if (k + 1 < n_rounds) {
+    issue(vb, k + 1); PACK_FENCE();
+    drain(va, k); PACK_FENCE();
+    drain(vb, k + 1);
+  } else {
+    drain(va, k);
+  }
+#undef PACK_FENCE
+}
+
 template <typename OT>
 __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrows, bf16_t* __restrict__ Xs) {
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));      // per call (see ffp_tile): nothing lane-derived is carried across the job loop
-  const int lane = tid_ & 63, wave = tid_ >> 6;
-  const int din = a.kx;
+  const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
   const int rl = wave * 32 + (lane & 31);                       // my row of the unit (lanes 32 .. 63 mirror 0 .. 31)
   int clip = 0, t = 0;
   if (rl < nrows) {
@@ -237,64 +329,149 @@ __device__ __forceinline__ void ffp_pack(const FfPassArgs& a, int row0, int nrow
     if (rgb) srgb = (const char*)rgb + (size_t)t * a.d_rgb * es;
     if (flow) sflow = (const char*)flow + (size_t)t * a.d_flow * es;
   }
-  // rounds of PR rows x four 512-column chunks (32 B per lane and chunk), double buffered: round k + 1 is requested before round k is
-  // converted and stored, so the wave always has a round of loads in flight (burst - wait - burst left a persistent workgroup at 28 GB/s)
-  constexpr int PR = 2;
-  const int cpr = (din + 2047) / 2048;                           // column rounds per row batch
   const int my_rows = nrows - wave * 32 < 32 ? nrows - wave * 32 : 32;
-  const int n_rounds = my_rows > 0 ? ((my_rows + PR - 1) / PR) * cpr : 0;
-  auto issue = [&](u32x4 (&v)[PR][4][2], int k) {
-    const int rr = (k / cpr) * PR, c0 = lane * 8 + (k % cpr) * 2048;
-#pragma unroll
-    for (int e = 0; e < PR; ++e) {
-      const char* pr_ = (const char*)__shfl((unsigned long long)srgb, rr + e, 64);
-      const char* pf_ = (const char*)__shfl((unsigned long long)sflow, rr + e, 64);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c = c0 + b * 512;
-        const char* src = nullptr;
-        if (c < din && rr + e < my_rows) src = c < a.d_rgb ? (pr_ ? pr_ + (size_t)c * es : nullptr) : (pf_ ? pf_ + (size_t)(c - a.d_rgb) * es : nullptr);
-        v[e][b][0] = (u32x4){0u, 0u, 0u, 0u}; v[e][b][1] = v[e][b][0];
-        if (src) {
-          v[e][b][0] = __builtin_nontemporal_load((const u32x4*)src);
-          if (!a.in16) v[e][b][1] = __builtin_nontemporal_load((const u32x4*)src + 1);
-        }
-      }
-    }
-  };
-  auto drain = [&](const u32x4 (&v)[PR][4][2], int k) {
-    const int rr = (k / cpr) * PR, c0 = lane * 8 + (k % cpr) * 2048;
-#pragma unroll
-    for (int e = 0; e < PR; ++e)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c = c0 + b * 512;
-        if (c < din && rr + e < my_rows) {
-          u32x4 o = v[e][b][0];
-          if (!a.in16) {
-            const u32x4 x = v[e][b][0], y = v[e][b][1];
-            o[0] = op16<OT>::pack2_sat(__uint_as_float(x[0]), __uint_as_float(x[1])); o[1] = op16<OT>::pack2_sat(__uint_as_float(x[2]), __uint_as_float(x[3]));
-            o[2] = op16<OT>::pack2_sat(__uint_as_float(y[0]), __uint_as_float(y[1])); o[3] = op16<OT>::pack2_sat(__uint_as_float(y[2]), __uint_as_float(y[3]));
-          }
-          *(u32x4*)(Xs + (size_t)(wave * 32 + rr + e) * din + c) = o;
-        }
-      }
-  };
-  u32x4 va[PR][4][2], vb[PR][4][2];
-  if (n_rounds > 0) issue(va, 0);
-  for (int k = 0; k < n_rounds; k += 2) {
-    if (k + 1 < n_rounds) issue(vb, k + 1);
-    drain(va, k);
-    if (k + 2 < n_rounds) issue(va, k + 2);
-    if (k + 1 < n_rounds) drain(vb, k + 1);
-  }
+  if (a.in16) ffp_pack_rows<OT, true>(a, my_rows, wave, lane, srgb, sflow, Xs);
+  else ffp_pack_rows<OT, false>(a, my_rows, wave, lane, srgb, sflow, Xs);
 }
+
+constexpr int FLN_MAX_E = 2048;       // embedding_dim up to which ff_pass_kernel keeps LayerNorm's gamma / beta in LDS (16 KB beside the GEMM buffers)
 
 // LayerNorm + ReLU of nrows 16-bit rows (ln_relu_rows_kernel's arithmetic: two-pass statistics, same summation order), a wave per row, NR
 // rows of a wave in flight together and the NEXT NR rows requested before this batch is reduced (a lone row is three dependent round
-// trips - load, two wave reductions - and a persistent workgroup has nobody to hide them behind: 111 us per 256-row job without the prefetch)
+// trips - load, two wave reductions - and a persistent workgroup has nobody to hide them behind: 111 us per 256-row job without the prefetch).
+// Round 6: that prefetch never overlapped anything (ISA: the request sat behind a condition, so the wait-count pass waited with vmcnt(0)
+// where the paths met, and the gamma / beta loads inside the store loop waited for it a second time): NV is a template parameter (no
+// branch per load), gamma / beta come from an LDS copy the workgroup makes once per launch (`gb`: LDS reads are counted by lgkmcnt and
+// wait for no row in flight; as registers they are 16 NV per lane and the job spills), the batches alternate between two register sets
+// with unconditional requests in the steady state, and the phases are fenced against the scheduler.
+template <typename OT, int NV, int NR>
+__device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es, const float* gb) {
+  int tid_ = threadIdx.x;
+  asm volatile("" : "+v"(tid_));      // per call (see ffp_tile)
+  const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+  const int E = NV * 512;
+  const float fE = (float)a.E;        // the divisor stays a run-time value
+  if (wave >= nrows) return;
+  auto request = [&](u32x4 (&dst)[NR][NV], int rb) {
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      int r = rb + 8 * e;
+      if (r >= nrows) r = wave;                                  // a missing row repeats an existing one (its result is not stored)
+      const bf16_t* y = Ys + (size_t)r * E;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) dst[e][i] = *(const u32x4*)(y + (i * 64 + lane) * 8);
+    }
+  };
+  // the rows stay in their 16-bit form (raw) and are unpacked where they are used - three times: the fp32 copy of NR rows would be
+  // 32 NR registers on top of the two raw batches
+  auto unpack = [](const u32x4 w, float (&f)[8]) {
+    f[0] = op16<OT>::lo(w[0]); f[1] = op16<OT>::hi(w[0]); f[2] = op16<OT>::lo(w[1]); f[3] = op16<OT>::hi(w[1]);
+    f[4] = op16<OT>::lo(w[2]); f[5] = op16<OT>::hi(w[2]); f[6] = op16<OT>::lo(w[3]); f[7] = op16<OT>::hi(w[3]);
+  };
+  auto process = [&](const u32x4 (&raw)[NR][NV], int rb) {
+    float s[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      s[e] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float f[8];
+        unpack(raw[e][i], f);
+        s[e] += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+      }
+    }
+    // wave_sum's butterfly on the NR rows side by side (same pairs, same order: bit-identical; one cross-lane round trip per level
+    // instead of NR)
+    auto wave_sum_rows = [](float (&v)[NR]) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        float t[NR];
+#pragma unroll
+        for (int e = 0; e < NR; ++e) t[e] = __shfl_xor(v[e], o, 64);
+#pragma unroll
+        for (int e = 0; e < NR; ++e) v[e] += t[e];
+      }
+    };
+    float mu[NR], rstd[NR];
+    wave_sum_rows(s);
+#pragma unroll
+    for (int e = 0; e < NR; ++e) mu[e] = s[e] / fE;
+#pragma unroll
+    for (int e = 0; e < NR; ++e) {
+      float qq = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float f[8];
+        unpack(raw[e][i], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // d * d is rounded before it is added: ln_relu_rows_kernel's squares compile to packed multiplies (v_pk_mul_f32), which cannot
+          // fuse with the add; under -ffp-contract=fast this loop would become v_fmac_f32 and about one row in 150 would differ from the
+          // chunked pass in the last bit of an output (tests/test_gpu_split.py holds the two passes to bit-identity)
+#pragma clang fp contract(off)
+          const float d = f[k] - mu[e];
+          const float dd = d * d;
+          qq = qq + dd;
+        }
+      }
+      rstd[e] = qq;
+    }
+    wave_sum_rows(rstd);
+#pragma unroll
+    for (int e = 0; e < NR; ++e) rstd[e] = 1.0f / sqrtf(rstd[e] / fE + a.ln_eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 8;
+#ifdef FFP_LN_GB_GLOBAL
+      const float4 g0 = *(const float4*)(a.ln_g + c), g1 = *(const float4*)(a.ln_g + c + 4);
+      const float4 b0 = *(const float4*)(a.ln_b + c), b1 = *(const float4*)(a.ln_b + c + 4);
+#else
+      const float4 g0 = *(const float4*)(gb + c), g1 = *(const float4*)(gb + c + 4);
+      const float4 b0 = *(const float4*)(gb + FLN_MAX_E + c), b1 = *(const float4*)(gb + FLN_MAX_E + c + 4);
+#endif
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < NR; ++e) {
+        float f[8], o[8];
+        unpack(raw[e][i], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = fmaxf((f[k] - mu[e]) * rstd[e] * gg[k] + bb[k], 0.f);
+        uint4 w;
+        w.x = op16<OT>::pack2_sat(o[0], o[1]); w.y = op16<OT>::pack2_sat(o[2], o[3]); w.z = op16<OT>::pack2_sat(o[4], o[5]); w.w = op16<OT>::pack2_sat(o[6], o[7]);
+        if (rb + 8 * e < nrows) *(uint4*)(Es + (size_t)(rb + 8 * e) * E + c) = w;
+      }
+    }
+  };
+  constexpr int STEP = 8 * NR;
+#ifdef FFP_LN_NOFENCE
+#define LN_FENCE()
+#else
+#define LN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+  u32x4 ra[NR][NV], rbuf[NR][NV];
+  int rb = wave;
+  request(ra, rb); LN_FENCE();
+  for (; rb + 2 * STEP < nrows; rb += 2 * STEP) {
+    request(rbuf, rb + STEP); LN_FENCE();
+    process(ra, rb); LN_FENCE();
+    request(ra, rb + 2 * STEP); LN_FENCE();
+    process(rbuf, rb + STEP); LN_FENCE();
+  }
+  if (rb + STEP < nrows) {
+    request(rbuf, rb + STEP); LN_FENCE();
+    process(ra, rb); LN_FENCE();
+    process(rbuf, rb + STEP);
+  } else {
+    process(ra, rb);
+  }
+#undef LN_FENCE
+}
+
+// any E / 512 (runtime nv <= MAXV): the form every embedding_dim but 512 / 1 024 / 2 048 runs (loads behind a branch each, gamma / beta
+// per batch: correct, and as slow as the comment above says)
 template <typename OT, int MAXV, int NR>
-__device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
+__device__ __forceinline__ void ffp_ln_generic(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es) {
   int tid_ = threadIdx.x;
   asm volatile("" : "+v"(tid_));      // per call (see ffp_tile)
   const int lane = tid_ & 63, wave = tid_ >> 6;
@@ -344,7 +521,12 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
           float f[8];
           unpack(raw[e][i], f);
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { const float d = f[k] - mu[e]; qq += d * d; }
+          for (int k = 0; k < 8; ++k) {
+#pragma clang fp contract(off)                                    // as in ffp_ln below
+            const float d = f[k] - mu[e];
+            const float dd = d * d;
+            qq = qq + dd;
+          }
         }
       rstd[e] = qq;
     }
@@ -380,6 +562,19 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
 }
 
 template <typename OT>
+__device__ __forceinline__ void ffp_ln_any(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es, const float* gb) {
+#ifdef FFP_LN_GENERIC                                              // A/B builds (scripts/build_alt.sh): every embedding_dim on the generic job
+  ffp_ln_generic<OT, 8, 2>(a, nrows, Ys, Es); return;
+#endif
+  switch (a.E >> 9) {                                            // E / 512 (launch_ff_pass: E % 512 == 0, E <= 4096)
+    case 4: ffp_ln<OT, 4, 2>(a, nrows, Ys, Es, gb); break;      // the shipped embedding_dim
+    case 2: ffp_ln<OT, 2, 4>(a, nrows, Ys, Es, gb); break;
+    case 1: ffp_ln<OT, 1, 4>(a, nrows, Ys, Es, gb); break;
+    default: ffp_ln_generic<OT, 8, 2>(a, nrows, Ys, Es); break;
+  }
+}
+
+template <typename OT>
 __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_job[2];
@@ -394,6 +589,10 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   }
   __syncthreads();
   if (!__builtin_amdgcn_readfirstlane(s_job[1])) return;
+  // LayerNorm's gamma / beta, once per launch (ffp_ln; embedding_dim <= FLN_MAX_E - larger ones take the generic form, which reads memory)
+  __shared__ __attribute__((aligned(16))) float s_gb[2 * FLN_MAX_E];
+  if (a.E <= FLN_MAX_E)
+    for (int c = tid; c < a.E; c += 512) { s_gb[c] = a.ln_g[c]; s_gb[FLN_MAX_E + c] = a.ln_b[c]; }
   const int q = xcc - a.xcd_lo, nf = 8 - a.xcd_lo;
   const int n_q = a.n_units > q ? (a.n_units - q + nf - 1) / nf : 0;         // units of this XCD: q, q + nf, ...
   // ticket k = job (k mod T) of super-round (k div T), T = sg (2 + nt1 + nt2): the sg units of a super-round go through each job kind
@@ -452,14 +651,15 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
     if (type == 0) {
       if (!(a.dbg & 1)) ffp_pack<OT>(a, row0, nrows, a.X + slot * a.kx);
     } else if (type == 1) {
+      if (!(a.dbg & 4))
       ffp_tile<OT, false>(smem, a.X + slot * a.kx, a.kx, nrows, a.w1 + (size_t)nb * 256 * a.ld_w1, a.ld_w1, a.b1 + nb * 256,
                           a.Y + slot * a.E + nb * 256, a.E, a.kx);
     } else if (type == 2) {
       if (a.dbg & 2) { }
-      else if (a.E <= 2048) ffp_ln<OT, 4, 4>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
-      else ffp_ln<OT, 8, 2>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E);
+      else ffp_ln_any<OT>(a, nrows, a.Y + slot * a.E, a.Eb + slot * a.E, s_gb);
     } else {
       const size_t gslot = (size_t)(u & (a.gi_ring_units - 1)) * 256;
+      if (!(a.dbg & 8))
       ffp_tile<OT, true>(smem, a.Eb + slot * a.E, a.E, nrows, a.w_ih + (size_t)nb * 256 * a.E, a.E, a.bias2 + nb * 256,
                          a.GI + gslot * a.n3 + nb * 256, a.n3, a.E);
     }

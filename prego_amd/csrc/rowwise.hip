@@ -117,7 +117,14 @@ __global__ __launch_bounds__(256) void ln_relu_rows_kernel(
     for (int i = 0; i < MAXV; ++i)
       if (i < nv) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const float d = v[i][k] - mu; q += d * d; }
+        for (int k = 0; k < 8; ++k) {
+          // the square is rounded before it is added (no fused multiply-add): the split pass's LayerNorm job (ff_pass.hip: ffp_ln) must
+          // reproduce this row bit for bit, and which of the two forms -ffp-contract=fast picks depends on the code around it
+#pragma clang fp contract(off)
+          const float d = v[i][k] - mu;
+          const float dd = d * d;
+          q = q + dd;
+        }
       }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)E + eps);
     if (stats && lane == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }

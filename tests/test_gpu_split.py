@@ -114,6 +114,54 @@ def test_split_pass_with_flow_16bit_features_logits_and_argmax_only(weights):
         assert torch.equal(a[i], ref_a[i]), i
 
 
+@pytest.mark.parametrize("dims", [(1024, 1024, 1024), (1088, 576, 512), (2048, 0, 1536), (0, 1024, 2048)],
+                         ids=["bninception_e1024", "odd_64s_e512", "rgb_only_e1536", "flow_only_e2048"])
+def test_split_pass_other_feature_and_embedding_sizes(dims):
+    """The row jobs of the feed-forward launch (pack, LayerNorm) at sizes other than the shipped 2 048 + 2 048 -> 2 048: sources that fill
+    part of a 2 048-column round or straddle a 512-column chunk (buffer accesses past the row's end return zeros / are dropped), a
+    missing stream, embedding_dim 512 / 1 024 (LDS gamma / beta) and 1 536 (the generic LayerNorm job) - bit for bit the chunked pass,
+    fp32 and 16-bit feature arrays, and a clip against the oracle."""
+    from prego_amd.engine import MiniRoadEngine
+    d_rgb, d_flow, emb = dims
+    C, H = 12, 1024
+    rng = np.random.default_rng(5)
+    din = d_rgb + d_flow
+    u = lambda shape, b: rng.uniform(-b, b, shape).astype(np.float32)
+    sd = {"gru.weight_ih_l0": u((3 * H, emb), 1 / 32), "gru.weight_hh_l0": u((3 * H, H), 1 / 32), "gru.bias_ih_l0": u((3 * H,), 1 / 32),
+          "gru.bias_hh_l0": u((3 * H,), 1 / 32), "layer1.0.weight": u((emb, din), din ** -0.5), "layer1.0.bias": u((emb,), din ** -0.5),
+          "layer1.1.weight": (1.0 + u((emb,), 0.25)), "layer1.1.bias": u((emb,), 0.1),
+          "f_classification.0.weight": 8.0 * u((C, H), 1 / 32), "f_classification.0.bias": u((C,), 1 / 32)}
+    lens = _lens(52, 5100, 5600, 31)
+    assert sum(lens) >= 262144 and sum(lens) % 256 != 0
+
+    def make(split):
+        def mk():
+            e = MiniRoadEngine(d_rgb, d_flow, emb, H, C, "cuda:0", "fp16")
+            e.set_weights({k: torch.from_numpy(v).cuda() for k, v in sd.items()})
+            return e
+        return _with_env("PREGO_SPLIT_PASS", split, mk)
+    e0, e3 = make("0"), make("3")
+    for fdt in (torch.float32, torch.float16):
+        rgb = [_feat((T, d_rgb), 3100 + i, fdt) for i, T in enumerate(lens)] if d_rgb else None
+        flow = [_feat((T, d_flow), 3900 + i, fdt) for i, T in enumerate(lens)] if d_flow else None
+        if rgb is None:                                     # --no_rgb models: the engine takes the flow stream alone
+            ref_o, ref_a, info = _run(e0, None, flow, softmax=True, want_out=True, want_argmax=True)
+        else:
+            ref_o, ref_a, info = _run(e0, rgb, flow, softmax=True, want_out=True, want_argmax=True)
+        assert info["mode"] == 0
+        for k in range(2):
+            o, a, info = _run(e3, rgb, flow, softmax=True, want_out=True, want_argmax=True)
+        assert info["mode"] == 3, info
+        for i in range(len(lens)):
+            assert torch.equal(o[i], ref_o[i]), (str(fdt), i)
+            assert torch.equal(a[i], ref_a[i]), (str(fdt), i)
+        if fdt == torch.float32:
+            i = int(np.argmin(lens))
+            streams = [x[i].cpu().numpy()[None] for x in (rgb, flow) if x is not None]      # a --no_rgb model's only stream is its first
+            ref = O.miniroad_forward(sd, streams[0], streams[1] if len(streams) > 1 else None)["logits"][0]
+            assert np.abs(o[i].cpu().numpy() - ref).max() < 3e-3
+
+
 def test_split_pass_is_chosen_per_call_and_falls_back(weights):
     """default handle (no PREGO_SPLIT_PASS): the library picks the pass per call - a cost model, corrected by what passes of either kind
     took on this device - so WHICH pass runs is not asserted for eligible calls (devices of the pool differ), only that every call agrees
