@@ -816,18 +816,34 @@ static void refresh_placement(prego_miniroad* h) {
 }
 
 // ---- split pass ----------------------------------------------------------------------------------------------------------------
-// Geometry: units of 256 packed rows; chunks of 64 units (16 384 rows) are what the two kernels tell each other about; X / Y / E rings
-// of 24 units (six super-rounds of four) per feed-forward XCD, a GI ring of 256 units = 4 chunks.  The rings come out of the caller's
-// workspace (0.9 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in a handle-owned buffer
-// (the head runs once, behind the pass).
-static const int kSplitGiRingUnits = 256, kSplitRingPerXcd = 24;   // ring: 12 super-rounds of 2 units
+// Geometry: units of 256 packed rows; chunks of 8 units (2 048 rows) are what the two kernels tell each other about; X / Y / E rings
+// of 24 units (twelve super-rounds of two) per feed-forward XCD, a GI ring of 32 units = 4 chunks.  The rings come out of the caller's
+// workspace (0.54 GB: they fit the default one), relu(h) + the row map of the whole pass and the counters live in the caller's resident
+// buffer (the head runs once, behind the pass).
+// (debug library: PREGO_SPLIT_GI_RING = a power of two of units, at least four chunks; PREGO_SPLIT_RING_PER_XCD = an even number of units
+// beyond the largest lag - sweeps of how much of the rings the 256 MB Infinity Cache can hold)
+static int tuned_pow2(const char* name, int dflt) {
+  const char* v = prego_tune_env(name);
+  const int x = v ? atoi(v) : 0;
+  return (x >= 16 && (x & (x - 1)) == 0) ? x : dflt;
+}
+// Round 6: a GI ring of 32 units (50 MB; 4 chunks of 8 units) instead of 256 (0.4 GB; 4 chunks of 64): same-device 91.7-92.0 against
+// 93.1 ms and 93.4 against 95.1-95.2 (profiles/r06_split_rings*.log).  The feed-forward launch may run 8 192 rows (~170 recurrence steps)
+// ahead instead of 65 536: what it has written and the recurrence has not yet read stays in the Infinity Cache, and so does more of its own
+// X -> Y -> E chain.  64 units: -0.5...-0.8 %; 32 units in chunks of 4: -1.0 %; 16 units or two chunks of 16: the launches wait for each
+// other (+0.4...+11 %).  The X / Y / E ring's size does not matter (16 / 24 / 32 units per XCD: +-0.1 %).
+// The rgb-only pass on 4 + 4 XCDs is bound by its feed-forward launch, not by the recurrence, and keeps the long ring (28.1-28.2 against
+// 27.8-28.0 M frames/s, profiles/r06_split_rings_zf.log).
+static int split_gi_ring_units(int R) { return tuned_pow2("PREGO_SPLIT_GI_RING", R <= 3 ? 32 : 256); }
+static const int kSplitRingPerXcd = (prego_tune_env("PREGO_SPLIT_RING_PER_XCD") && atoi(prego_tune_env("PREGO_SPLIT_RING_PER_XCD")) >= 12 &&
+                                     atoi(prego_tune_env("PREGO_SPLIT_RING_PER_XCD")) % 4 == 0) ? atoi(prego_tune_env("PREGO_SPLIT_RING_PER_XCD")) : 24;   // ring: 12 super-rounds of 2 units
 // units per super-round (debug library: sweep).  Round 6: 2 instead of 4.  ALONE the feed-forward launch is flat between 2 and 4 (93.0 / 92.3 ms,
 // round 5); IN THE PASS 2 is 1.0-1.2 % faster on every box and alternation (profiles/r06_split_knobs.log: 95.6-97.7 against 96.8-98.6 ms):
 // half the look-ahead in rows (lags 2 / 3 / 4 super-rounds = 4 / 6 / 8 units) keeps a unit's X -> Y -> E -> GI chain closer together in
 // the XCD's L2, and a weight slab is still shared by two row blocks.  1 (no sharing) runs the GEMM tiles at 0.75 of the rate: 127 ms.
 static const int kSplitSg = (prego_tune_env("PREGO_SPLIT_SG") && kSplitRingPerXcd % std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) == 0)
                                 ? std::max(1, atoi(prego_tune_env("PREGO_SPLIT_SG"))) : 2;
-static const int kSplitChunkUnitShift = prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT")) : 6;
+static int split_chunk_shift(int R) { return prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT") ? atoi(prego_tune_env("PREGO_SPLIT_CHUNK_SHIFT")) : (R <= 3 ? 3 : 6); }
 struct SplitRings { size_t x, y, e, gi, total; int ring_units; };
 static SplitRings split_rings(const prego_miniroad* h, int R) {
   SplitRings g;
@@ -835,7 +851,7 @@ static SplitRings split_rings(const prego_miniroad* h, int R) {
   g.x = align_up((size_t)g.ring_units * 256 * (size_t)(h->d_rgb + h->d_flow) * 2, 256);
   g.y = align_up((size_t)g.ring_units * 256 * (size_t)h->emb * 2, 256);
   g.e = g.y;
-  g.gi = align_up((size_t)kSplitGiRingUnits * 256 * (size_t)3 * h->hid * 2, 256);
+  g.gi = align_up((size_t)split_gi_ring_units(R) * 256 * (size_t)3 * h->hid * 2, 256);
   g.total = g.x + g.y + g.e + g.gi;
   return g;
 }
@@ -845,7 +861,8 @@ static bool split_workspace_ok(const prego_miniroad* h, int R, size_t workspace_
 // (prego_miniroad_resident_bytes / _set_resident); a buffer that is too small keeps the call on the chunked pass
 static size_t split_buf_need(const prego_miniroad* h, long long total) {
   const long long n_units = (total + 255) / 256;
-  const long long n_chunks = (n_units + (1 << kSplitChunkUnitShift) - 1) >> kSplitChunkUnitShift;
+  const int shift = split_chunk_shift(1);                       // the smallest chunk any R uses: the most counters
+  const long long n_chunks = (n_units + (1 << shift) - 1) >> shift;
   return align_up((size_t)total * h->hid * 2, 256) + align_up((size_t)total * 8, 256) + align_up(((size_t)4 * n_units + 2 * (size_t)n_chunks + 32) * 4, 256);
 }
 static bool split_resident_ok(const prego_miniroad* h, long long total) { return h->res_buf && split_buf_need(h, total) <= h->res_bytes; }
@@ -865,8 +882,9 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   const int H = h->hid, E = h->emb, din = h->d_rgb + h->d_flow;
   const int total = h->h_rowoff[h->t_max];
   const int n_units = (total + 255) / 256;
-  const int upc = 1 << kSplitChunkUnitShift;
-  const int n_chunks = (n_units + upc - 1) >> kSplitChunkUnitShift;
+  const int chunk_shift = split_chunk_shift(R), gi_ring = split_gi_ring_units(R);
+  const int upc = 1 << chunk_shift;
+  const int n_chunks = (n_units + upc - 1) >> chunk_shift;
   const SplitRings rg = split_rings(h, R);
   if (workspace_bytes < rg.total) return fail(PREGO_EWORKSPACE, "split pass: workspace %zu B < %zu B of rings", workspace_bytes, rg.total);
   char* wp = (char*)workspace;
@@ -913,8 +931,8 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   fa.d_rgb = h->d_rgb; fa.d_flow = with_flow ? h->d_flow : 0; fa.in16 = in16 ? 1 : 0; fa.kx = kx;
   fa.w1 = (const unsigned short*)h->w1; fa.ld_w1 = din; fa.b1 = h->b1; fa.ln_g = h->ln_g; fa.ln_b = h->ln_b; fa.ln_eps = 1e-5f;
   fa.w_ih = (const unsigned short*)h->w_ih_perm; fa.bias2 = h->bias2_perm; fa.E = E; fa.n3 = 3 * H;      // permuted rows: GI rows in (unit pair, gate) order
-  fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = kSplitGiRingUnits;
-  fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = kSplitChunkUnitShift;
+  fa.X = X; fa.Y = Y; fa.Eb = Eb; fa.GI = GI; fa.ring_units = rg.ring_units; fa.gi_ring_units = gi_ring;
+  fa.total_rows = total; fa.n_units = n_units; fa.xcd_lo = R; fa.chunk_unit_shift = chunk_shift;
   fa.rec_expect = R * h->P * 4; fa.nt1 = E / 256; fa.nt2 = 3 * H / 256;
   static const int lag1 = prego_tune_env("PREGO_SPLIT_LAG1") ? atoi(prego_tune_env("PREGO_SPLIT_LAG1")) : 2;
   static const int lag2 = prego_tune_env("PREGO_SPLIT_LAG2") ? atoi(prego_tune_env("PREGO_SPLIT_LAG2")) : 3;
@@ -941,8 +959,8 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   ga.n_clips = h->n_slots; ga.G = h->G; ga.seg_off = h->plan_single ? nullptr : h->d_seg_off;
   ga.seg_start = h->plan_single ? nullptr : h->d_seg_start; ga.stamps = (h->use_stamps && !want_stats) ? h->stamps : nullptr;
   ga.sync = h->flags; ga.armed = 0; ga.Gd = R;
-  ga.gi_cnt = gi_cnt; ga.rec_cnt = rec_cnt; ga.chunk_shift = kSplitChunkUnitShift + 8; ga.n_chunks = n_chunks;
-  ga.units_per_chunk = upc; ga.units_last = n_units - upc * (n_chunks - 1); ga.gi_row_mask = (unsigned)kSplitGiRingUnits * 256u - 1u;
+  ga.gi_cnt = gi_cnt; ga.rec_cnt = rec_cnt; ga.chunk_shift = chunk_shift + 8; ga.n_chunks = n_chunks;
+  ga.units_per_chunk = upc; ga.units_last = n_units - upc * (n_chunks - 1); ga.gi_row_mask = (unsigned)gi_ring * 256u - 1u;
   ga.hs = hs;
 
   // the feed-forward launch goes to the side stream (another hardware queue: it must be resident TOGETHER with the recurrence), forked
