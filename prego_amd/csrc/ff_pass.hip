@@ -422,13 +422,8 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 8;
-#ifdef FFP_LN_GB_GLOBAL
-      const float4 g0 = *(const float4*)(a.ln_g + c), g1 = *(const float4*)(a.ln_g + c + 4);
-      const float4 b0 = *(const float4*)(a.ln_b + c), b1 = *(const float4*)(a.ln_b + c + 4);
-#else
       const float4 g0 = *(const float4*)(gb + c), g1 = *(const float4*)(gb + c + 4);
       const float4 b0 = *(const float4*)(gb + FLN_MAX_E + c), b1 = *(const float4*)(gb + FLN_MAX_E + c + 4);
-#endif
       const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -444,11 +439,7 @@ __device__ __forceinline__ void ffp_ln(const FfPassArgs& a, int nrows, const bf1
     }
   };
   constexpr int STEP = 8 * NR;
-#ifdef FFP_LN_NOFENCE
-#define LN_FENCE()
-#else
 #define LN_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
   u32x4 ra[NR][NV], rbuf[NR][NV];
   int rb = wave;
   request(ra, rb); LN_FENCE();
@@ -563,9 +554,6 @@ __device__ __forceinline__ void ffp_ln_generic(const FfPassArgs& a, int nrows, c
 
 template <typename OT>
 __device__ __forceinline__ void ffp_ln_any(const FfPassArgs& a, int nrows, const bf16_t* __restrict__ Ys, bf16_t* __restrict__ Es, const float* gb) {
-#ifdef FFP_LN_GENERIC                                              // A/B builds (scripts/build_alt.sh): every embedding_dim on the generic job
-  ffp_ln_generic<OT, 8, 2>(a, nrows, Ys, Es); return;
-#endif
   switch (a.E >> 9) {                                            // E / 512 (launch_ff_pass: E % 512 == 0, E <= 4096)
     case 4: ffp_ln<OT, 4, 2>(a, nrows, Ys, Es, gb); break;      // the shipped embedding_dim
     case 2: ffp_ln<OT, 2, 4>(a, nrows, Ys, Es, gb); break;
