@@ -420,7 +420,7 @@ int prego_attention_layer_backward(prego_attn_layer* h, int batch, int len, int 
  *   PREGO_NO_XCD_OVERLAP  no layer1 worker on the XCDs a thinned-out recurrence has left (the serial chunked pass)            tests/test_gpu_fullsize.py
  *   PREGO_GRU_NO_LOCAL    never the XCD-local hand-off of the recurrence (sc1 stores / loads everywhere)                      tests/test_gpu_miniroad.py
  *   PREGO_GRU_NO_MT       multi-tile steps on the classic recurrence kernel                                                   tests/test_gpu_fullsize.py
- * Every tuning / calibration / diagnostic knob (PREGO_SPLIT_LAG1..3, PREGO_SPLIT_CHUNK_SHIFT, PREGO_SPLIT_STATS, PREGO_PLAN_SLOTS,
+ * Every tuning / calibration / diagnostic knob (PREGO_SPLIT_LAG1..3, PREGO_SPLIT_CHUNK_SHIFT, PREGO_SPLIT_GI_RING, PREGO_SPLIT_STATS, PREGO_PLAN_SLOTS,
  * PREGO_SIDE_PRIO, PREGO_PACK_*, PREGO_GRU_STAMPS, PREGO_GRU_MT_SPEC, PREGO_GEMM_NO_*, PREGO_HEAD_V1, PREGO_ATTN_NW, ...) is read by
  * libprego_amd_debug.so ONLY (csrc/kernels.h: prego_tune_env returns NULL in this library), like the probe / unit-test entry points
  * (prego_debug_*, prego_miniroad_debug_stamps: include/prego_amd_debug.h; the same sources built with -DPREGO_DEBUG_ABI). */
