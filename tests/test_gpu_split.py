@@ -144,6 +144,8 @@ def test_split_pass_other_feature_and_embedding_sizes(dims):
     for fdt in (torch.float32, torch.float16):
         rgb = [_feat((T, d_rgb), 3100 + i, fdt) for i, T in enumerate(lens)] if d_rgb else None
         flow = [_feat((T, d_flow), 3900 + i, fdt) for i, T in enumerate(lens)] if d_flow else None
+        if flow is not None and d_rgb and dims[2] == 1024:                 # some clips without a flow array (= zeros, datasets/dataset.py:69):
+            flow = [None if i % 5 == 2 else f for i, f in enumerate(flow)]  # a missing row is a buffer resource of length 0
         if rgb is None:                                     # --no_rgb models: the engine takes the flow stream alone
             ref_o, ref_a, info = _run(e0, None, flow, softmax=True, want_out=True, want_argmax=True)
         else:
@@ -157,7 +159,7 @@ def test_split_pass_other_feature_and_embedding_sizes(dims):
             assert torch.equal(a[i], ref_a[i]), (str(fdt), i)
         if fdt == torch.float32:
             i = int(np.argmin(lens))
-            streams = [x[i].cpu().numpy()[None] for x in (rgb, flow) if x is not None]      # a --no_rgb model's only stream is its first
+            streams = [(x[i].cpu().numpy() if x[i] is not None else np.zeros((lens[i], d_flow), np.float32))[None] for x in (rgb, flow) if x is not None]
             ref = O.miniroad_forward(sd, streams[0], streams[1] if len(streams) > 1 else None)["logits"][0]
             assert np.abs(o[i].cpu().numpy() - ref).max() < 3e-3
 
