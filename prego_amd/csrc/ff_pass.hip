@@ -572,8 +572,9 @@ __global__ __launch_bounds__(512, 2) void ff_pass_kernel(FfPassArgs a) {
   // start handshake (kernels.h: PassHandshake): nothing is read or written before the recurrence's leader has seen both launches resident;
   // a bounded wait that runs out ends BOTH launches before either has touched memory (the host then runs the chunked pass)
   if (tid == 0) {
-    __hip_atomic_fetch_add(a.hs.ff_here + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned nth = __hip_atomic_fetch_add(a.hs.ff_here + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_job[1] = hs_wait(a.hs, a.hs.ticks_all) == PREGO_HS_GO ? 1 : 0;
+    if (a.max_wg > 0 && (int)nth >= a.max_wg) s_job[1] = 0;        // debug library: this XCD runs with fewer workgroups (contention experiments)
   }
   __syncthreads();
   if (!__builtin_amdgcn_readfirstlane(s_job[1])) return;

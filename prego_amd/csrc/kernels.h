@@ -110,6 +110,7 @@ struct FfPassArgs {
   int rec_expect;               // recurrence waves that signal a chunk (groups x P x 4)
   int nt1, nt2;                 // tiles per unit of the two GEMMs (E / 256, 3H / 256)
   int sg;                       // units per super-round of an XCD's ticket order
+  int max_wg;                   // debug library (PREGO_SPLIT_FF_CUS): workgroups per feed-forward XCD that take jobs (0 = all 32); the others leave after the handshake
   int lag1, lag2, lag3;         // super-rounds between PACK and L1 / LN / WIH of a unit
   int dbg;                      // timing experiments only (PREGO_SPLIT_DBG; wrong results): 1 skip the pack copies, 2 skip the LayerNorm rows, 4 / 8 skip the layer1 / W_ih tiles
   unsigned long long* stats;    // debug, nullable: [8] 10 ns tick sums (pack, l1, ln, wih, waits, ticket), [6] shader-clock cycles and [7] ticks of the workgroups' lifetime

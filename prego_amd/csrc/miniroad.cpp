@@ -939,6 +939,8 @@ static int forward_split(prego_miniroad* h, int R, int flags, bool with_flow, bo
   static const int lag3 = prego_tune_env("PREGO_SPLIT_LAG3") ? atoi(prego_tune_env("PREGO_SPLIT_LAG3")) : 4;
   static const bool want_stats = prego_tune_env("PREGO_SPLIT_STATS") != nullptr;
   fa.sg = kSplitSg; fa.lag1 = lag1; fa.lag2 = lag2; fa.lag3 = lag3; fa.f16 = h->f16 ? 1 : 0;
+  static const int ff_cus = prego_tune_env("PREGO_SPLIT_FF_CUS") ? atoi(prego_tune_env("PREGO_SPLIT_FF_CUS")) : 0;        // debug library only
+  fa.max_wg = ff_cus;
   fa.stats = want_stats ? h->stamps : nullptr;
 #ifdef PREGO_DEBUG_ABI
   static const int dbg = prego_tune_env("PREGO_SPLIT_DBG") ? atoi(prego_tune_env("PREGO_SPLIT_DBG")) : 0;     // timing experiments (wrong results): debug library only
